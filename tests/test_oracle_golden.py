@@ -1,0 +1,166 @@
+"""Pin the CPU oracle (oracle/pybold_oracle.py) to golden vectors captured
+from the real reference by tests/golden/make_golden.py.  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import pybold_oracle as orc
+
+TIGHT = dict(rtol=1e-11, atol=1e-12)
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-300)
+
+
+@pytest.mark.parametrize("name", ["case1", "case2"])
+def test_deconv_500_iterations(golden, name):
+    g = golden(name)
+    x, z, w, J, n_done, lip = orc.deconv_fixed_lbda(
+        g["y"], g["hrf"], float(g["lbda"]), nb_iter=int(g["nb_iter"]),
+        early_stopping=False, x0_power=g["x0"])
+    assert lip == pytest.approx(float(g["lipschitz"]), rel=1e-13)
+    assert n_done == 500
+    assert rel(w, g["diff_z"]) < 1e-12
+    assert rel(z, g["z"]) < 1e-12
+    assert rel(x, g["x"]) < 1e-12      # causal conv == reference's FFT conv
+    np.testing.assert_allclose(J, g["J"], rtol=1e-11)
+
+
+def test_known_answers_case1(golden):
+    """Scalars quoted in SURVEY.md §8(c) case 1."""
+    g = golden("case1")
+    assert float(g["lipschitz"]) == pytest.approx(723876.2744579345, rel=1e-12)
+    assert np.linalg.norm(g["diff_z"]) == pytest.approx(6.832817291243165e-01, rel=1e-12)
+    assert np.abs(g["diff_z"]).sum() == pytest.approx(9.360762523738066, rel=1e-12)
+    assert g["J"][-1] == pytest.approx(4.711232148913732e-01, rel=1e-12)
+
+
+def test_grid_lambda_seed_iterations(golden):
+    g = golden("grid")
+    hrf = g["hrf"]
+    for seed in range(4):
+        y, x0 = g["y_s%d" % seed], g["x0_s%d" % seed]
+        for lbda in (0.1, 1.0, 10.0):
+            for nit in (1, 2, 3, 10, 500):
+                key = "s%d_l%g_n%d" % (seed, lbda, nit)
+                x, z, w, J, n_done, lip = orc.deconv_fixed_lbda(
+                    y, hrf, lbda, nb_iter=nit, early_stopping=False, x0_power=x0)
+                assert lip == pytest.approx(float(g["lip_s%d" % seed]), rel=1e-13)
+                assert rel(w, g["dz_" + key]) < 1e-12, key
+                np.testing.assert_allclose(J, g["J_" + key], rtol=1e-11)
+
+
+def test_batched_residual_form_matches_reference(golden):
+    """The batched matrix-free recurrence the HIP solver is compared with."""
+    g = golden("grid")
+    hrf = g["hrf"]
+    Y = np.stack([g["y_s%d" % s] for s in range(4)])
+    lip = float(g["lip_s0"])
+    for s in range(1, 4):   # rho does not depend on the start vector
+        assert float(g["lip_s%d" % s]) == pytest.approx(lip, rel=1e-9)
+    for lbda in (0.1, 1.0, 10.0):
+        for nit in (1, 2, 3, 10, 500):
+            W = orc.fista_batch(Y, hrf, lbda, 1.0 / lip, nit)
+            for s in range(4):
+                ref = g["dz_s%d_l%g_n%d" % (s, lbda, nit)]
+                assert rel(W[s], ref) < 1e-8, (s, lbda, nit)
+
+
+def test_early_stopping(golden):
+    g = golden("early_stop")
+    for tol, n_ref in ((0.1, 26), (0.03, 77), (0.01, 191), (0.005, 311)):
+        assert int(g["n_%g" % tol]) == n_ref
+        x, z, w, J, n_done, _ = orc.deconv_fixed_lbda(
+            g["y"], g["hrf"], 1.0, nb_iter=1000, early_stopping=True, tol=tol,
+            wind=6, x0_power=g["x0"])
+        assert n_done == n_ref
+        assert rel(w, g["dz_%g" % tol]) < 1e-12
+        assert rel(x, g["x_%g" % tol]) < 1e-12
+    assert int(g["n_default"]) == 1000    # default tol=1e-6 never triggers
+
+
+def test_loops_deconv(golden):
+    g = golden("loops_deconv")
+    y, h = g["y"], g["h"]
+    H = orc.toeplitz_from_kernel(h, len(y), len(y))
+    for nit in (1, 2, 5, 100):
+        for es_on, tol in ((False, 1e-12), (True, 1e-2), (True, 1e-3)):
+            w = orc.loops_deconv(y, np.zeros_like(y), H, 1.7, nit, es_on, 4, tol)
+            ref = g["w_n%d_es%d_tol%g" % (nit, es_on, tol)]
+            assert rel(w, ref) < 1e-12, (nit, es_on, tol)
+    w = orc.loops_deconv(y, g["w0"], H, 1.7, 5, False, 4, 1e-12)
+    assert rel(w, g["w_warm_n5"]) < 1e-12
+    # the same recurrence through the matrix-free batched form, Frobenius step
+    lip = orc.gram_lipschitz(h, len(y))
+    W = orc.fista_batch(y[None], h, 1.7, 1.0 / lip, 100)
+    assert rel(W[0], g["w_n100_es0_tol1e-12"]) < 1e-9
+
+
+def test_bd_five_outer_iterations(golden):
+    g = golden("bd")
+    x, z, w, h, d = orc.bd(g["y"], float(g["t_r"]), lbda=float(g["lbda"]),
+                           hrf_dur=float(g["hrf_dur"]), nb_iter=int(g["nb_iter"]))
+    # theta-step = L-BFGS-B with finite differences: pinned to 1e-6 only
+    np.testing.assert_allclose(d["J"], g["J"], rtol=1e-6)
+    np.testing.assert_allclose(d["r"], g["r"], rtol=1e-6)
+    assert rel(h, g["h"]) < 1e-5
+    assert rel(w, g["diff_z"]) < 1e-4
+    assert rel(x, g["x"]) < 1e-5
+
+
+def test_hrf_fit_err_and_estim(golden):
+    g = golden("hrf_estim")
+    t_r, dur = float(g["t_r"]), float(g["hrf_dur"])
+    for theta, err in zip(g["thetas"], g["errs"]):
+        assert orc.hrf_fit_err(theta, g["z"], g["y"], t_r, dur) == pytest.approx(err, rel=1e-10)
+    h, J = orc.hrf_estim(g["z"], g["y"], t_r, dur)
+    assert rel(h, g["h"]) < 1e-6
+
+
+def test_operator_known_answers(golden):
+    g = golden("operators")
+    for tag in "abcde":
+        k, x = g[tag + "_k"], g[tag + "_x"]
+        n = len(x)
+        H = orc.DenseH(k, n, n)
+        np.testing.assert_allclose(H.op(x), g[tag + "_op"], **TIGHT)
+        np.testing.assert_allclose(H.adj(x), g[tag + "_adj"], **TIGHT)
+        np.testing.assert_allclose(orc.integ_op(x), g[tag + "_integ_op"], **TIGHT)
+        np.testing.assert_allclose(orc.integ_adj(x), g[tag + "_integ_adj"], **TIGHT)
+        np.testing.assert_allclose(orc.simple_convolve(k, x), g[tag + "_conv"], **TIGHT)
+        np.testing.assert_allclose(orc.simple_retro_convolve(k, x), g[tag + "_retro"], **TIGHT)
+        np.testing.assert_allclose(orc.causal_conv(k, x), g[tag + "_conv"], **TIGHT)
+        np.testing.assert_allclose(orc.causal_corr(k, x), g[tag + "_retro"], **TIGHT)
+        # batched operator forms agree with the 1-D ones
+        X = np.stack([x, 2 * x])
+        np.testing.assert_allclose(H.op(X)[1], 2 * g[tag + "_op"], **TIGHT)
+        np.testing.assert_allclose(H.adj(X)[1], 2 * g[tag + "_adj"], **TIGHT)
+    # the reference's FFT forms equal the causal truncated forms at the hot
+    # path's sizes (a: N=300,K=30; b: N=240,K=27; c: N=600,K=30)
+    for tag in "abc":
+        assert np.abs(g[tag + "_spec"] - g[tag + "_conv"]).max() < 1e-11
+        assert np.abs(g[tag + "_spec_retro"] - g[tag + "_retro"]).max() < 1e-11
+    T = orc.toeplitz_from_kernel(g["rect_sig"], len(g["rect_k"]), len(g["rect_sig"]))
+    np.testing.assert_array_equal(T, g["rect_T"])
+    np.testing.assert_allclose(T.dot(g["rect_k"]), g["rect_conv"], **TIGHT)
+    np.testing.assert_array_equal(orc.toeplitz_from_kernel(np.arange(1., 5.), 6, 6),
+                                  g["toep_small"])
+
+
+def test_spm_hrf_values(golden):
+    g = golden("spm_hrf")
+    for i in range(6):
+        delta, t_r, dur, norm = g["p%d" % i]
+        h, t = orc.spm_hrf(delta, t_r=t_r, dur=dur, normalized_hrf=bool(norm))
+        np.testing.assert_allclose(h, g["h%d" % i], rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(t, g["t%d" % i], rtol=1e-13)
+    with pytest.raises(ValueError):
+        orc.spm_hrf(2.5)
+
+
+def test_adjointness():
+    rng = np.random.RandomState(0)
+    k = rng.randn(30)
+    a, b = rng.randn(300), rng.randn(300)
+    H = orc.DenseH(k, 300, 300)
+    assert np.dot(H.op(a), b) == pytest.approx(np.dot(a, H.adj(b)), rel=1e-10)
