@@ -1,0 +1,144 @@
+/*
+ * pybold_hip.h -- C ABI of the MI355X (gfx950) implementation of pyBOLD's
+ * deconvolution hot path.
+ *
+ * The reference (hcherkaoui/pybold) has no FFI: its "plugin surface" is Python
+ * duck typing (objects with .op(x)/.adj(x)) and plain functions on 1-D NumPy
+ * arrays.  Each entry point below therefore cites the reference *Python*
+ * interface it stands in for (file:line in the reference checkout); the
+ * binding a maintainer would add on the reference side is the ctypes stub in
+ * INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer named *_dev is a DEVICE pointer (HBM of the current HIP
+ *     device); pointers named *_host are host pointers read synchronously
+ *     before the call returns; nothing else is dereferenced on the host;
+ *   - matrices are row-major, one row per problem ("voxel"), leading dimension
+ *     ld* counted in ELEMENTS;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *     all work is enqueued asynchronously on it, nothing is allocated, no
+ *     synchronisation is performed (graph-capture safe);
+ *   - return value 0 = success; a negative value = error, text available from
+ *     pb_last_error() (thread-local).  No entry point ever falls back to a
+ *     CPU computation.
+ */
+#ifndef PYBOLD_HIP_H
+#define PYBOLD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PB_OK 0
+#define PB_ERR_INVALID (-1)   /* bad argument (shape, NULL pointer, size limit) */
+#define PB_ERR_HIP (-2)       /* HIP runtime error at launch */
+
+/* flags for pb_fista_solve */
+#define PB_FLAG_FORCE_GENERIC 1u  /* use the any-size LDS kernel even when a
+                                     register-resident specialisation exists */
+#define PB_FLAG_FORCE_FAST 2u     /* fail instead of using the generic kernel */
+
+/* early-stop rules (evaluated per problem, inside the kernel) */
+#define PB_STOP_NONE 0
+#define PB_STOP_LOOPS 1   /* _loops_deconv rule, pybold/bold_signal.py:267-273 */
+#define PB_STOP_WINDOW 2  /* deconv windowed rule, pybold/bold_signal.py:82-95 */
+
+/* Library version (major*10000 + minor*100 + patch). */
+int pb_version(void);
+
+/* Text of the last error on the calling thread ("" if none). */
+const char* pb_last_error(void);
+
+/* 1 if a register-resident specialisation exists for (N scans, K taps),
+ * else 0 (the generic kernel is used).  Host-only query. */
+int pb_fista_has_fast_path(int N, int K);
+
+/*
+ * Fused FISTA-like solver: n_iter iterations of the recurrence of
+ *   deconv (fixed-lambda loop)   pybold/bold_signal.py:62-72
+ *   _loops_deconv                pybold/bold_signal.py:259-276
+ * for P independent problems in ONE launch, state resident on chip:
+ *
+ *   u = w - step * H^T (H w - y)      H = toeplitz(taps) . cumsum
+ *   p = soft(u, lbda_p * step)        pybold/linear.py:73-113, convolution.py:105-132
+ *   w = p + beta_k (p - u)            (beta_0 = 0; see SURVEY.md 8a for the aliasing)
+ *
+ * y_dev      float32 [ceil(P / y_rep)][ldy]: observed series; problem p reads
+ *            row p / y_rep (y_rep > 1 = several lambdas per voxel).
+ * w_dev      float64 [P][ldw]: in = warm start (w_0), out = final iterate.
+ * taps_host  float64 [K]: HRF taps (shared by all problems), host copy: the
+ *            register-resident kernel receives them as kernel arguments.
+ * taps_dev   the same taps in device memory (used by the generic LDS kernel;
+ *            may be NULL when pb_fista_has_fast_path(N, K) and the stop rule is
+ *            not PB_STOP_WINDOW).
+ * step       1/L, L = 0.9*rho (deconv, :52-53) or ||A^T A||_F (_loops_deconv, :253-254).
+ * lbda, lbda_dev  regularisation: per-problem float64 [P] if lbda_dev != NULL,
+ *            else the scalar.
+ * betas_dev  float64 [n_iter]: momentum factors (t_k - 1)/t_{k+1} for the
+ *            iterations of THIS launch (:68-69).
+ * J_dev      optional float32 [P][ldj], ldj >= n_iter: un-normalised cost
+ *            0.5||H w_{k+1} - y||^2 + lbda ||w_{k+1}||_1 after each iteration (:74-77).
+ * stop_mode, tol, wind, n_done_dev: optional per-problem early stopping
+ *            (PB_STOP_*); n_done_dev int32 [P] receives the number of
+ *            iterations executed.  PB_STOP_NONE ignores tol/wind; n_done_dev
+ *            may be NULL.
+ */
+int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep,
+                   double* w_dev, int64_t ldw, int P, int N,
+                   const double* taps_host, const double* taps_dev, int K,
+                   double step, double lbda, const double* lbda_dev,
+                   const double* betas_dev, int n_iter,
+                   float* J_dev, int64_t ldj,
+                   int stop_mode, double tol, int wind, int32_t* n_done_dev,
+                   unsigned flags, void* stream);
+
+/*
+ * z = cumsum(w), x = taps * z (causal, truncated): the outputs deconv returns
+ * next to diff_z (pybold/bold_signal.py:74-75,97).  float64 in, float64 out.
+ * Either output pointer may be NULL.
+ */
+int pb_fista_outputs(const double* w_dev, int64_t ldw, int P, int N,
+                     const double* taps_dev, int K,
+                     double* z_dev, int64_t ldz, double* x_dev, int64_t ldx,
+                     void* stream);
+
+/*
+ * Operator surface (float64, any size that fits LDS: 3*max(n_in,n_out)+K <= 20000).
+ * All of them act row-wise on V rows.
+ *
+ * pb_integ_op / pb_integ_adj   DiscretInteg.op / .adj      pybold/linear.py:15-43
+ * pb_conv                      toeplitz_from_kernel(k, n_in, n_out) @ x
+ *                                                          pybold/convolution.py:105-132
+ * pb_corr                      toeplitz_from_kernel(k, n_in, n_out).T @ r
+ * pb_op_forward / pb_op_adjoint  ConvAndLinear(DiscretInteg(), k, n_in, n_out).op / .adj
+ *                                                          pybold/linear.py:73-113
+ */
+int pb_integ_op(const double* x_dev, int64_t ldx, double* out_dev, int64_t ldo,
+                int V, int N, void* stream);
+int pb_integ_adj(const double* x_dev, int64_t ldx, double* out_dev, int64_t ldo,
+                 int V, int N, void* stream);
+int pb_conv(const double* x_dev, int64_t ldx, double* out_dev, int64_t ldo,
+            int V, int n_in, int n_out, const double* taps_dev, int K, void* stream);
+int pb_corr(const double* r_dev, int64_t ldr, double* out_dev, int64_t ldo,
+            int V, int n_in, int n_out, const double* taps_dev, int K, void* stream);
+int pb_op_forward(const double* x_dev, int64_t ldx, double* out_dev, int64_t ldo,
+                  int V, int n_in, int n_out, const double* taps_dev, int K, void* stream);
+int pb_op_adjoint(const double* r_dev, int64_t ldr, double* out_dev, int64_t ldo,
+                  int V, int n_in, int n_out, const double* taps_dev, int K, void* stream);
+
+/*
+ * Per-voxel HRF fit error  cost[v] = 0.5 || y_v - taps * z_v ||^2
+ * (hrf_fit_err, pybold/bold_signal.py:217-222) for n_hrf candidate HRFs at
+ * once: taps_dev float64 [n_hrf][K], cost_dev float64 [n_hrf][V].  The caller
+ * sums over voxels (and all-reduces over ranks) for the shared-HRF step.
+ */
+int pb_hrf_cost(const double* z_dev, int64_t ldz, const float* y_dev, int64_t ldy,
+                int V, int N, const double* taps_dev, int K, int n_hrf,
+                double* cost_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYBOLD_HIP_H */

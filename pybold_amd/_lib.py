@@ -1,0 +1,83 @@
+"""ctypes binding of ``libpybold_hip.so`` (C ABI in ``include/pybold_hip.h``).
+
+There is no CPU fallback: if the shared library is missing or a call fails the
+caller gets an exception.  Build the library with ``python -c "import
+__graft_entry__ as g; g.build()"`` or ``make -C pybold_amd/csrc``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpybold_hip.so")
+
+PB_FLAG_FORCE_GENERIC = 1
+PB_FLAG_FORCE_FAST = 2
+PB_STOP_NONE = 0
+PB_STOP_LOOPS = 1
+PB_STOP_WINDOW = 2
+
+_c_int = ctypes.c_int
+_c_i64 = ctypes.c_int64
+_c_dbl = ctypes.c_double
+_ptr = ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/pybold_hip.h one to one
+SIGNATURES = {
+    "pb_version": (_c_int, []),
+    "pb_last_error": (ctypes.c_char_p, []),
+    "pb_fista_has_fast_path": (_c_int, [_c_int, _c_int]),
+    "pb_fista_solve": (_c_int, [
+        _ptr, _c_i64, _c_int,            # y_dev, ldy, y_rep
+        _ptr, _c_i64, _c_int, _c_int,    # w_dev, ldw, P, N
+        _ptr, _ptr, _c_int,              # taps_host, taps_dev, K
+        _c_dbl, _c_dbl, _ptr,            # step, lbda, lbda_dev
+        _ptr, _c_int,                    # betas_dev, n_iter
+        _ptr, _c_i64,                    # J_dev, ldj
+        _c_int, _c_dbl, _c_int, _ptr,    # stop_mode, tol, wind, n_done_dev
+        ctypes.c_uint, _ptr]),           # flags, stream
+    "pb_fista_outputs": (_c_int, [_ptr, _c_i64, _c_int, _c_int, _ptr, _c_int,
+                                  _ptr, _c_i64, _ptr, _c_i64, _ptr]),
+    "pb_integ_op": (_c_int, [_ptr, _c_i64, _ptr, _c_i64, _c_int, _c_int, _ptr]),
+    "pb_integ_adj": (_c_int, [_ptr, _c_i64, _ptr, _c_i64, _c_int, _c_int, _ptr]),
+    "pb_conv": (_c_int, [_ptr, _c_i64, _ptr, _c_i64, _c_int, _c_int, _c_int,
+                         _ptr, _c_int, _ptr]),
+    "pb_corr": (_c_int, [_ptr, _c_i64, _ptr, _c_i64, _c_int, _c_int, _c_int,
+                         _ptr, _c_int, _ptr]),
+    "pb_op_forward": (_c_int, [_ptr, _c_i64, _ptr, _c_i64, _c_int, _c_int,
+                               _c_int, _ptr, _c_int, _ptr]),
+    "pb_op_adjoint": (_c_int, [_ptr, _c_i64, _ptr, _c_i64, _c_int, _c_int,
+                               _c_int, _ptr, _c_int, _ptr]),
+    "pb_hrf_cost": (_c_int, [_ptr, _c_i64, _ptr, _c_i64, _c_int, _c_int, _ptr,
+                             _c_int, _c_int, _ptr, _ptr]),
+}
+
+_lib = None
+
+
+class PyboldHipError(RuntimeError):
+    """A libpybold_hip entry point returned an error code."""
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises if the HIP library has
+    not been built -- the product never computes on the CPU instead."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "pybold_amd: %s not found; build it with "
+                "`make -C pybold_amd/csrc` (hipcc, gfx950). There is no CPU "
+                "fallback." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)      # AttributeError if a symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().pb_last_error().decode("utf-8", "replace")
+        raise PyboldHipError("%s failed (%d): %s" % (what or "libpybold_hip", rc, msg))

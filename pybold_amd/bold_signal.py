@@ -1,0 +1,211 @@
+"""Drop-in counterparts of ``pybold/bold_signal.py`` running on MI355X.
+
+Same function names, argument order, defaults and return tuples as the
+reference.  ``y`` may be 1-D (reference behaviour, NumPy in / NumPy float64 out)
+or a 2-D ``(V, N)`` batch of voxels solved in one kernel launch (the axis the
+reference fans out with joblib, examples/icassp_2019/simulation.py:62-72).
+
+Deviations from the reference, all deliberate:
+  * the fixed-lambda ``deconv`` does not print one line per iteration
+    (pybold/bold_signal.py:79-80 does, unconditionally);
+  * ``y`` is stored in float32 in HBM (the iterate and its update stay float64
+    on chip); outputs are float64 like the reference's;
+  * ``_loops_deconv`` does not overwrite the caller's ``diff_z`` (the reference
+    does at :261; every caller rebinds the returned array);
+  * ``deconv(lbda=None)`` (noise-driven lambda search, :99-214) needs the db3
+    wavelet noise estimate and is not implemented yet.
+There is no CPU fallback: without the HIP library or a GPU these raise.
+"""
+import numpy as np
+import torch
+from scipy.optimize import fmin_l_bfgs_b
+
+from . import solver
+from .convolution import kernel_from_toeplitz, toeplitz_from_kernel
+from .hrf_model import MAX_DELTA, MIN_DELTA, spm_hrf
+from .linear import ConvAndLinear, DiscretInteg
+from .utils import gram_frobenius, spectral_radius_est
+
+
+def _y_to_device(y):
+    """-> (float32 CUDA (V, N), one_d flag)"""
+    if torch.is_tensor(y):
+        one_d = y.dim() == 1
+        t = y.to(device=solver.device(y.device if y.is_cuda else None), dtype=torch.float32)
+    else:
+        a = np.asarray(y)
+        one_d = a.ndim == 1
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(solver.device())
+    return (t.reshape(1, -1) if one_d else t), one_d
+
+
+def _host(t, one_d):
+    a = t.cpu().numpy()
+    return a[0] if one_d else a
+
+
+def deconv(y, t_r, hrf, lbda=None, early_stopping=True, tol=1.0e-6,  # noqa
+           wind=6, nb_iter=1000, nb_sub_iter=1000, verbose=0):
+    """Deconvolve BOLD signal(s) ``y`` with the HRF ``hrf``
+    (pybold/bold_signal.py:13-97): ``min_w 0.5 ||h * cumsum(w) - y||^2 +
+    lbda ||w||_1`` by the reference's FISTA-like loop, constant step
+    ``1 / (0.9 rho)``.
+
+    Returns ``(x, z, diff_z, J, None, None)`` with ``J`` normalised by ``J[0]``.
+    For a 2-D ``y`` every output gains a leading voxel axis and ``J`` is
+    ``(V, max iterations run)`` padded with NaN after a voxel's early stop.
+    """
+    if lbda is None:
+        raise NotImplementedError(
+            "deconv(lbda=None): the noise-driven lambda search "
+            "(pybold/bold_signal.py:99-214) is not implemented in this build")
+    Y, one_d = _y_to_device(y)
+    n = Y.shape[1]
+    hrf = np.asarray(hrf, dtype=np.float64)
+    H = ConvAndLinear(DiscretInteg(), hrf, dim_in=n, dim_out=n)
+    grad_lipschitz_cst = 0.9 * spectral_radius_est(H, (n,))
+    step = 1.0 / grad_lipschitz_cst
+    W, J, n_done = solver.fista_solve(
+        Y, hrf, lbda, step, int(nb_iter), want_J=True,
+        stop="window" if early_stopping else None, tol=tol, wind=wind)
+    X, Z = solver.fista_outputs(W, hrf)
+    n_done = n_done.cpu().numpy()
+    J = J.cpu().numpy().astype(np.float64)[:, :max(int(n_done.max()), 1)]
+    J = J / (J[:, :1] + 1.0e-30)
+    if verbose > 0:
+        print("deconv: {0} voxel(s), {1} iteration(s), final normalised cost "
+              "{2:.6f}".format(Y.shape[0], int(n_done.max()),
+                               float(np.nanmean(J[np.arange(len(n_done)), n_done - 1]))))
+    if one_d:
+        return _host(X, True), _host(Z, True), _host(W, True), J[0, :n_done[0]], None, None
+    return _host(X, False), _host(Z, False), _host(W, False), J, None, None
+
+
+def hrf_fit_err(theta, z, y, t_r, hrf_dur):
+    """``0.5 || y - h(theta) * z ||^2`` (pybold/bold_signal.py:217-222); the
+    convolution and the reduction run on the GPU."""
+    theta = float(np.ravel(theta)[0])
+    h, _ = spm_hrf(theta, t_r, hrf_dur, False)
+    Y, _ = _y_to_device(y)
+    Z = torch.from_numpy(np.ascontiguousarray(np.atleast_2d(np.asarray(z, dtype=np.float64)))).to(Y.device)
+    return float(solver.hrf_cost(Z, Y, h).sum().item())
+
+
+class _Tracker:
+    """L-BFGS-B callback recording the cost (pybold/utils.py:28-45)."""
+
+    def __init__(self, f, args, verbose=0):
+        self.J, self.f, self.args, self.verbose, self.idx = [], f, list(args), verbose, 0
+
+    def __call__(self, x):
+        self.idx += 1
+        j = self.f(*([x] + self.args))
+        if self.verbose > 2:
+            print("At iterate {0}, tracked function = {1:.6f}".format(self.idx, j))
+        self.J.append(j)
+
+
+def hrf_estim(z, y, t_r, dur, verbose=0):
+    """HRF dilation fit for a known block signal (pybold/bold_signal.py:225-239)."""
+    args = (z, y, t_r, dur)
+    bounds = [(MIN_DELTA + 1.0e-1, MAX_DELTA - 1.0e-1)]
+    f_cost = _Tracker(hrf_fit_err, args, verbose)
+    theta, _, _ = fmin_l_bfgs_b(func=hrf_fit_err, x0=MAX_DELTA, args=args, bounds=bounds,
+                                approx_grad=True, callback=f_cost, maxiter=99999,
+                                pgtol=1.0e-12)
+    h, _ = spm_hrf(float(np.ravel(theta)[0]), t_r, dur, False)
+    return h, f_cost.J
+
+
+def _loops_deconv(y, diff_z, H, lbda, nb_iter, early_stopping, wind, tol):
+    """Inner FISTA loop of the blind solver (pybold/bold_signal.py:246-278):
+    warm start ``diff_z``, step ``1 / ||A^T A||_F`` with ``A = H tril(1)``.
+    ``H`` must be the causal Toeplitz matrix of an HRF (what ``bd`` passes);
+    the GPU works matrix-free from its first column.  Returns ``diff_z``."""
+    taps = kernel_from_toeplitz(H)
+    Y, one_d = _y_to_device(y)
+    n = Y.shape[1]
+    step = 1.0 / gram_frobenius(taps, n)
+    W0 = torch.from_numpy(np.ascontiguousarray(
+        np.atleast_2d(np.asarray(diff_z, dtype=np.float64)))).to(Y.device)
+    W, _, _ = solver.fista_solve(Y, taps, lbda, step, int(nb_iter), W0=W0,
+                                 stop="loops" if early_stopping else None, tol=tol, wind=wind)
+    return _host(W, one_d)
+
+
+def bd(y, t_r, lbda=1.0, theta_0=None, z_0=None, hrf_dur=20.0,  # noqa
+       bounds=None, nb_iter=100, nb_sub_iter=1000, nb_last_iter=10000,
+       print_period=50, early_stopping=False, wind=4, tol=1.0e-12, verbose=0):
+    """Blind deconvolution of one voxel (pybold/bold_signal.py:281-382):
+    alternate the GPU z-step (:func:`_loops_deconv`, ``nb_iter`` inner
+    iterations exactly like the reference's call at :324) with a bounded
+    L-BFGS-B fit of the HRF dilation ``theta`` on the GPU-evaluated cost.
+    ``nb_sub_iter`` and ``nb_last_iter`` are accepted and unused, as in the
+    reference.  Returns ``(x, z, diff_z, h, d)``."""
+    y = np.asarray(y).astype(np.float64)
+    n = len(y)
+    theta = MAX_DELTA if theta_0 is None else theta_0
+    h, _ = spm_hrf(theta, t_r, hrf_dur, False)
+
+    def outputs(w, h):
+        Wd = torch.from_numpy(np.ascontiguousarray(w[None])).to(solver.device())
+        X, Z = solver.fista_outputs(Wd, h)
+        return X.cpu().numpy()[0], Z.cpu().numpy()[0]
+
+    if z_0 is None:
+        diff_z, z, x = np.zeros_like(y), np.zeros_like(y), np.zeros_like(y)
+    else:
+        z_0 = np.asarray(z_0, dtype=np.float64)
+        diff_z = np.append(0, z_0[1:] - z_0[:-1])
+        z = z_0
+        x = solver.conv(torch.from_numpy(z[None].copy()).to(solver.device()), h).cpu().numpy()[0]
+    if bounds is None:
+        bounds = [(MIN_DELTA + 1.0e-1, MAX_DELTA - 1.0e-1)]
+
+    d = {}
+    r_0 = np.sum(np.square(x - y))
+    d['r'] = [1.0]
+    g_0 = np.sum(np.abs(diff_z))
+    d['g'] = [g_0]
+    j_0 = r_0 + lbda * g_0
+    d['J'] = [1.0]
+    d['l_alpha'] = []
+    if verbose > 0:
+        print("normalized global cost-function (init): {0:.6f}".format(d['J'][-1]))
+
+    for idx in range(nb_iter):
+        H = toeplitz_from_kernel(h, dim_in=n, dim_out=n)
+        diff_z = _loops_deconv(y, diff_z, H, lbda, nb_iter, early_stopping, wind, tol)
+        z = np.cumsum(diff_z)
+        args = (z, y, t_r, hrf_dur)
+        theta, _, _ = fmin_l_bfgs_b(func=hrf_fit_err, x0=theta, args=args, bounds=bounds,
+                                    approx_grad=True, maxiter=999, pgtol=1.0e-12)
+        h, _ = spm_hrf(float(np.ravel(theta)[0]), t_r, hrf_dur, False)
+        x, z = outputs(diff_z, h)
+        r = np.sum(np.square(x - y))
+        g = np.sum(np.abs(diff_z))
+        d['J'].append((r + lbda * g) / j_0 + 1.0e-30)
+        d['r'].append(r / r_0 + 1.0e-30)
+        d['g'].append(g)
+        if (verbose > 0) and ((idx + 1) % print_period == 0):
+            print("normalized global cost-function ({0:03d}/{1:03d}): "
+                  "{2:.6f}".format(idx + 1, nb_iter, d['J'][-1]))
+        if early_stopping and idx > wind:
+            sub_wind_len = int(wind / 2)
+            old_j = np.mean(d['J'][:-sub_wind_len])
+            new_j = np.mean(d['J'][-sub_wind_len:])
+            if (new_j - old_j) / new_j < tol:
+                break
+
+    H = toeplitz_from_kernel(h, dim_in=n, dim_out=n)
+    diff_z = _loops_deconv(y, diff_z, H, lbda, nb_iter, early_stopping, wind, tol)
+    x, z = outputs(diff_z, h)
+    r = np.sum(np.square(x - y))
+    g = np.sum(np.abs(diff_z))
+    d['J'].append((r + lbda * g) / j_0)
+    d['r'].append(r / r_0)
+    d['g'].append(g)
+    d['J'] = np.array(d['J'])
+    d['r'] = np.array(d['r'])
+    d['g'] = np.array(d['g'])
+    return x, z, diff_z, h, d

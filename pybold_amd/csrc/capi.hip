@@ -1,0 +1,198 @@
+// C ABI of libpybold_hip.so (see include/pybold_hip.h for the contract and the
+// reference interfaces each entry point replaces).
+#include "../../include/pybold_hip.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "fista_fast.h"
+#include "generic.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PB_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+  g_err[0] = 0;
+  return PB_OK;
+}
+
+constexpr int LDS_DOUBLES_MAX = 20000;  // 160 KB of LDS per workgroup
+
+// ---- register-resident specialisations --------------------------------------
+typedef int (*fast_launch_fn)(const pb::FistaArgs&, const double* taps, int K, bool with_j,
+                              int stop, hipStream_t);
+
+template <int S, int KT>
+int launch_fast(const pb::FistaArgs& a, const double* taps, int K, bool with_j, int stop,
+                hipStream_t st) {
+  const auto tp = pb::make_tap_pairs<KT>(taps, K);
+  const dim3 grid((unsigned)(((int64_t)a.P * 16 + 255) / 256)), block(256);
+  if (stop == PB_STOP_NONE) {
+    if (with_j) hipLaunchKernelGGL((pb::fista_fast_kernel<S, KT, true, 0>), grid, block, 0, st, a, tp);
+    else hipLaunchKernelGGL((pb::fista_fast_kernel<S, KT, false, 0>), grid, block, 0, st, a, tp);
+  } else {
+    if (with_j) hipLaunchKernelGGL((pb::fista_fast_kernel<S, KT, true, 1>), grid, block, 0, st, a, tp);
+    else hipLaunchKernelGGL((pb::fista_fast_kernel<S, KT, false, 1>), grid, block, 0, st, a, tp);
+  }
+  return check_launch("fista_fast_kernel");
+}
+
+struct FastEntry {
+  int S, KT;
+  fast_launch_fn fn;
+};
+
+#define PB_FAST(S, KT) {S, KT, &launch_fast<S, KT>}
+const FastEntry kFast[] = {
+#include "fast_table.inc"
+};
+#undef PB_FAST
+
+const FastEntry* pick_fast(int N, int K) {
+  const FastEntry* best = nullptr;
+  const int s_need = (N + 15) / 16;
+  for (const FastEntry& e : kFast) {
+    if (e.S < s_need || e.KT < K) continue;
+    if (!best || (int64_t)e.S * e.KT < (int64_t)best->S * best->KT) best = &e;
+  }
+  return best;
+}
+
+template <int KIND>
+int launch_op(const double* x, int64_t ldx, double* out, int64_t ldo, int V, int n_src, int n_dst,
+              const double* taps, int K, void* stream, const char* name) {
+  if (V < 0 || n_src < 1 || n_dst < 1 || K < 0 || !x || !out || (K > 0 && !taps))
+    return fail(PB_ERR_INVALID, "%s: bad argument", name);
+  if (ldx < n_src || ldo < n_dst) return fail(PB_ERR_INVALID, "%s: leading dimension too small", name);
+  const int nmax = n_src > n_dst ? n_src : n_dst;
+  if (2 * (int64_t)nmax + K + 8 > LDS_DOUBLES_MAX)
+    return fail(PB_ERR_INVALID, "%s: row of %d with %d taps exceeds LDS", name, nmax, K);
+  if (V == 0) return PB_OK;
+  const size_t lds = (size_t)(2 * nmax + K + 8) * sizeof(double);
+  hipLaunchKernelGGL((pb::op_kernel<KIND>), dim3(V), dim3(pb::GEN_THREADS), lds, (hipStream_t)stream,
+                     x, ldx, out, ldo, n_src, n_dst, taps, K);
+  return check_launch(name);
+}
+
+}  // namespace
+
+extern "C" {
+
+int pb_version(void) { return 100; }
+
+const char* pb_last_error(void) { return g_err; }
+
+int pb_fista_has_fast_path(int N, int K) { return (N >= 1 && K >= 1 && pick_fast(N, K)) ? 1 : 0; }
+
+int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, int64_t ldw, int P,
+                   int N, const double* taps_host, const double* taps_dev, int K, double step,
+                   double lbda,
+                   const double* lbda_dev, const double* betas_dev, int n_iter, float* J_dev,
+                   int64_t ldj, int stop_mode, double tol, int wind, int32_t* n_done_dev,
+                   unsigned flags, void* stream) {
+  if (!y_dev || !w_dev || !taps_host || (n_iter > 0 && !betas_dev))
+    return fail(PB_ERR_INVALID, "pb_fista_solve: NULL pointer");
+  if (P < 0 || N < 1 || K < 1 || n_iter < 0 || y_rep < 1)
+    return fail(PB_ERR_INVALID, "pb_fista_solve: bad size (P=%d N=%d K=%d n_iter=%d y_rep=%d)", P,
+                N, K, n_iter, y_rep);
+  if (ldy < N || ldw < N) return fail(PB_ERR_INVALID, "pb_fista_solve: leading dimension < N");
+  if (J_dev && ldj < n_iter) return fail(PB_ERR_INVALID, "pb_fista_solve: ldj < n_iter");
+  if (!(step > 0.0)) return fail(PB_ERR_INVALID, "pb_fista_solve: step must be positive");
+  if (stop_mode < PB_STOP_NONE || stop_mode > PB_STOP_WINDOW)
+    return fail(PB_ERR_INVALID, "pb_fista_solve: unknown stop_mode %d", stop_mode);
+  if (stop_mode == PB_STOP_WINDOW && wind < 2)
+    return fail(PB_ERR_INVALID, "pb_fista_solve: wind must be >= 2");
+  if (P == 0) return PB_OK;
+
+  pb::FistaArgs a;
+  a.y = y_dev; a.ldy = ldy; a.w = w_dev; a.ldw = ldw; a.lbda_vec = lbda_dev; a.betas = betas_dev;
+  a.J = J_dev; a.ldj = ldj; a.n_done = n_done_dev; a.step = step; a.lbda = lbda; a.tol = tol;
+  a.y_rep = y_rep; a.P = P; a.N = N; a.n_iter = n_iter; a.stop_mode = stop_mode;
+
+  const FastEntry* fe = (flags & PB_FLAG_FORCE_GENERIC) ? nullptr : pick_fast(N, K);
+  if (fe && stop_mode == PB_STOP_WINDOW) fe = nullptr;   // window rule: LDS kernel only
+  if (fe) return fe->fn(a, taps_host, K, J_dev != nullptr, stop_mode, (hipStream_t)stream);
+  if (flags & PB_FLAG_FORCE_FAST)
+    return fail(PB_ERR_INVALID, "pb_fista_solve: no register-resident kernel for N=%d K=%d stop=%d",
+                N, K, stop_mode);
+
+  // generic path (any N, K that fit LDS; all stop rules)
+  if (!taps_dev) return fail(PB_ERR_INVALID, "pb_fista_solve: taps_dev required for the generic kernel");
+  const int64_t nd = 3 * (int64_t)N + K + 2 * pb::GEN_WAVES +
+                     (stop_mode == PB_STOP_WINDOW ? (int64_t)wind * N : 0);
+  if (nd > LDS_DOUBLES_MAX)
+    return fail(PB_ERR_INVALID, "pb_fista_solve: N=%d K=%d wind=%d exceeds LDS", N, K, wind);
+  const size_t lds = (size_t)nd * sizeof(double);
+  if (J_dev)
+    hipLaunchKernelGGL((pb::fista_generic_kernel<true>), dim3(P), dim3(pb::GEN_THREADS), lds,
+                       (hipStream_t)stream, a, taps_dev, K, wind);
+  else
+    hipLaunchKernelGGL((pb::fista_generic_kernel<false>), dim3(P), dim3(pb::GEN_THREADS), lds,
+                       (hipStream_t)stream, a, taps_dev, K, wind);
+  return check_launch("fista_generic_kernel");
+}
+
+int pb_fista_outputs(const double* w_dev, int64_t ldw, int P, int N, const double* taps_dev, int K,
+                     double* z_dev, int64_t ldz, double* x_dev, int64_t ldx, void* stream) {
+  if (!w_dev || !taps_dev || P < 0 || N < 1 || K < 1 || ldw < N || (z_dev && ldz < N) ||
+      (x_dev && ldx < N))
+    return fail(PB_ERR_INVALID, "pb_fista_outputs: bad argument");
+  if (2 * (int64_t)N + K + 8 > LDS_DOUBLES_MAX)
+    return fail(PB_ERR_INVALID, "pb_fista_outputs: N=%d K=%d exceeds LDS", N, K);
+  if (P == 0 || (!z_dev && !x_dev)) return PB_OK;
+  const size_t lds = (size_t)(2 * N + K + 8) * sizeof(double);
+  hipLaunchKernelGGL(pb::outputs_kernel, dim3(P), dim3(pb::GEN_THREADS), lds, (hipStream_t)stream,
+                     w_dev, ldw, N, taps_dev, K, z_dev, ldz, x_dev, ldx);
+  return check_launch("outputs_kernel");
+}
+
+int pb_integ_op(const double* x, int64_t ldx, double* out, int64_t ldo, int V, int N, void* st) {
+  return launch_op<pb::OP_INTEG>(x, ldx, out, ldo, V, N, N, nullptr, 0, st, "pb_integ_op");
+}
+int pb_integ_adj(const double* x, int64_t ldx, double* out, int64_t ldo, int V, int N, void* st) {
+  return launch_op<pb::OP_INTEG_ADJ>(x, ldx, out, ldo, V, N, N, nullptr, 0, st, "pb_integ_adj");
+}
+int pb_conv(const double* x, int64_t ldx, double* out, int64_t ldo, int V, int n_in, int n_out,
+            const double* taps, int K, void* st) {
+  return launch_op<pb::OP_CONV>(x, ldx, out, ldo, V, n_in, n_out, taps, K, st, "pb_conv");
+}
+int pb_corr(const double* r, int64_t ldr, double* out, int64_t ldo, int V, int n_in, int n_out,
+            const double* taps, int K, void* st) {
+  // r has n_out samples (the range of the Toeplitz matrix), the result n_in
+  return launch_op<pb::OP_CORR>(r, ldr, out, ldo, V, n_out, n_in, taps, K, st, "pb_corr");
+}
+int pb_op_forward(const double* x, int64_t ldx, double* out, int64_t ldo, int V, int n_in, int n_out,
+                  const double* taps, int K, void* st) {
+  return launch_op<pb::OP_FWD>(x, ldx, out, ldo, V, n_in, n_out, taps, K, st, "pb_op_forward");
+}
+int pb_op_adjoint(const double* r, int64_t ldr, double* out, int64_t ldo, int V, int n_in, int n_out,
+                  const double* taps, int K, void* st) {
+  return launch_op<pb::OP_ADJ>(r, ldr, out, ldo, V, n_out, n_in, taps, K, st, "pb_op_adjoint");
+}
+
+int pb_hrf_cost(const double* z_dev, int64_t ldz, const float* y_dev, int64_t ldy, int V, int N,
+                const double* taps_dev, int K, int n_hrf, double* cost_dev, void* stream) {
+  if (!z_dev || !y_dev || !taps_dev || !cost_dev || V < 0 || N < 1 || K < 1 || n_hrf < 1 ||
+      ldz < N || ldy < N)
+    return fail(PB_ERR_INVALID, "pb_hrf_cost: bad argument");
+  if ((int64_t)N + K + 8 > LDS_DOUBLES_MAX) return fail(PB_ERR_INVALID, "pb_hrf_cost: exceeds LDS");
+  if (V == 0) return PB_OK;
+  const size_t lds = (size_t)(N + K + 8) * sizeof(double);
+  hipLaunchKernelGGL(pb::hrf_cost_kernel, dim3(V, n_hrf), dim3(pb::GEN_THREADS), lds,
+                     (hipStream_t)stream, z_dev, ldz, y_dev, ldy, V, N, taps_dev, K, cost_dev);
+  return check_launch("hrf_cost_kernel");
+}
+
+}  // extern "C"

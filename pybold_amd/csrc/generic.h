@@ -1,0 +1,274 @@
+// Any-size float64 kernels: one 256-thread workgroup per row, the row staged in
+// LDS.  They serve (i) the operator surface (.op/.adj of DiscretInteg and
+// ConvAndLinear, pybold/linear.py:9-113; toeplitz products,
+// pybold/convolution.py:105-132), (ii) the outputs z, x of deconv
+// (pybold/bold_signal.py:74-75), (iii) hrf_fit_err (pybold/bold_signal.py:217-222)
+// and (iv) the FISTA recurrence for shapes the register-resident kernel does not
+// cover, including the windowed early-stopping rule (pybold/bold_signal.py:82-95).
+#pragma once
+#include "common.h"
+#include "fista_fast.h"  // FistaArgs
+
+namespace pb {
+
+constexpr int GEN_THREADS = 256;
+constexpr int GEN_WAVES = GEN_THREADS / 64;
+
+// ---- block-wide primitives (all threads of the workgroup must call) ---------
+
+// sum of one double per thread, result in every thread; red = 2*GEN_WAVES doubles of LDS
+__device__ __forceinline__ double block_sum(double v, double* red) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int wid = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[wid] = v;
+  __syncthreads();
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < GEN_WAVES; ++i) s += red[i];
+  return s;
+}
+
+// dst[i] = sum_{j<=i} src[j] (REVERSE=false) or sum_{j>=i} src[j] (REVERSE=true),
+// i in [0, n).  src/dst in LDS, may alias.  Each thread owns a contiguous chunk.
+template <bool REVERSE>
+__device__ __forceinline__ void block_cumsum(const double* src, double* dst, int n, double* red) {
+  const int chunk = (n + GEN_THREADS - 1) / GEN_THREADS;
+  const int t = threadIdx.x;
+  const int lo = t * chunk;
+  const int hi = min(lo + chunk, n);
+  auto idx = [&](int i) { return REVERSE ? n - 1 - i : i; };
+  double local = 0.0;
+  for (int i = lo; i < hi; ++i) local += src[idx(i)];
+  // exclusive scan of the per-thread totals
+  double incl = local;
+  const int lane = t & 63, wid = t >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const double up = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += up;
+  }
+  __syncthreads();
+  if (lane == 63) red[wid] = incl;
+  __syncthreads();
+  double woff = 0.0;
+  for (int i = 0; i < wid; ++i) woff += red[i];
+  double run = woff + incl - local;
+  __syncthreads();   // all reads of src done before dst (may alias) is written
+  // (each thread only rewrites its own chunk, and read it above, so aliasing is safe)
+  for (int i = lo; i < hi; ++i) {
+    // re-read is safe: this thread is the only writer of its chunk
+    run += src[idx(i)];
+    dst[idx(i)] = run;
+  }
+  __syncthreads();
+}
+
+// out[i] = sum_m k[m] in[i-m], 0 <= i-m < n_in, i in [0, n_out)   (toeplitz @ in)
+__device__ __forceinline__ void block_conv(const double* in, int n_in, double* out, int n_out,
+                                           const double* k, int K) {
+  for (int i = threadIdx.x; i < n_out; i += GEN_THREADS) {
+    const int m0 = max(0, i - n_in + 1);
+    const int m1 = min(K - 1, i);
+    double acc = 0.0;
+    for (int m = m0; m <= m1; ++m) acc = fma(k[m], in[i - m], acc);
+    out[i] = acc;
+  }
+  __syncthreads();
+}
+
+// out[j] = sum_m k[m] r[j+m], j+m < n_r, j in [0, n_out)           (toeplitz^T @ r)
+__device__ __forceinline__ void block_corr(const double* r, int n_r, double* out, int n_out,
+                                           const double* k, int K) {
+  for (int j = threadIdx.x; j < n_out; j += GEN_THREADS) {
+    const int m1 = min(K - 1, n_r - 1 - j);
+    double acc = 0.0;
+    for (int m = 0; m <= m1; ++m) acc = fma(k[m], r[j + m], acc);
+    out[j] = acc;
+  }
+  __syncthreads();
+}
+
+// ---- operator kernels -------------------------------------------------------
+enum OpKind { OP_INTEG = 0, OP_INTEG_ADJ = 1, OP_CONV = 2, OP_CORR = 3, OP_FWD = 4, OP_ADJ = 5 };
+
+// LDS: a[nmax] b[nmax] k[K] red[8]
+template <int KIND>
+__global__ __launch_bounds__(GEN_THREADS) void op_kernel(const double* x, int64_t ldx, double* out,
+                                                         int64_t ldo, int n_src, int n_dst,
+                                                         const double* taps, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nmax = max(n_src, n_dst);
+  double* a = reinterpret_cast<double*>(smem);
+  double* b = a + nmax;
+  double* k = b + nmax;
+  double* red = k + K;
+  const double* xr = x + (int64_t)blockIdx.x * ldx;
+  double* orow = out + (int64_t)blockIdx.x * ldo;
+  for (int i = threadIdx.x; i < n_src; i += GEN_THREADS) a[i] = xr[i];
+  for (int i = threadIdx.x; i < K; i += GEN_THREADS) k[i] = taps[i];
+  __syncthreads();
+  double* res = b;
+  if constexpr (KIND == OP_INTEG) {
+    block_cumsum<false>(a, b, n_src, red);
+  } else if constexpr (KIND == OP_INTEG_ADJ) {
+    block_cumsum<true>(a, b, n_src, red);
+  } else if constexpr (KIND == OP_CONV) {
+    block_conv(a, n_src, b, n_dst, k, K);
+  } else if constexpr (KIND == OP_CORR) {
+    block_corr(a, n_src, b, n_dst, k, K);
+  } else if constexpr (KIND == OP_FWD) {       // K . cumsum
+    block_cumsum<false>(a, a, n_src, red);
+    block_conv(a, n_src, b, n_dst, k, K);
+  } else {                                     // revcumsum . K^T
+    block_corr(a, n_src, b, n_dst, k, K);
+    block_cumsum<true>(b, b, n_dst, red);
+  }
+  for (int i = threadIdx.x; i < n_dst; i += GEN_THREADS) orow[i] = res[i];
+}
+
+// z = cumsum(w), x = k * z
+__global__ __launch_bounds__(GEN_THREADS) void outputs_kernel(const double* w, int64_t ldw, int N,
+                                                              const double* taps, int K, double* z,
+                                                              int64_t ldz, double* x, int64_t ldx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* a = reinterpret_cast<double*>(smem);
+  double* b = a + N;
+  double* k = b + N;
+  double* red = k + K;
+  const double* wr = w + (int64_t)blockIdx.x * ldw;
+  for (int i = threadIdx.x; i < N; i += GEN_THREADS) a[i] = wr[i];
+  for (int i = threadIdx.x; i < K; i += GEN_THREADS) k[i] = taps[i];
+  __syncthreads();
+  block_cumsum<false>(a, a, N, red);
+  if (z) {
+    double* zr = z + (int64_t)blockIdx.x * ldz;
+    for (int i = threadIdx.x; i < N; i += GEN_THREADS) zr[i] = a[i];
+  }
+  if (x) {
+    block_conv(a, N, b, N, k, K);
+    double* xr = x + (int64_t)blockIdx.x * ldx;
+    for (int i = threadIdx.x; i < N; i += GEN_THREADS) xr[i] = b[i];
+  }
+}
+
+// cost[c][v] = 0.5 || y_v - taps_c * z_v ||^2 ; grid = (V, n_hrf)
+__global__ __launch_bounds__(GEN_THREADS) void hrf_cost_kernel(const double* z, int64_t ldz,
+                                                               const float* y, int64_t ldy, int V,
+                                                               int N, const double* taps, int K,
+                                                               double* cost) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* a = reinterpret_cast<double*>(smem);
+  double* k = a + N;
+  double* red = k + K;
+  const int v = blockIdx.x, c = blockIdx.y;
+  const double* zr = z + (int64_t)v * ldz;
+  const float* yr = y + (int64_t)v * ldy;
+  const double* tc = taps + (int64_t)c * K;
+  for (int i = threadIdx.x; i < N; i += GEN_THREADS) a[i] = zr[i];
+  for (int i = threadIdx.x; i < K; i += GEN_THREADS) k[i] = tc[i];
+  __syncthreads();
+  double sq = 0.0;
+  for (int i = threadIdx.x; i < N; i += GEN_THREADS) {
+    const int m1 = min(K - 1, i);
+    double acc = 0.0;
+    for (int m = 0; m <= m1; ++m) acc = fma(k[m], a[i - m], acc);
+    const double d = (double)yr[i] - acc;
+    sq = fma(d, d, sq);
+  }
+  const double tot = block_sum(sq, red);
+  if (threadIdx.x == 0) cost[(int64_t)c * V + v] = 0.5 * tot;
+}
+
+// ---- generic FISTA: one workgroup per problem, float64 state in LDS ---------
+// LDS: w[N] a[N] b[N] k[K] red[8] hist[wind*N] (window rule only)
+template <bool WITH_J>
+__global__ __launch_bounds__(GEN_THREADS) void fista_generic_kernel(FistaArgs a_, const double* taps,
+                                                                    int K, int wind) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int N = a_.N;
+  double* w = reinterpret_cast<double*>(smem);
+  double* a = w + N;
+  double* b = a + N;
+  double* k = b + N;
+  double* red = k + K;
+  double* hist = red + 2 * GEN_WAVES;
+  const int p = blockIdx.x;
+  const float* yr = a_.y + (int64_t)(p / a_.y_rep) * a_.ldy;
+  double* wrow = a_.w + (int64_t)p * a_.ldw;
+  for (int i = threadIdx.x; i < N; i += GEN_THREADS) w[i] = wrow[i];
+  for (int i = threadIdx.x; i < K; i += GEN_THREADS) k[i] = taps[i];
+  __syncthreads();
+  const double lb = a_.lbda_vec ? a_.lbda_vec[p] : a_.lbda;
+  const double th = lb * a_.step;
+  const int stop = a_.stop_mode;
+  float* Jrow = WITH_J ? a_.J + (int64_t)p * a_.ldj : nullptr;
+
+  int n_stop = a_.n_iter;   // iterations to execute (shrinks when the stop rule fires)
+  int it = 0;
+  for (;; ++it) {
+    if (!WITH_J && it >= n_stop) break;
+    // forward: a = cumsum(w); b = k*a - y
+    block_cumsum<false>(w, a, N, red);
+    block_conv(a, N, b, N, k, K);
+    for (int i = threadIdx.x; i < N; i += GEN_THREADS) b[i] -= (double)yr[i];
+    __syncthreads();
+    if constexpr (WITH_J) {
+      if (it > 0) {
+        double part = 0.0;
+        for (int i = threadIdx.x; i < N; i += GEN_THREADS)
+          part += 0.5 * b[i] * b[i] + lb * fabs(w[i]);
+        const double cost = block_sum(part, red);
+        if (threadIdx.x == 0) Jrow[it - 1] = (float)cost;
+      }
+      if (it >= n_stop) break;
+    }
+    // adjoint: a = K^T b ; a = revcumsum(a)
+    block_corr(b, N, a, N, k, K);
+    block_cumsum<true>(a, a, N, red);
+    // update
+    const double beta = a_.betas[it];
+    const double nb1 = -(1.0 + beta);
+    double num = 0.0, den = 0.0;
+    for (int i = threadIdx.x; i < N; i += GEN_THREADS) {
+      const double u = fma(-a_.step, a[i], w[i]);
+      const double d = fmin(fmax(u, -th), th);
+      const double wn = fma(nb1, d, u);
+      w[i] = wn;
+      if (stop == 1) {
+        num = fma(wn - u, wn - u, num);
+        den = fma(wn, wn, den);
+      } else if (stop == 2) {
+        // window of the last `wind` stored iterates; the slot that held w_k was
+        // overwritten in place by u_k (pybold/bold_signal.py:65,72,82)
+        if (it > 0) hist[((it - 1) % wind) * N + i] = u;
+        hist[(it % wind) * N + i] = wn;
+      }
+    }
+    __syncthreads();
+    if (stop == 1) {
+      num = block_sum(num, red);
+      den = block_sum(den, red);
+      if (it > 2 && sqrt(num) / (sqrt(den) + 1.0e-10) < a_.tol) n_stop = it + 1;
+    } else if (stop == 2 && it > wind) {
+      const int half = wind / 2;
+      for (int i = threadIdx.x; i < N; i += GEN_THREADS) {
+        double so = 0.0, sn = 0.0;
+        for (int q = it - wind + 1; q <= it - half; ++q) so += hist[(q % wind) * N + i];
+        for (int q = it - half + 1; q <= it; ++q) sn += hist[(q % wind) * N + i];
+        so /= (double)(wind - half);
+        sn /= (double)half;
+        num = fma(sn - so, sn - so, num);
+        den = fma(sn, sn, den);
+      }
+      num = block_sum(num, red);
+      den = block_sum(den, red);
+      if (sqrt(num) / (sqrt(den) + 1.0e-10) < a_.tol) n_stop = it + 1;
+    }
+  }
+  for (int i = threadIdx.x; i < N; i += GEN_THREADS) wrow[i] = w[i];
+  if (a_.n_done && threadIdx.x == 0) a_.n_done[p] = min(n_stop, a_.n_iter);
+}
+
+}  // namespace pb

@@ -1,0 +1,222 @@
+"""Device-level batched API over the C ABI (``include/pybold_hip.h``).
+
+Everything here takes and returns ``torch`` CUDA tensors (PyTorch is used for
+device memory and streams only); the arithmetic happens in the hand-written
+HIP kernels of ``libpybold_hip.so``.  Rows are problems ("voxels"), the last
+dimension is time.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (PB_FLAG_FORCE_FAST, PB_FLAG_FORCE_GENERIC, PB_STOP_LOOPS,
+                   PB_STOP_NONE, PB_STOP_WINDOW)
+
+_STOP = {None: PB_STOP_NONE, "none": PB_STOP_NONE, "loops": PB_STOP_LOOPS,
+         "window": PB_STOP_WINDOW}
+_FORCE = {None: 0, "generic": PB_FLAG_FORCE_GENERIC, "fast": PB_FLAG_FORCE_FAST}
+
+
+def device(dev=None):
+    """The HIP device to run on; raises when no GPU is visible (no CPU path)."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("pybold_amd needs a ROCm GPU (MI355X); none is visible "
+                           "and there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device()) if dev is None else torch.device(dev)
+
+
+def momentum_betas(n_iter, t0=1.0):
+    """``beta_k = (t_k - 1) / t_{k+1}`` with ``t_{k+1} = (1 + sqrt(1 + 4 t_k^2)) / 2``
+    in float64, exactly the scalar sequence of pybold/bold_signal.py:60,68-71."""
+    betas = np.empty(n_iter, dtype=np.float64)
+    t_old = float(t0)
+    for k in range(n_iter):
+        t = 0.5 * (1.0 + np.sqrt(1.0 + 4.0 * t_old ** 2))
+        betas[k] = (t_old - 1.0) / t
+        t_old = t
+    return betas
+
+
+_beta_cache = {}
+
+
+def _betas_on(dev, n_iter):
+    key = (dev.type, dev.index)
+    cur = _beta_cache.get(key)
+    if cur is None or cur.numel() < n_iter:
+        n = max(n_iter, 1024, 2 * (cur.numel() if cur is not None else 0))
+        cur = torch.from_numpy(momentum_betas(n)).to(dev)
+        _beta_cache[key] = cur
+    return cur
+
+
+def _stream_ptr(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _as_taps(hrf):
+    taps = np.ascontiguousarray(np.asarray(hrf, dtype=np.float64).ravel())
+    if taps.size < 1:
+        raise ValueError("empty HRF")
+    return taps
+
+
+def _rows(t, dtype, name):
+    if t.dim() != 2:
+        raise ValueError("%s must be 2-D (problems, time), got %s" % (name, tuple(t.shape)))
+    if t.dtype != dtype or not t.is_cuda:
+        raise TypeError("%s must be a CUDA tensor of %s" % (name, dtype))
+    if t.stride(1) != 1:
+        t = t.contiguous()
+    return t
+
+
+def _ld(t):
+    """Leading dimension in elements (a single-row view may report stride 0)."""
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def has_fast_path(n_scans, n_taps):
+    return bool(_lib.load().pb_fista_has_fast_path(int(n_scans), int(n_taps)))
+
+
+def fista_solve(Y, hrf, lbda, step, n_iter, W0=None, want_J=False, stop=None,
+                tol=0.0, wind=6, y_rep=1, force=None):
+    """Run ``n_iter`` iterations of the reference recurrence
+    (pybold/bold_signal.py:62-72, :259-276) for every row of ``Y`` in one launch.
+
+    Y     float32 CUDA ``(V, N)``
+    hrf   1-D array of K taps (host)
+    lbda  scalar, or array/tensor of ``V * y_rep`` per-problem values
+    step  ``1 / L``
+    W0    optional float64 CUDA ``(P, N)`` warm start (not modified)
+    stop  None | "loops" (_loops_deconv rule) | "window" (deconv rule)
+    Returns ``(W float64 (P, N), J float32 (P, n_iter) or None, n_done int32 (P,))``.
+    """
+    lib = _lib.load()
+    Y = _rows(Y, torch.float32, "Y")
+    dev = Y.device
+    V, N = Y.shape
+    P = V * int(y_rep)
+    taps = _as_taps(hrf)
+    taps_dev = torch.from_numpy(taps).to(dev)
+    if W0 is None:
+        W = torch.zeros((P, N), dtype=torch.float64, device=dev)
+    else:
+        W = _rows(W0, torch.float64, "W0").clone()
+        if W.shape != (P, N):
+            raise ValueError("W0 must be %s, got %s" % ((P, N), tuple(W.shape)))
+    lbda_dev = None
+    lbda_scalar = 0.0
+    if np.ndim(lbda) == 0 and not torch.is_tensor(lbda):
+        lbda_scalar = float(lbda)
+    else:
+        lbda_dev = torch.as_tensor(lbda, dtype=torch.float64).to(dev).contiguous().ravel()
+        if lbda_dev.numel() != P:
+            raise ValueError("per-problem lbda must have %d entries" % P)
+    betas = _betas_on(dev, n_iter)
+    J = torch.empty((P, max(n_iter, 1)), dtype=torch.float32, device=dev) if want_J else None
+    if J is not None:
+        J.fill_(float("nan"))
+    n_done = torch.empty((P,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.pb_fista_solve(
+            Y.data_ptr(), _ld(Y), int(y_rep), W.data_ptr(), _ld(W), P, N,
+            taps.ctypes.data, taps_dev.data_ptr(), taps.size, float(step), lbda_scalar,
+            lbda_dev.data_ptr() if lbda_dev is not None else None,
+            betas.data_ptr(), int(n_iter),
+            J.data_ptr() if J is not None else None, _ld(J) if J is not None else 0,
+            _STOP[stop], float(tol), int(wind), n_done.data_ptr(), _FORCE[force],
+            _stream_ptr(dev))
+    _lib.check(rc, "pb_fista_solve")
+    return W, J, n_done
+
+
+def fista_outputs(W, hrf):
+    """``z = cumsum(w)`` and ``x = hrf * z`` (pybold/bold_signal.py:74-75), float64."""
+    lib = _lib.load()
+    W = _rows(W, torch.float64, "W")
+    dev = W.device
+    P, N = W.shape
+    taps_dev = torch.from_numpy(_as_taps(hrf)).to(dev)
+    Z = torch.empty_like(W)
+    X = torch.empty_like(W)
+    with torch.cuda.device(dev):
+        rc = lib.pb_fista_outputs(W.data_ptr(), _ld(W), P, N, taps_dev.data_ptr(),
+                                  taps_dev.numel(), Z.data_ptr(), _ld(Z),
+                                  X.data_ptr(), _ld(X), _stream_ptr(dev))
+    _lib.check(rc, "pb_fista_outputs")
+    return X, Z
+
+
+def _apply(fn_name, X, n_out, taps=None, n_in=None):
+    lib = _lib.load()
+    X = _rows(X, torch.float64, "x")
+    dev = X.device
+    V, n_src = X.shape
+    out = torch.empty((V, n_out), dtype=torch.float64, device=dev)
+    fn = getattr(lib, fn_name)
+    with torch.cuda.device(dev):
+        if taps is None:
+            rc = fn(X.data_ptr(), _ld(X), out.data_ptr(), _ld(out), V, n_src,
+                    _stream_ptr(dev))
+        else:
+            t = torch.from_numpy(_as_taps(taps)).to(dev)
+            if fn_name in ("pb_conv", "pb_op_forward"):
+                dim_in, dim_out = n_src, n_out
+            else:                       # adjoint forms: input lives in the range
+                dim_in, dim_out = n_out, n_src
+            rc = fn(X.data_ptr(), _ld(X), out.data_ptr(), _ld(out), V, dim_in,
+                    dim_out, t.data_ptr(), t.numel(), _stream_ptr(dev))
+    _lib.check(rc, fn_name)
+    return out
+
+
+def integ_op(X):
+    """Row-wise cumulative sum (DiscretInteg.op, pybold/linear.py:15-28)."""
+    return _apply("pb_integ_op", X, X.shape[1])
+
+
+def integ_adj(X):
+    """Row-wise reverse cumulative sum (DiscretInteg.adj, pybold/linear.py:30-43)."""
+    return _apply("pb_integ_adj", X, X.shape[1])
+
+
+def conv(X, taps, dim_out=None):
+    """``toeplitz_from_kernel(taps, n_in, dim_out) @ x`` per row (convolution.py:105-132)."""
+    return _apply("pb_conv", X, X.shape[1] if dim_out is None else dim_out, taps)
+
+
+def corr(R, taps, dim_in=None):
+    """``toeplitz_from_kernel(taps, dim_in, n_out).T @ r`` per row."""
+    return _apply("pb_corr", R, R.shape[1] if dim_in is None else dim_in, taps)
+
+
+def op_forward(X, taps, dim_out=None):
+    """``ConvAndLinear(DiscretInteg(), taps, n_in, dim_out).op`` (linear.py:73-93)."""
+    return _apply("pb_op_forward", X, X.shape[1] if dim_out is None else dim_out, taps)
+
+
+def op_adjoint(R, taps, dim_in=None):
+    """``ConvAndLinear(DiscretInteg(), taps, dim_in, n_out).adj`` (linear.py:95-113)."""
+    return _apply("pb_op_adjoint", R, R.shape[1] if dim_in is None else dim_in, taps)
+
+
+def hrf_cost(Z, Y, taps):
+    """``0.5 ||y_v - taps_c * z_v||^2`` for every voxel v and candidate HRF c
+    (hrf_fit_err, pybold/bold_signal.py:217-222).  ``taps`` is ``(K,)`` or
+    ``(C, K)``; returns float64 ``(C, V)``."""
+    lib = _lib.load()
+    Z = _rows(Z, torch.float64, "Z")
+    Y = _rows(Y, torch.float32, "Y")
+    dev = Z.device
+    V, N = Z.shape
+    t = np.atleast_2d(np.asarray(taps, dtype=np.float64))
+    C, K = t.shape
+    t_dev = torch.from_numpy(np.ascontiguousarray(t)).to(dev)
+    cost = torch.empty((C, V), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.pb_hrf_cost(Z.data_ptr(), _ld(Z), Y.data_ptr(), _ld(Y), V, N,
+                             t_dev.data_ptr(), K, C, cost.data_ptr(), _stream_ptr(dev))
+    _lib.check(rc, "pb_hrf_cost")
+    return cost

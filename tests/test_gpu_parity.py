@@ -1,0 +1,283 @@
+"""GPU parity tests: the HIP kernels, called through the C ABI
+(libpybold_hip.so via pybold_amd._lib), against the float64 CPU oracle and the
+golden vectors captured from the reference.
+
+Tolerance (north_star): relative L2 error <= 1e-5 per voxel on diff_z, z, x
+(float32 FIR/scans on device, float64 iterate; the reference is float64).
+The operator surface (.op/.adj) is float64 on device and held to 1e-12.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pybold_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+EPS = 1.0e-5
+
+
+def rel_rows(a, b):
+    a, b = np.atleast_2d(a), np.atleast_2d(b)
+    return (np.linalg.norm(a - b, axis=1) / (np.linalg.norm(b, axis=1) + 1e-300)).max()
+
+
+@pytest.fixture(scope="module")
+def pa():
+    import pybold_amd
+    from pybold_amd import solver
+    assert torch.cuda.is_available()
+    return pybold_amd, solver
+
+
+def dev32(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def dev64(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+
+
+def grid_inputs(golden):
+    g = golden("grid")
+    Y = np.stack([g["y_s%d" % s] for s in range(4)])
+    return g, Y, g["hrf"], float(g["lip_s0"])
+
+
+@pytest.mark.parametrize("force", ["fast", "generic"])
+def test_fista_vs_golden_grid(pa, golden, force):
+    """lambda x iterations grid of SURVEY 8c case 3 (captures k=0 and the aliasing)."""
+    _, solver = pa
+    g, Y, hrf, lip = grid_inputs(golden)
+    for lbda in (0.1, 1.0, 10.0):
+        for nit in (1, 2, 3, 10, 500):
+            W, _, n_done = solver.fista_solve(dev32(Y), hrf, lbda, 1.0 / lip, nit, force=force)
+            W = W.cpu().numpy()
+            ref = np.stack([g["dz_s%d_l%g_n%d" % (s, lbda, nit)] for s in range(4)])
+            assert rel_rows(W, ref) < EPS, (force, lbda, nit, rel_rows(W, ref))
+            assert (n_done.cpu().numpy() == nit).all()
+            # and against the oracle's batched form
+            Wo = orc.fista_batch(Y, hrf, lbda, 1.0 / lip, nit)
+            assert rel_rows(W, Wo) < EPS
+
+
+@pytest.mark.parametrize("force", ["fast", "generic"])
+def test_outputs_and_cost_trace(pa, golden, force):
+    _, solver = pa
+    g = golden("case1")
+    y, hrf, lip = g["y"], g["hrf"], float(g["lipschitz"])
+    W, J, _ = solver.fista_solve(dev32(y[None]), hrf, 1.0, 1.0 / lip, 500, want_J=True, force=force)
+    X, Z = solver.fista_outputs(W, hrf)
+    assert rel_rows(W.cpu().numpy(), g["diff_z"]) < EPS
+    assert rel_rows(Z.cpu().numpy(), g["z"]) < EPS
+    assert rel_rows(X.cpu().numpy(), g["x"]) < EPS
+    J = J.cpu().numpy()[0].astype(np.float64)
+    np.testing.assert_allclose(J / J[0], g["J"], rtol=2e-5)
+
+
+def test_per_problem_lambda_and_y_rep(pa, golden):
+    """Regularisation path: several lambdas per voxel share one y row (config 5)."""
+    _, solver = pa
+    g, Y, hrf, lip = grid_inputs(golden)
+    lbdas = np.array([0.1, 1.0, 10.0])
+    lam = np.tile(lbdas, Y.shape[0])
+    W, _, _ = solver.fista_solve(dev32(Y), hrf, lam, 1.0 / lip, 10, y_rep=3, force="fast")
+    W = W.cpu().numpy().reshape(Y.shape[0], 3, -1)
+    for s in range(4):
+        for i, lbda in enumerate(lbdas):
+            assert rel_rows(W[s, i], g["dz_s%d_l%g_n10" % (s, lbda)]) < EPS
+
+
+def test_warm_start_chunks_equal_one_run(pa, golden):
+    """Two launches of 250 iterations (momentum table offset by the caller) would
+    differ from one of 500; a warm start with restarted momentum must equal the
+    oracle's warm-started run."""
+    _, solver = pa
+    g, Y, hrf, lip = grid_inputs(golden)
+    W1, _, _ = solver.fista_solve(dev32(Y), hrf, 1.0, 1.0 / lip, 7, force="fast")
+    W2, _, _ = solver.fista_solve(dev32(Y), hrf, 1.0, 1.0 / lip, 5, W0=W1, force="fast")
+    Wo = orc.fista_batch(Y, hrf, 1.0, 1.0 / lip, 7)
+    Wo = orc.fista_batch(Y, hrf, 1.0, 1.0 / lip, 5, W0=Wo)
+    assert rel_rows(W2.cpu().numpy(), Wo) < EPS
+
+
+@pytest.mark.parametrize("N,K", [(300, 30), (290, 30), (304, 30), (17, 5), (40, 30), (300, 1),
+                                 (33, 27), (1, 1), (16, 2)])
+def test_edge_shapes_fast_and_generic_agree_with_oracle(pa, N, K):
+    _, solver = pa
+    rng = np.random.RandomState(N * 100 + K)
+    hrf = rng.randn(K) * 0.3
+    Y = rng.randn(5, N)
+    H = orc.DenseH(hrf, N, N)
+    lip = 1.1 * np.linalg.norm(H.K.dot(np.tril(np.ones((N, N)))), 2) ** 2 + 1e-12
+    Wo = orc.fista_batch(Y.astype(np.float32).astype(np.float64), hrf, 0.05, 1.0 / lip, 40)
+    for force in ("fast", "generic"):
+        if force == "fast" and not solver.has_fast_path(N, K):
+            continue
+        W, _, _ = solver.fista_solve(dev32(Y), hrf, 0.05, 1.0 / lip, 40, force=force)
+        err = np.abs(W.cpu().numpy() - Wo).max() / (np.abs(Wo).max() + 1e-30)
+        assert err < EPS, (force, N, K, err)
+
+
+def test_lambda_zero_and_huge(pa, golden):
+    """lambda = 0 (no prox) and a lambda that thresholds everything: because the
+    momentum uses the gradient-step point the iterate is then
+    -beta_k * u_k, not 0 -- exactly what the reference returns."""
+    _, solver = pa
+    g, Y, hrf, lip = grid_inputs(golden)
+    Y32 = Y.astype(np.float32).astype(np.float64)
+    for lbda in (0.0, 1e9):
+        for force in ("fast", "generic"):
+            W, _, _ = solver.fista_solve(dev32(Y), hrf, lbda, 1.0 / lip, 20, force=force)
+            Wo = orc.fista_batch(Y32, hrf, lbda, 1.0 / lip, 20)
+            assert rel_rows(W.cpu().numpy(), Wo) < EPS, (lbda, force)
+    W, _, _ = solver.fista_solve(dev32(Y), hrf, 1e9, 1.0 / lip, 1)
+    assert float(W.abs().max()) == 0.0        # beta_0 = 0: first iterate is the prox point
+
+
+def test_many_problems_partial_last_block(pa, golden):
+    """P not a multiple of 16: the last workgroup has idle rows."""
+    _, solver = pa
+    g, Y, hrf, lip = grid_inputs(golden)
+    Yb = np.tile(Y, (9, 1))[:35] * np.linspace(0.5, 1.5, 35)[:, None]
+    W, _, _ = solver.fista_solve(dev32(Yb), hrf, 1.0, 1.0 / lip, 25)
+    Wo = orc.fista_batch(Yb.astype(np.float32).astype(np.float64), hrf, 1.0, 1.0 / lip, 25)
+    assert rel_rows(W.cpu().numpy(), Wo) < EPS
+
+
+def test_loops_deconv_goldens(pa, golden):
+    pybold_amd, _ = pa
+    g = golden("loops_deconv")
+    y, h = g["y"], g["h"]
+    H = pybold_amd.toeplitz_from_kernel(h, len(y), len(y))
+    for nit in (1, 2, 5, 100):
+        for es_on, tol in ((False, 1e-12), (True, 1e-2), (True, 1e-3)):
+            w = pybold_amd._loops_deconv(y, np.zeros_like(y), H, 1.7, nit, es_on, 4, tol)
+            ref = g["w_n%d_es%d_tol%g" % (nit, es_on, tol)]
+            assert rel_rows(w, ref) < EPS, (nit, es_on, tol)
+    w = pybold_amd._loops_deconv(y, g["w0"], H, 1.7, 5, False, 4, 1e-12)
+    assert rel_rows(w, g["w_warm_n5"]) < EPS
+
+
+def test_deconv_end_to_end_case1(pa, golden):
+    pybold_amd, _ = pa
+    g = golden("case1")
+    np.random.seed(0)
+    x, z, dz, J, R, G = pybold_amd.deconv(g["y"], 1.0, g["hrf"], lbda=1.0, nb_iter=500,
+                                          early_stopping=False)
+    assert R is None and G is None
+    assert x.dtype == np.float64 and x.shape == g["x"].shape
+    assert rel_rows(dz, g["diff_z"]) < EPS
+    assert rel_rows(z, g["z"]) < EPS
+    assert rel_rows(x, g["x"]) < EPS
+    assert len(J) == 500
+    np.testing.assert_allclose(J, g["J"], rtol=2e-5)
+
+
+def test_deconv_early_stopping_goldens(pa, golden):
+    pybold_amd, _ = pa
+    g = golden("early_stop")
+    for tol, n_ref in ((0.1, 26), (0.03, 77), (0.01, 191), (0.005, 311)):
+        np.random.seed(0)
+        x, z, dz, J, _, _ = pybold_amd.deconv(g["y"], 1.0, g["hrf"], lbda=1.0, nb_iter=1000,
+                                              early_stopping=True, tol=tol, wind=6)
+        assert len(J) == n_ref, (tol, len(J))
+        assert rel_rows(dz, g["dz_%g" % tol]) < EPS
+        assert rel_rows(x, g["x_%g" % tol]) < EPS
+
+
+def test_deconv_batch_matches_single(pa, golden):
+    pybold_amd, _ = pa
+    g, Y, hrf, lip = grid_inputs(golden)
+    np.random.seed(0)
+    X, Z, W, J, _, _ = pybold_amd.deconv(Y, 1.0, hrf, lbda=1.0, nb_iter=10, early_stopping=False)
+    assert W.shape == Y.shape and J.shape == (4, 10)
+    for s in range(4):
+        assert rel_rows(W[s], g["dz_s%d_l1_n10" % s]) < EPS
+        np.testing.assert_allclose(J[s], g["J_s%d_l1_n10" % s], rtol=2e-5)
+
+
+def test_operator_surface_goldens(pa, golden):
+    pybold_amd, _ = pa
+    g = golden("operators")
+    for tag in "abcde":
+        k, x = g[tag + "_k"], g[tag + "_x"]
+        n = len(x)
+        H = pybold_amd.ConvAndLinear(pybold_amd.DiscretInteg(), k, dim_in=n, dim_out=n)
+        np.testing.assert_allclose(H.op(x), g[tag + "_op"], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(H.adj(x), g[tag + "_adj"], rtol=1e-12, atol=1e-12)
+        I = pybold_amd.DiscretInteg()
+        np.testing.assert_allclose(I.op(x), g[tag + "_integ_op"], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(I.adj(x), g[tag + "_integ_adj"], rtol=1e-12, atol=1e-12)
+    # rectangular Toeplitz product of pybold/tests/test_convolution.py:169-176
+    _, solver = pa
+    sig, k = g["rect_sig"], g["rect_k"]
+    out = solver.conv(dev64(k[None]), sig, dim_out=len(sig)).cpu().numpy()[0]
+    np.testing.assert_allclose(out, g["rect_conv"], rtol=1e-12, atol=1e-12)
+    # its transpose against the dense matrix
+    r = np.random.RandomState(1).randn(len(sig))
+    out = solver.corr(dev64(r[None]), sig, dim_in=len(k)).cpu().numpy()[0]
+    np.testing.assert_allclose(out, g["rect_T"].T.dot(r), rtol=1e-12, atol=1e-12)
+
+
+def test_operator_identities_like_reference_tests(pa):
+    """toeplitz @ x == conv, toeplitz.T @ x == retro-conv, adjointness
+    (pybold/tests/test_convolution.py:29-36,95-102; test_linear.py:12-28)."""
+    pybold_amd, solver = pa
+    rng = np.random.RandomState(5)
+    for n, K in ((500, 30), (180, 60), (64, 64), (1000, 7)):
+        k, a, b = rng.randn(K), rng.randn(n), rng.randn(n)
+        T = orc.toeplitz_from_kernel(k, n, n)
+        np.testing.assert_allclose(solver.conv(dev64(a[None]), k).cpu().numpy()[0], T.dot(a),
+                                   rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(solver.corr(dev64(a[None]), k).cpu().numpy()[0], T.T.dot(a),
+                                   rtol=1e-11, atol=1e-11)
+        H = pybold_amd.ConvAndLinear(pybold_amd.DiscretInteg(), k, n, n)
+        assert np.dot(H.op(a), b) == pytest.approx(np.dot(a, H.adj(b)), rel=1e-9)
+        I = pybold_amd.DiscretInteg()
+        np.testing.assert_allclose(I.op(a), np.cumsum(a), rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(I.adj(a), np.flipud(np.cumsum(np.flipud(a))), rtol=1e-12,
+                                   atol=1e-12)
+
+
+def test_spectral_radius_matches_golden(pa, golden):
+    pybold_amd, _ = pa
+    g = golden("case1")
+    n = len(g["y"])
+    H = pybold_amd.ConvAndLinear(pybold_amd.DiscretInteg(), g["hrf"], n, n)
+    np.random.seed(0)
+    rho = pybold_amd.spectral_radius_est(H, (n,))
+    assert 0.9 * rho == pytest.approx(float(g["lipschitz"]), rel=1e-10)
+
+
+def test_hrf_fit_err_and_estim(pa, golden):
+    pybold_amd, _ = pa
+    g = golden("hrf_estim")
+    t_r, dur = float(g["t_r"]), float(g["hrf_dur"])
+    for theta, err in zip(g["thetas"], g["errs"]):
+        got = pybold_amd.hrf_fit_err(theta, g["z"], g["y"], t_r, dur)
+        assert got == pytest.approx(err, rel=1e-6)    # y is float32 on device
+    h, J = pybold_amd.hrf_estim(g["z"], g["y"], t_r, dur)
+    assert rel_rows(h, g["h"]) < 1e-4
+
+
+def test_bd_five_outer_iterations(pa, golden):
+    pybold_amd, _ = pa
+    g = golden("bd")
+    x, z, dz, h, d = pybold_amd.bd(g["y"], float(g["t_r"]), lbda=float(g["lbda"]),
+                                   hrf_dur=float(g["hrf_dur"]), nb_iter=int(g["nb_iter"]))
+    np.testing.assert_allclose(d["J"], g["J"], rtol=1e-4)
+    assert rel_rows(h, g["h"]) < 1e-3
+    assert rel_rows(x, g["x"]) < 1e-3
+
+
+def test_errors_are_loud(pa, golden):
+    _, solver = pa
+    from pybold_amd._lib import PyboldHipError
+    g, Y, hrf, lip = grid_inputs(golden)
+    with pytest.raises(PyboldHipError):
+        solver.fista_solve(dev32(Y), hrf, 1.0, -1.0, 5)              # bad step
+    with pytest.raises(PyboldHipError):
+        solver.fista_solve(dev32(Y), np.ones(5000), 1.0, 1.0, 5, force="fast")
+    with pytest.raises(TypeError):
+        solver.fista_solve(torch.zeros(4, 300), hrf, 1.0, 1.0, 5)   # CPU tensor
