@@ -1,0 +1,49 @@
+"""ctypes access to oracle/libfista_oracle.so (the C form of the CPU oracle).
+Test infrastructure / CPU baseline only."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libfista_oracle.so")
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        lib = ctypes.CDLL(_SO)
+        lib.oracle_fista_batch.restype = ctypes.c_int
+        lib.oracle_fista_batch.argtypes = [
+            ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+            ctypes.c_double, ctypes.c_void_p, ctypes.c_double, ctypes.c_int, ctypes.c_void_p,
+            ctypes.c_void_p, ctypes.c_int]
+        _lib = lib
+    return _lib
+
+
+def fista_batch(Y, hrf, lbda, step, n_iter, W0=None, want_J=False, threads=0):
+    """Same contract as pybold_oracle.fista_batch; returns (W, J or None, threads used)."""
+    lib = load()
+    Y = np.ascontiguousarray(np.atleast_2d(Y), dtype=np.float64)
+    V, N = Y.shape
+    h = np.ascontiguousarray(hrf, dtype=np.float64)
+    W = np.zeros((V, N)) if W0 is None else np.array(W0, dtype=np.float64, order="C")
+    J = np.zeros((V, n_iter)) if want_J else None
+    lv = None
+    if np.ndim(lbda) > 0:
+        lv = np.ascontiguousarray(lbda, dtype=np.float64)
+        lbda = 0.0
+    used = lib.oracle_fista_batch(Y.ctypes.data, V, N, h.ctypes.data, len(h), float(lbda),
+                                  lv.ctypes.data if lv is not None else None, float(step),
+                                  int(n_iter), W.ctypes.data,
+                                  J.ctypes.data if J is not None else None, int(threads))
+    return W, J, used

@@ -132,6 +132,50 @@ def fista_solve(Y, hrf, lbda, step, n_iter, W0=None, want_J=False, stop=None,
     return W, J, n_done
 
 
+class FistaPlan:
+    """Pre-allocated, launch-only form of :func:`fista_solve` for hot loops and
+    graph capture: ``run()`` enqueues a memset of the iterate and ONE
+    ``pb_fista_solve`` launch on the current stream and allocates nothing."""
+
+    def __init__(self, Y, hrf, lbda, step, n_iter, y_rep=1, force="fast"):
+        self.lib = _lib.load()
+        self.Y = _rows(Y, torch.float32, "Y")
+        self.dev = self.Y.device
+        V, self.N = self.Y.shape
+        self.P = V * int(y_rep)
+        self.y_rep = int(y_rep)
+        self.taps = _as_taps(hrf)
+        self.taps_dev = torch.from_numpy(self.taps).to(self.dev)
+        self.W = torch.zeros((self.P, self.N), dtype=torch.float64, device=self.dev)
+        self.n_done = torch.empty((self.P,), dtype=torch.int32, device=self.dev)
+        self.lbda_dev = None
+        self.lbda = 0.0
+        if np.ndim(lbda) == 0 and not torch.is_tensor(lbda):
+            self.lbda = float(lbda)
+        else:
+            self.lbda_dev = torch.as_tensor(lbda, dtype=torch.float64).to(self.dev).contiguous().ravel()
+        self.step = float(step)
+        self.n_iter = int(n_iter)
+        self.betas = _betas_on(self.dev, self.n_iter)
+        self.flags = _FORCE[force]
+
+    def launch(self):
+        """Only the solver launch (the iterate continues from its current value)."""
+        rc = self.lib.pb_fista_solve(
+            self.Y.data_ptr(), _ld(self.Y), self.y_rep, self.W.data_ptr(), _ld(self.W), self.P,
+            self.N, self.taps.ctypes.data, self.taps_dev.data_ptr(), self.taps.size, self.step,
+            self.lbda, self.lbda_dev.data_ptr() if self.lbda_dev is not None else None,
+            self.betas.data_ptr(), self.n_iter, None, 0, PB_STOP_NONE, 0.0, 0,
+            self.n_done.data_ptr(), self.flags, _stream_ptr(self.dev))
+        _lib.check(rc, "pb_fista_solve")
+
+    def run(self):
+        """Cold start: zero the iterate, then solve."""
+        self.W.zero_()
+        self.launch()
+        return self.W
+
+
 def fista_outputs(W, hrf):
     """``z = cumsum(w)`` and ``x = hrf * z`` (pybold/bold_signal.py:74-75), float64."""
     lib = _lib.load()

@@ -1,0 +1,80 @@
+"""CPU-only: the C-ABI library loads, exports every symbol include/pybold_hip.h
+declares, and validates its arguments loudly (no kernel is launched here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    from pybold_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        ge.build()
+    return _lib.load()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "pybold_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pb_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from pybold_amd import _lib
+    names = declared_symbols()
+    assert len(names) >= 12
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in names:
+        assert hasattr(raw, name), "missing export " + name
+    assert sorted(_lib.SIGNATURES) == names     # the Python binding covers the header 1:1
+
+
+def test_version_and_dispatch_table(lib):
+    assert lib.pb_version() >= 100
+    assert lib.pb_fista_has_fast_path(300, 30) == 1     # BASELINE configs 1-3, 5
+    assert lib.pb_fista_has_fast_path(300, 27) == 1     # config 4
+    assert lib.pb_fista_has_fast_path(240, 27) == 1     # golden _loops_deconv case
+    assert lib.pb_fista_has_fast_path(100000, 30) == 0
+    assert lib.pb_fista_has_fast_path(300, 5000) == 0
+    assert lib.pb_fista_has_fast_path(0, 30) == 0
+
+
+def test_argument_errors_do_not_reach_the_gpu(lib):
+    from pybold_amd import _lib
+    taps = np.ones(4)
+    rc = lib.pb_fista_solve(None, 300, 1, None, 300, 4, 300, taps.ctypes.data, None, 4, 1.0, 1.0,
+                            None, None, 10, None, 0, 0, 0.0, 6, None, 0, None)
+    assert rc == -1 and b"NULL" in lib.pb_last_error()
+    with pytest.raises(_lib.PyboldHipError):
+        _lib.check(rc, "pb_fista_solve")
+    fake = ctypes.c_void_p(4096)     # never dereferenced: validation fails first
+    rc = lib.pb_fista_solve(fake, 10, 1, fake, 300, 4, 300, taps.ctypes.data, None, 4, 1.0, 1.0,
+                            None, fake, 10, None, 0, 0, 0.0, 6, None, 0, None)
+    assert rc == -1 and b"leading dimension" in lib.pb_last_error()
+    rc = lib.pb_fista_solve(fake, 300, 1, fake, 300, 4, 300, taps.ctypes.data, None, 4, -1.0, 1.0,
+                            None, fake, 10, None, 0, 0, 0.0, 6, None, 0, None)
+    assert rc == -1 and b"step" in lib.pb_last_error()
+    rc = lib.pb_fista_solve(fake, 300, 1, fake, 300, 4, 300, taps.ctypes.data, None, 4, 1.0, 1.0,
+                            None, fake, 10, None, 0, 7, 0.0, 6, None, 0, None)
+    assert rc == -1 and b"stop_mode" in lib.pb_last_error()
+    rc = lib.pb_conv(fake, 30000, fake, 30000, 1, 30000, 30000, fake, 5, None)
+    assert rc == -1 and b"exceeds LDS" in lib.pb_last_error()
+    rc = lib.pb_hrf_cost(None, 0, None, 0, 1, 1, None, 1, 1, None, None)
+    assert rc == -1
+    # zero problems is a no-op, not an error
+    assert lib.pb_fista_solve(fake, 300, 1, fake, 300, 0, 300, taps.ctypes.data, None, 4, 1.0, 1.0,
+                              None, fake, 10, None, 0, 0, 0.0, 6, None, 0, None) == 0
+
+
+def test_missing_library_is_an_import_error(monkeypatch, tmp_path):
+    from pybold_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError, match="no CPU"):
+        _lib.load()

@@ -1,0 +1,103 @@
+"""CPU-only tests of the host-side logic of pybold_amd (no kernel launches):
+scalar sequences, Toeplitz helpers, Lipschitz constants, the HRF model, the
+generic power iteration, sharding, and the "no CPU fallback" rule."""
+import numpy as np
+import pytest
+import torch
+
+import pybold_amd
+from oracle import pybold_oracle as orc
+from pybold_amd import distributed, solver
+
+
+def test_momentum_sequence_matches_oracle():
+    b = solver.momentum_betas(600)
+    np.testing.assert_array_equal(b, orc.momentum_sequence(600))
+    assert b[0] == 0.0 and 0.99 < b[-1] < 1.0
+    # restart from an explicit t (chunked launches)
+    t = 1.0
+    for _ in range(7):
+        t = 0.5 * (1.0 + np.sqrt(1.0 + 4.0 * t * t))
+    np.testing.assert_array_equal(solver.momentum_betas(5, t0=t), b[7:12])
+
+
+def test_toeplitz_helpers(golden):
+    g = golden("operators")
+    np.testing.assert_array_equal(pybold_amd.toeplitz_from_kernel(np.arange(1., 5.), 6, 6),
+                                  g["toep_small"])
+    np.testing.assert_array_equal(
+        pybold_amd.toeplitz_from_kernel(g["rect_sig"], len(g["rect_k"]), len(g["rect_sig"])),
+        g["rect_T"])
+    k = np.random.RandomState(0).randn(27)
+    H = pybold_amd.toeplitz_from_kernel(k, 240, 240)
+    np.testing.assert_array_equal(pybold_amd.kernel_from_toeplitz(H), k)
+    H[5, 100] = 1.0
+    with pytest.raises(ValueError, match="Toeplitz"):
+        pybold_amd.kernel_from_toeplitz(H)
+
+
+def test_gram_frobenius_matches_dense_definition(golden):
+    g = golden("loops_deconv")
+    h, n = g["h"], len(g["y"])
+    assert pybold_amd.gram_frobenius(h, n) == pytest.approx(orc.gram_lipschitz(h, n), rel=1e-13)
+    assert pybold_amd.gram_frobenius(h[:3], 5) == pytest.approx(orc.gram_lipschitz(h[:3], 5), rel=1e-13)
+
+
+def test_spm_hrf_matches_reference_values(golden):
+    g = golden("spm_hrf")
+    for i in range(6):
+        delta, t_r, dur, norm = g["p%d" % i]
+        h, t = pybold_amd.spm_hrf(delta, t_r=t_r, dur=dur, normalized_hrf=bool(norm))
+        np.testing.assert_allclose(h, g["h%d" % i], rtol=1e-12, atol=1e-15)
+        np.testing.assert_array_equal(t, g["t%d" % i])
+    for bad in (0.49, 2.01):
+        with pytest.raises(ValueError):
+            pybold_amd.spm_hrf(bad)
+
+
+def test_spectral_radius_est_is_duck_typed(golden):
+    """Any object with .op/.adj works (reference contract, pybold/utils.py:94-109)."""
+    g = golden("case1")
+    H = orc.DenseH(g["hrf"], 300, 300)          # CPU stand-in for an operator object
+    np.random.seed(0)
+    rho = pybold_amd.spectral_radius_est(H, (300,))
+    assert 0.9 * rho == pytest.approx(float(g["lipschitz"]), rel=1e-13)
+
+
+def test_shard_bounds_cover_everything_once():
+    for n in (0, 1, 7, 100000, 100001):
+        for world in (1, 2, 3, 8):
+            spans = [distributed.shard_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for (a, b), (c, d) in zip(spans, spans[1:]):
+                assert b == c and a <= b and c <= d
+            assert max(b - a for a, b in spans) == -(-n // world)
+
+
+def test_no_cpu_fallback_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    y = np.zeros(300)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pybold_amd.deconv(y, 1.0, np.ones(30), lbda=1.0, nb_iter=2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pybold_amd.DiscretInteg().op(y)
+    with pytest.raises(TypeError):
+        solver.fista_solve(torch.zeros(2, 300), np.ones(30), 1.0, 1.0, 2)
+
+
+def test_unsupported_modes_raise():
+    with pytest.raises(NotImplementedError):
+        pybold_amd.ConvAndLinear(pybold_amd.DiscretInteg(), np.ones(3), 10, spectral_conv=True)
+
+
+def test_product_never_imports_the_oracle():
+    """The shipped package must not route through oracle/ (checked textually)."""
+    import os
+    pkg = os.path.dirname(pybold_amd.__file__)
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".inc")):
+                text = open(os.path.join(root, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+                assert "pybold_oracle" not in text and "fista_oracle" not in text, f

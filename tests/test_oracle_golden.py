@@ -164,3 +164,22 @@ def test_adjointness():
     a, b = rng.randn(300), rng.randn(300)
     H = orc.DenseH(k, 300, 300)
     assert np.dot(H.op(a), b) == pytest.approx(np.dot(a, H.adj(b)), rel=1e-10)
+
+
+def test_c_oracle_matches_goldens(golden):
+    """oracle/fista_oracle.c (the cpu_baseline port) against the same goldens."""
+    from oracle import c_oracle
+    g = golden("grid")
+    hrf, lip = g["hrf"], float(g["lip_s0"])
+    Y = np.stack([g["y_s%d" % s] for s in range(4)])
+    for lbda in (0.1, 1.0, 10.0):
+        for nit in (1, 2, 3, 10, 500):
+            W, J, _ = c_oracle.fista_batch(Y, hrf, lbda, 1.0 / lip, nit, want_J=True, threads=2)
+            for s in range(4):
+                key = "s%d_l%g_n%d" % (s, lbda, nit)
+                assert rel(W[s], g["dz_" + key]) < 1e-8, key
+                np.testing.assert_allclose(J[s] / (J[s][0] + 1e-30), g["J_" + key], rtol=1e-8)
+    g5 = golden("loops_deconv")
+    W, _, _ = c_oracle.fista_batch(g5["y"][None], g5["h"], 1.7,
+                                   1.0 / orc.gram_lipschitz(g5["h"], len(g5["y"])), 5, W0=g5["w0"][None])
+    assert rel(W[0], g5["w_warm_n5"]) < 1e-9
