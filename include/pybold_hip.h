@@ -105,6 +105,16 @@ int pb_fista_outputs(const double* w_dev, int64_t ldw, int P, int N,
                      void* stream);
 
 /*
+ * Per-problem residual and sparsity of an iterate:
+ *   r2[p] = || taps * cumsum(w_p) - y_p ||^2 ,  l1[p] = || w_p ||_1
+ * -- the quantities the noise-driven lambda search of deconv(lbda=None) tracks
+ * and feeds back into lambda (pybold/bold_signal.py:141-157).  float64 [P] each.
+ */
+int pb_fista_stats(const double* w_dev, int64_t ldw, const float* y_dev, int64_t ldy,
+                   int y_rep, int P, int N, const double* taps_dev, int K,
+                   double* r2_dev, double* l1_dev, void* stream);
+
+/*
  * Operator surface (float64, any size that fits LDS: 3*max(n_in,n_out)+K <= 20000).
  * All of them act row-wise on V rows.
  *

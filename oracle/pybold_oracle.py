@@ -404,3 +404,101 @@ def bd(y, t_r, lbda=1.0, theta_0=None, z_0=None, hrf_dur=20.0, bounds=None,
     for key in ('J', 'r', 'g'):
         d[key] = np.array(d[key])
     return x, z, w, h, d
+
+
+# --------------------------------------------------------------------------
+# noise-driven lambda search (deconv with lbda=None)  -- UNPINNED
+# --------------------------------------------------------------------------
+# db3 decomposition high-pass filter (PyWavelets' Wavelet('db3').dec_hi)
+DB3_DEC_HI = np.array([-0.3326705529509569, 0.8068915093133388, -0.4598775021193313,
+                       -0.13501102001039084, 0.08544127388224149, 0.035226291882100656])
+
+
+def db3_detail_level1(x):
+    """Level-1 detail coefficients of the db3 DWT with half-sample symmetric
+    extension (PyWavelets' default mode), as ``pywt.wavedec(x, 'db3', level=1)[1]``
+    computes them: ``cD[k] = sum_j g[j] xe[2k + 1 - j]``, ``len = (N + 5) // 2``.
+    UNPINNED: pywt is absent from the build image (pybold/utils.py:16-25 calls it),
+    so this follows the published filter/extension definition only."""
+    x = np.asarray(x, dtype=np.float64)
+    n, F = len(x), len(DB3_DEC_HI)
+    xe = np.concatenate([x[:F - 1][::-1], x, x[::-1][:F - 1]])   # xe[i + F-1] = x_ext[i]
+    out = np.empty((n + F - 1) // 2)
+    for k in range(len(out)):
+        i = 2 * k + 1
+        out[k] = sum(DB3_DEC_HI[j] * xe[i - j + F - 1] for j in range(F))
+    return out
+
+
+def mad_daub_noise_est(x, c=0.6744):
+    """pybold/utils.py:10-25: MAD of the db3 level-1 detail coefficients / c."""
+    cD = db3_detail_level1(x)
+    return np.median(np.abs(cD - np.median(cD))) / c
+
+
+def _inner_fista(w, H, H_adj_y, step, th, nb_sub_iter, early_stopping, wind, tol):
+    """Inner loop shared by the lambda search (pybold/bold_signal.py:114-138 and
+    :185-209): the fixed-lambda recurrence, momentum restarted, window rule."""
+    hist = []
+    t_old = 1.0
+    for j in range(nb_sub_iter):
+        u = w - step * (H.adj(H.op(w)) - H_adj_y)
+        if j > 0 and hist:
+            hist[-1] = u
+        prev = u if j > 0 else 0.0
+        p = soft_threshold(u, th)
+        t = 0.5 * (1.0 + np.sqrt(1.0 + 4.0 * t_old ** 2))
+        w = p + (t_old - 1.0) / t * (p - prev)
+        t_old = t
+        hist.append(w)
+        if len(hist) > wind:
+            hist = hist[1:]
+        if early_stopping and j > wind and _window_stop(hist, wind, tol):
+            break
+    return w
+
+
+def deconv_auto_lbda(y, hrf, sigma, lipschitz, early_stopping=True, tol=1.0e-6, wind=6,
+                     nb_iter=1000, nb_sub_iter=1000):
+    """lbda=None branch of ``deconv`` (pybold/bold_signal.py:99-214) for a given
+    noise level ``sigma`` (:103) and Lipschitz constant (:52): outer loop
+    ``alpha += mu (||x - y||^2 - N sigma^2)``, ``lbda = 1 / (2 alpha)`` (:141-145)
+    around warm-started inner solves, windowed stop on ``alpha`` (:164-178), final
+    inner solve (:181-209).  Returns ``(x, z, w, J, R, G)`` as lists like the
+    reference.  UNPINNED (the reference branch needs pywt and could not be run)."""
+    y = np.asarray(y, dtype=np.float64)
+    n = len(y)
+    hrf = np.asarray(hrf, dtype=np.float64)
+    H = _MatrixFreeH(hrf)
+    H_adj_y = H.adj(y)
+    step = 1.0 / lipschitz
+    w = np.zeros(n)
+    alpha, mu = 1.0, 1.0e-4
+    lbda = 1.0 / (2.0 * alpha)
+    l_alpha, J, R, G = [], [], [], []
+    for i in range(nb_iter):
+        w = _inner_fista(w, H, H_adj_y, step, lbda / lipschitz, nb_sub_iter, early_stopping,
+                         wind, tol)
+        z = np.cumsum(w)
+        x = causal_conv(hrf, z)
+        grad = np.sum(np.square(x - y)) - n * sigma ** 2
+        alpha += mu * grad
+        lbda = 1.0 / (2.0 * alpha)
+        l_alpha.append(alpha)
+        if len(l_alpha) > wind:
+            l_alpha = l_alpha[1:]
+        r = np.sum(np.square(x - y))
+        g = np.sum(np.abs(w))
+        R.append(r)
+        G.append(g)
+        J.append(0.5 * r + lbda * g)
+        if early_stopping and i > wind:
+            half = int(wind / 2)
+            old = np.mean(l_alpha[:-half])
+            new = np.mean(l_alpha[-half:])
+            if np.abs(new - old) / np.abs(new) < tol:
+                break
+    w = _inner_fista(w, H, H_adj_y, step, lbda / lipschitz, nb_sub_iter, early_stopping, wind, tol)
+    z = np.cumsum(w)
+    x = causal_conv(hrf, z)
+    return x, z, w, J, R, G

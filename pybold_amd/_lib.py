@@ -37,6 +37,8 @@ SIGNATURES = {
         ctypes.c_uint, _ptr]),           # flags, stream
     "pb_fista_outputs": (_c_int, [_ptr, _c_i64, _c_int, _c_int, _ptr, _c_int,
                                   _ptr, _c_i64, _ptr, _c_i64, _ptr]),
+    "pb_fista_stats": (_c_int, [_ptr, _c_i64, _ptr, _c_i64, _c_int, _c_int, _c_int, _ptr,
+                                _c_int, _ptr, _ptr, _ptr]),
     "pb_integ_op": (_c_int, [_ptr, _c_i64, _ptr, _c_i64, _c_int, _c_int, _ptr]),
     "pb_integ_adj": (_c_int, [_ptr, _c_i64, _ptr, _c_i64, _c_int, _c_int, _ptr]),
     "pb_conv": (_c_int, [_ptr, _c_i64, _ptr, _c_i64, _c_int, _c_int, _c_int,

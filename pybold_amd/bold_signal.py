@@ -12,8 +12,9 @@ Deviations from the reference, all deliberate:
     on chip); outputs are float64 like the reference's;
   * ``_loops_deconv`` does not overwrite the caller's ``diff_z`` (the reference
     does at :261; every caller rebinds the returned array);
-  * ``deconv(lbda=None)`` (noise-driven lambda search, :99-214) needs the db3
-    wavelet noise estimate and is not implemented yet.
+  * ``deconv(lbda=None)`` (noise-driven lambda search, :99-214) estimates the
+    noise level with an in-package db3 detail band instead of PyWavelets
+    (``utils.mad_daub_noise_est``; parity of that estimate is unpinned).
 There is no CPU fallback: without the HIP library or a GPU these raise.
 """
 import numpy as np
@@ -24,7 +25,7 @@ from . import solver
 from .convolution import kernel_from_toeplitz, toeplitz_from_kernel
 from .hrf_model import MAX_DELTA, MIN_DELTA, spm_hrf
 from .linear import ConvAndLinear, DiscretInteg
-from .utils import gram_frobenius, spectral_radius_est
+from .utils import gram_frobenius, mad_daub_noise_est, spectral_radius_est
 
 
 def _y_to_device(y):
@@ -56,9 +57,7 @@ def deconv(y, t_r, hrf, lbda=None, early_stopping=True, tol=1.0e-6,  # noqa
     ``(V, max iterations run)`` padded with NaN after a voxel's early stop.
     """
     if lbda is None:
-        raise NotImplementedError(
-            "deconv(lbda=None): the noise-driven lambda search "
-            "(pybold/bold_signal.py:99-214) is not implemented in this build")
+        return _deconv_auto_lbda(y, hrf, early_stopping, tol, wind, nb_iter, nb_sub_iter, verbose)
     Y, one_d = _y_to_device(y)
     n = Y.shape[1]
     hrf = np.asarray(hrf, dtype=np.float64)
@@ -79,6 +78,78 @@ def deconv(y, t_r, hrf, lbda=None, early_stopping=True, tol=1.0e-6,  # noqa
     if one_d:
         return _host(X, True), _host(Z, True), _host(W, True), J[0, :n_done[0]], None, None
     return _host(X, False), _host(Z, False), _host(W, False), J, None, None
+
+
+def _deconv_auto_lbda(y, hrf, early_stopping, tol, wind, nb_iter, nb_sub_iter, verbose):
+    """``lbda=None`` branch of ``deconv`` (pybold/bold_signal.py:99-214), batched.
+
+    Per voxel: ``sigma`` = db3 MAD noise level (:103); ``alpha_0 = 1``,
+    ``lbda = 1/(2 alpha)``, ``mu = 1e-4`` (:104-106); each outer iteration runs a
+    warm-started inner solve of at most ``nb_sub_iter`` iterations with the
+    window rule (ONE kernel launch for all voxels, per-voxel lambda), then
+    ``alpha += mu (||x - y||^2 - N sigma^2)`` (:141-145); a voxel leaves the
+    outer loop on the windowed ``alpha`` rule (:164-178) and keeps its iterate;
+    a last inner solve (:181-209) ends the run.  Returns ``(x, z, diff_z, J, R, G)``:
+    lists of floats for a 1-D ``y`` (as the reference), ``(n_outer, V)`` arrays
+    padded with NaN for a batch.
+    """
+    y_host = y.detach().cpu().numpy() if torch.is_tensor(y) else np.asarray(y, dtype=np.float64)
+    sigma = np.atleast_1d(mad_daub_noise_est(y_host))
+    Y, one_d = _y_to_device(y)
+    V, n = Y.shape
+    dev = Y.device
+    hrf = np.asarray(hrf, dtype=np.float64)
+    H = ConvAndLinear(DiscretInteg(), hrf, dim_in=n, dim_out=n)
+    grad_lipschitz_cst = 0.9 * spectral_radius_est(H, (n,))
+    step = 1.0 / grad_lipschitz_cst
+    stop = "window" if early_stopping else None
+
+    alpha = np.ones(V)
+    lbda = 1.0 / (2.0 * alpha)
+    mu = 1.0e-4
+    active = np.ones(V, dtype=bool)
+    l_alpha = []                                   # last `wind` alpha vectors
+    J, R, G = [], [], []
+    W = torch.zeros((V, n), dtype=torch.float64, device=dev)
+    for i in range(nb_iter):
+        W_new, _, _ = solver.fista_solve(Y, hrf, lbda, step, int(nb_sub_iter), W0=W, stop=stop,
+                                         tol=tol, wind=wind)
+        if active.all():
+            W = W_new
+        else:
+            W = torch.where(torch.from_numpy(active).to(dev)[:, None], W_new, W)
+        r2, l1 = solver.fista_stats(W, Y, hrf)
+        r, g = r2.cpu().numpy(), l1.cpu().numpy()
+        grad = r - n * sigma ** 2
+        alpha = np.where(active, alpha + mu * grad, alpha)
+        lbda = 1.0 / (2.0 * alpha)
+        l_alpha.append(alpha.copy())
+        if len(l_alpha) > wind:
+            l_alpha = l_alpha[1:]
+        nan = np.where(active, 0.0, np.nan)
+        R.append(r + nan)
+        G.append(g + nan)
+        J.append(0.5 * r + lbda * g + nan)
+        if verbose > 0:
+            print("Main loop: iteration {0:03d}, |grad| = {1:0.6f}, lbda = {2:0.6f},".format(
+                i + 1, float(np.abs(grad[active]).mean()), float(lbda[active].mean())))
+        if early_stopping and i > wind:
+            sub_wind_len = int(wind / 2)
+            old_iter = np.mean(l_alpha[:-sub_wind_len], axis=0)
+            new_iter = np.mean(l_alpha[-sub_wind_len:], axis=0)
+            diff = np.abs(new_iter - old_iter) / np.abs(new_iter)
+            active &= ~(diff < tol)
+            if not active.any():
+                break
+    W, _, _ = solver.fista_solve(Y, hrf, lbda, step, int(nb_sub_iter), W0=W, stop=stop, tol=tol,
+                                 wind=wind)
+    X, Z = solver.fista_outputs(W, hrf)
+    if one_d:
+        keep = [k for k in range(len(J)) if not np.isnan(J[k][0])]
+        return (_host(X, True), _host(Z, True), _host(W, True), [float(J[k][0]) for k in keep],
+                [float(R[k][0]) for k in keep], [float(G[k][0]) for k in keep])
+    return (_host(X, False), _host(Z, False), _host(W, False), np.array(J), np.array(R),
+            np.array(G))
 
 
 def hrf_fit_err(theta, z, y, t_r, hrf_dur):

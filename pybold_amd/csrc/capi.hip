@@ -8,6 +8,7 @@
 
 #include "fista_fast.h"
 #include "generic.h"
+#include "launch_fast.h"
 
 namespace {
 
@@ -34,27 +35,24 @@ constexpr int LDS_DOUBLES_MAX = 20000;  // 160 KB of LDS per workgroup
 typedef int (*fast_launch_fn)(const pb::FistaArgs&, const double* taps, int K, bool with_j,
                               int stop, hipStream_t);
 
-template <int S, int KT>
-int launch_fast(const pb::FistaArgs& a, const double* taps, int K, bool with_j, int stop,
-                hipStream_t st) {
-  const auto tp = pb::make_tap_pairs<KT>(taps, K);
-  const dim3 grid((unsigned)(((int64_t)a.P * 16 + 255) / 256)), block(256);
-  if (stop == PB_STOP_NONE) {
-    if (with_j) hipLaunchKernelGGL((pb::fista_fast_kernel<S, KT, true, 0>), grid, block, 0, st, a, tp);
-    else hipLaunchKernelGGL((pb::fista_fast_kernel<S, KT, false, 0>), grid, block, 0, st, a, tp);
-  } else {
-    if (with_j) hipLaunchKernelGGL((pb::fista_fast_kernel<S, KT, true, 1>), grid, block, 0, st, a, tp);
-    else hipLaunchKernelGGL((pb::fista_fast_kernel<S, KT, false, 1>), grid, block, 0, st, a, tp);
-  }
-  return check_launch("fista_fast_kernel");
-}
-
 struct FastEntry {
   int S, KT;
   fast_launch_fn fn;
 };
 
-#define PB_FAST(S, KT) {S, KT, &launch_fast<S, KT>}
+}  // namespace
+
+// instantiated in fast_inst.hip, one translation unit per table entry
+namespace pb {
+#define PB_FAST(S, KT) \
+  extern template int launch_fast<S, KT>(const FistaArgs&, const double*, int, bool, int, hipStream_t);
+#include "fast_table.inc"
+#undef PB_FAST
+}  // namespace pb
+
+namespace {
+
+#define PB_FAST(S, KT) {S, KT, &pb::launch_fast<S, KT>},
 const FastEntry kFast[] = {
 #include "fast_table.inc"
 };
@@ -123,7 +121,10 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
 
   const FastEntry* fe = (flags & PB_FLAG_FORCE_GENERIC) ? nullptr : pick_fast(N, K);
   if (fe && stop_mode == PB_STOP_WINDOW) fe = nullptr;   // window rule: LDS kernel only
-  if (fe) return fe->fn(a, taps_host, K, J_dev != nullptr, stop_mode, (hipStream_t)stream);
+  if (fe) {
+    fe->fn(a, taps_host, K, J_dev != nullptr, stop_mode, (hipStream_t)stream);
+    return check_launch("fista_fast_kernel");
+  }
   if (flags & PB_FLAG_FORCE_FAST)
     return fail(PB_ERR_INVALID, "pb_fista_solve: no register-resident kernel for N=%d K=%d stop=%d",
                 N, K, stop_mode);
@@ -156,6 +157,21 @@ int pb_fista_outputs(const double* w_dev, int64_t ldw, int P, int N, const doubl
   hipLaunchKernelGGL(pb::outputs_kernel, dim3(P), dim3(pb::GEN_THREADS), lds, (hipStream_t)stream,
                      w_dev, ldw, N, taps_dev, K, z_dev, ldz, x_dev, ldx);
   return check_launch("outputs_kernel");
+}
+
+int pb_fista_stats(const double* w_dev, int64_t ldw, const float* y_dev, int64_t ldy, int y_rep,
+                   int P, int N, const double* taps_dev, int K, double* r2_dev, double* l1_dev,
+                   void* stream) {
+  if (!w_dev || !y_dev || !taps_dev || !r2_dev || !l1_dev || P < 0 || N < 1 || K < 1 ||
+      y_rep < 1 || ldw < N || ldy < N)
+    return fail(PB_ERR_INVALID, "pb_fista_stats: bad argument");
+  if (2 * (int64_t)N + K + 8 > LDS_DOUBLES_MAX)
+    return fail(PB_ERR_INVALID, "pb_fista_stats: N=%d K=%d exceeds LDS", N, K);
+  if (P == 0) return PB_OK;
+  const size_t lds = (size_t)(2 * N + K + 8) * sizeof(double);
+  hipLaunchKernelGGL(pb::stats_kernel, dim3(P), dim3(pb::GEN_THREADS), lds, (hipStream_t)stream,
+                     w_dev, ldw, y_dev, ldy, y_rep, N, taps_dev, K, r2_dev, l1_dev);
+  return check_launch("stats_kernel");
 }
 
 int pb_integ_op(const double* x, int64_t ldx, double* out, int64_t ldo, int V, int N, void* st) {

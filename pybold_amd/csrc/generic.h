@@ -55,10 +55,10 @@ __device__ __forceinline__ void block_cumsum(const double* src, double* dst, int
   double woff = 0.0;
   for (int i = 0; i < wid; ++i) woff += red[i];
   double run = woff + incl - local;
-  __syncthreads();   // all reads of src done before dst (may alias) is written
-  // (each thread only rewrites its own chunk, and read it above, so aliasing is safe)
+  __syncthreads();
+  // dst may alias src: a thread reads an element of its own chunk right before
+  // it overwrites it and never touches another thread's chunk
   for (int i = lo; i < hi; ++i) {
-    // re-read is safe: this thread is the only writer of its chunk
     run += src[idx(i)];
     dst[idx(i)] = run;
   }
@@ -179,6 +179,42 @@ __global__ __launch_bounds__(GEN_THREADS) void hrf_cost_kernel(const double* z, 
   }
   const double tot = block_sum(sq, red);
   if (threadIdx.x == 0) cost[(int64_t)c * V + v] = 0.5 * tot;
+}
+
+// r2[p] = || taps * cumsum(w_p) - y_p ||^2 , l1[p] = || w_p ||_1
+// (the quantities R, G the lambda search tracks, pybold/bold_signal.py:141-157)
+__global__ __launch_bounds__(GEN_THREADS) void stats_kernel(const double* w, int64_t ldw,
+                                                            const float* y, int64_t ldy, int y_rep,
+                                                            int N, const double* taps, int K,
+                                                            double* r2, double* l1) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* a = reinterpret_cast<double*>(smem);
+  double* b = a + N;
+  double* k = b + N;
+  double* red = k + K;
+  const int p = blockIdx.x;
+  const double* wr = w + (int64_t)p * ldw;
+  const float* yr = y + (int64_t)(p / y_rep) * ldy;
+  double part_l1 = 0.0;
+  for (int i = threadIdx.x; i < N; i += GEN_THREADS) {
+    a[i] = wr[i];
+    part_l1 += fabs(a[i]);
+  }
+  for (int i = threadIdx.x; i < K; i += GEN_THREADS) k[i] = taps[i];
+  __syncthreads();
+  block_cumsum<false>(a, a, N, red);
+  block_conv(a, N, b, N, k, K);
+  double part_r2 = 0.0;
+  for (int i = threadIdx.x; i < N; i += GEN_THREADS) {
+    const double d = b[i] - (double)yr[i];
+    part_r2 = fma(d, d, part_r2);
+  }
+  const double tot_r2 = block_sum(part_r2, red);
+  const double tot_l1 = block_sum(part_l1, red);
+  if (threadIdx.x == 0) {
+    r2[p] = tot_r2;
+    l1[p] = tot_l1;
+  }
 }
 
 // ---- generic FISTA: one workgroup per problem, float64 state in LDS ---------

@@ -1,0 +1,26 @@
+// Host-side launcher of one (S, KT) specialisation of fista_fast_kernel.  Each
+// specialisation is instantiated in its own translation unit (fast_inst.hip with
+// -DPB_S/-DPB_KT) so the table builds in parallel; capi.hip only sees the
+// extern template declarations.
+#pragma once
+#include "../../include/pybold_hip.h"
+#include "fista_fast.h"
+
+namespace pb {
+
+template <int S, int KT>
+int launch_fast(const FistaArgs& a, const double* taps, int K, bool with_j, int stop,
+                hipStream_t st) {
+  const auto tp = make_tap_pairs<KT>(taps, K);
+  const dim3 grid((unsigned)(((int64_t)a.P * 16 + 255) / 256)), block(256);
+  if (stop == PB_STOP_NONE) {
+    if (with_j) hipLaunchKernelGGL((fista_fast_kernel<S, KT, true, 0>), grid, block, 0, st, a, tp);
+    else hipLaunchKernelGGL((fista_fast_kernel<S, KT, false, 0>), grid, block, 0, st, a, tp);
+  } else {
+    if (with_j) hipLaunchKernelGGL((fista_fast_kernel<S, KT, true, 1>), grid, block, 0, st, a, tp);
+    else hipLaunchKernelGGL((fista_fast_kernel<S, KT, false, 1>), grid, block, 0, st, a, tp);
+  }
+  return 0;
+}
+
+}  // namespace pb

@@ -193,6 +193,25 @@ def fista_outputs(W, hrf):
     return X, Z
 
 
+def fista_stats(W, Y, hrf, y_rep=1):
+    """Per-problem ``||hrf * cumsum(w) - y||^2`` and ``||w||_1`` (float64 ``(P,)``
+    each): the R / G terms of pybold/bold_signal.py:141-157."""
+    lib = _lib.load()
+    W = _rows(W, torch.float64, "W")
+    Y = _rows(Y, torch.float32, "Y")
+    dev = W.device
+    P, N = W.shape
+    taps_dev = torch.from_numpy(_as_taps(hrf)).to(dev)
+    r2 = torch.empty((P,), dtype=torch.float64, device=dev)
+    l1 = torch.empty((P,), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.pb_fista_stats(W.data_ptr(), _ld(W), Y.data_ptr(), _ld(Y), int(y_rep), P, N,
+                                taps_dev.data_ptr(), taps_dev.numel(), r2.data_ptr(),
+                                l1.data_ptr(), _stream_ptr(dev))
+    _lib.check(rc, "pb_fista_stats")
+    return r2, l1
+
+
 def _apply(fn_name, X, n_out, taps=None, n_in=None):
     lib = _lib.load()
     X = _rows(X, torch.float64, "x")

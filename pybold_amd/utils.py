@@ -38,3 +38,36 @@ def inf_norm(x):
     """``x / (max|x| + 1e-12)`` (pybold/utils.py:112-115), 1-D helper."""
     x = np.asarray(x, dtype=np.float64)
     return x / (np.max(np.abs(x)) + 1.0e-12)
+
+
+# db3 decomposition high-pass filter (PyWavelets' Wavelet('db3').dec_hi)
+_DB3_DEC_HI = np.array([-0.3326705529509569, 0.8068915093133388, -0.4598775021193313,
+                        -0.13501102001039084, 0.08544127388224149, 0.035226291882100656])
+
+
+def mad(x, c=0.6744):
+    """Median absolute deviation / c along the last axis (pybold/utils.py:10-13)."""
+    x = np.asarray(x, dtype=np.float64)
+    med = np.median(x, axis=-1, keepdims=True)
+    return np.median(np.abs(x - med), axis=-1) / c
+
+
+def mad_daub_noise_est(x, c=0.6744):
+    """Noise level from the MAD of the level-1 db3 detail coefficients
+    (pybold/utils.py:16-25), for a 1-D signal or every row of a 2-D batch.  The
+    reference calls PyWavelets; here the level-1 detail band is computed directly
+    (6-tap high-pass, half-sample symmetric extension, stride 2:
+    ``cD[k] = sum_j g[j] xe[2k + 1 - j]``, ``(N + 5) // 2`` coefficients).
+    Parity of this function is unpinned (PyWavelets is absent from the build image)."""
+    x = np.asarray(x, dtype=np.float64)
+    F = len(_DB3_DEC_HI)
+    n = x.shape[-1]
+    if n < F - 1:
+        raise ValueError("signal too short for a db3 decomposition")
+    xe = np.concatenate([np.flip(x[..., :F - 1], -1), x, np.flip(x, -1)[..., :F - 1]], axis=-1)
+    n_out = (n + F - 1) // 2
+    cD = np.zeros(x.shape[:-1] + (n_out,))
+    base = 1 + (F - 1) + 2 * np.arange(n_out)        # index of x_ext[2k + 1] in xe
+    for j in range(F):
+        cD += _DB3_DEC_HI[j] * xe[..., base - j]
+    return mad(cD, c=c)

@@ -102,7 +102,9 @@ def test_warm_start_chunks_equal_one_run(pa, golden):
 
 
 @pytest.mark.parametrize("N,K", [(300, 30), (290, 30), (304, 30), (17, 5), (40, 30), (300, 1),
-                                 (33, 27), (1, 1), (16, 2)])
+                                 (33, 27), (1, 1), (16, 2), (600, 30), (284, 28), (384, 32),
+                                 (240, 27), (160, 30), (128, 16), (300, 27), (300, 32), (608, 29),
+                                 (700, 30), (300, 40)])
 def test_edge_shapes_fast_and_generic_agree_with_oracle(pa, N, K):
     _, solver = pa
     rng = np.random.RandomState(N * 100 + K)
@@ -195,6 +197,44 @@ def test_deconv_batch_matches_single(pa, golden):
     for s in range(4):
         assert rel_rows(W[s], g["dz_s%d_l1_n10" % s]) < EPS
         np.testing.assert_allclose(J[s], g["J_s%d_l1_n10" % s], rtol=2e-5)
+
+
+def test_deconv_auto_lambda_matches_oracle(pa, golden):
+    """lbda=None branch (pybold/bold_signal.py:99-214): GPU vs the oracle's
+    restatement, same noise estimate; 1-D (lists, as the reference) and batched."""
+    pybold_amd, _ = pa
+    g, Y, hrf, lip = grid_inputs(golden)
+    kw = dict(early_stopping=True, tol=1e-3, wind=6, nb_iter=14, nb_sub_iter=40)
+    refs = []
+    for s in range(4):
+        y32 = Y[s].astype(np.float32).astype(np.float64)
+        sigma = orc.mad_daub_noise_est(Y[s])
+        refs.append(orc.deconv_auto_lbda(y32, hrf, sigma, lip, **kw))
+    np.random.seed(0)
+    x, z, dz, J, R, G = pybold_amd.deconv(Y[1], 1.0, hrf, lbda=None, **kw)
+    xr, zr, wr, Jr, Rr, Gr = refs[1]
+    assert isinstance(J, list) and len(J) == len(Jr)
+    assert rel_rows(dz, wr) < EPS and rel_rows(x, xr) < EPS and rel_rows(z, zr) < EPS
+    np.testing.assert_allclose(J, Jr, rtol=1e-5)
+    np.testing.assert_allclose(R, Rr, rtol=1e-5)
+    np.testing.assert_allclose(G, Gr, rtol=1e-5)
+    np.random.seed(0)
+    X, Z, W, Jb, Rb, Gb = pybold_amd.deconv(Y, 1.0, hrf, lbda=None, **kw)
+    for s in range(4):
+        assert rel_rows(W[s], refs[s][2]) < EPS, s
+        n_out = len(refs[s][3])
+        np.testing.assert_allclose(Jb[:n_out, s], refs[s][3], rtol=1e-5)
+        assert np.isnan(Jb[n_out:, s]).all()
+
+
+def test_fista_stats(pa, golden):
+    _, solver = pa
+    g = golden("case1")
+    W = dev64(g["diff_z"][None])
+    r2, l1 = solver.fista_stats(W, dev32(g["y"][None]), g["hrf"])
+    y32 = g["y"].astype(np.float32).astype(np.float64)
+    assert float(r2[0]) == pytest.approx(np.sum(np.square(g["x"] - y32)), rel=1e-10)
+    assert float(l1[0]) == pytest.approx(np.abs(g["diff_z"]).sum(), rel=1e-12)
 
 
 def test_operator_surface_goldens(pa, golden):

@@ -64,6 +64,25 @@ def test_spectral_radius_est_is_duck_typed(golden):
     assert 0.9 * rho == pytest.approx(float(g["lipschitz"]), rel=1e-13)
 
 
+def test_mad_daub_noise_est_properties():
+    """db3 level-1 detail band + MAD (pybold/utils.py:10-25).  Unpinned against
+    PyWavelets; checked against the filter's defining properties instead."""
+    from pybold_amd.utils import _DB3_DEC_HI, mad, mad_daub_noise_est
+    g = _DB3_DEC_HI
+    assert abs(g.sum()) < 1e-10 and abs((g ** 2).sum() - 1.0) < 1e-10     # orthonormal high-pass
+    assert abs((g * np.arange(6)).sum()) < 1e-9                           # vanishing moments
+    assert abs((g * np.arange(6) ** 2).sum()) < 1e-9
+    rng = np.random.RandomState(0)
+    X = rng.randn(64, 300) * 2.5
+    est = mad_daub_noise_est(X)
+    np.testing.assert_allclose(est, [orc.mad_daub_noise_est(x) for x in X], rtol=1e-12)
+    assert abs(est.mean() - 2.5) < 0.15                                   # consistent for white noise
+    t = np.linspace(0, 1, 300)
+    assert mad_daub_noise_est(3.0 + 2.0 * t + 0.5 * t ** 2) < 1e-8        # blind to quadratics
+    assert mad(np.array([1., 2., 3., 4., 100.]), c=1.0) == 1.0
+    assert mad_daub_noise_est(X[0]) == pytest.approx(est[0])              # 1-D form
+
+
 def test_shard_bounds_cover_everything_once():
     for n in (0, 1, 7, 100000, 100001):
         for world in (1, 2, 3, 8):
