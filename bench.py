@@ -49,6 +49,22 @@ def parse():
 
 def main():
     args = parse()
+    # Everything but the final JSON line goes to stderr, including what native
+    # libraries (RCCL's version banner) write to file descriptor 1.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        line = run(args)
+    finally:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
+    if line is not None:
+        print(line, flush=True)
+
+
+def run(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -61,9 +77,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from pybold_amd import data, solver
@@ -151,10 +168,9 @@ def main():
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"], out["parity"] = cpu_baseline(Y, plan.W, hrf, args.lbda, step, n_iter,
                                                           args.cpu_seconds)
-    if rank == 0:
-        print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    return json.dumps(out) if rank == 0 else None
 
 
 def cpu_baseline(Y, W_gpu, hrf, lbda, step, n_iter, target_s):

@@ -120,7 +120,9 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
   a.y_rep = y_rep; a.P = P; a.N = N; a.n_iter = n_iter; a.stop_mode = stop_mode;
 
   const FastEntry* fe = (flags & PB_FLAG_FORCE_GENERIC) ? nullptr : pick_fast(N, K);
-  if (fe && stop_mode == PB_STOP_WINDOW) fe = nullptr;   // window rule: LDS kernel only
+  // the register-resident window rule keeps wind-1 = 5 iterates in VGPRs: wind = 6
+  // (the reference default) on entries small enough to hold them; else LDS kernel
+  if (fe && stop_mode == PB_STOP_WINDOW && (wind != 6 || fe->S > 20)) fe = nullptr;
   if (fe) {
     fe->fn(a, taps_host, K, J_dev != nullptr, stop_mode, (hipStream_t)stream);
     return check_launch("fista_fast_kernel");

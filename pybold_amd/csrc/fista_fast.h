@@ -134,6 +134,17 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
     asm volatile("" : "+v"(odd_v[t]));
   }
 
+  // window rule: the last WIND-1 gradient-step points, float64, slot = iteration mod 5
+  constexpr int WIND = 6;
+  constexpr int HDEPTH = WIND - 1;
+  double hist[STOP == 2 ? HDEPTH : 1][STOP == 2 ? S : 1];
+  if constexpr (STOP == 2) {
+#pragma unroll
+    for (int q = 0; q < HDEPTH; ++q)
+#pragma unroll
+      for (int j = 0; j < S; ++j) hist[q][j] = 0.0;
+  }
+
   bool active = true;                       // per-problem (row-uniform) early-stop state
   int done = 0;
   float* Jrow = WITH_J ? a.J + (int64_t)p * a.ldj : nullptr;
@@ -266,18 +277,54 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
         w[j] = fma(nb1, d, u);
       }
     } else {
-      // _loops_deconv rule (pybold/bold_signal.py:267-273):
-      //   ||w' - u|| / (||w'|| + 1e-10) < tol, tested from the 4th iteration on
-      double wn[S];
+      // One pass per sample: gradient step, prox+momentum, stop-rule partial sums.
+      // A stopped problem (row) keeps its iterate: the select is per lane.
       double num = 0.0, den = 0.0;
+      double floor_eps = 1.0e-10;
+      if constexpr (STOP == 1) {
+        // _loops_deconv rule (pybold/bold_signal.py:267-273):
+        //   ||w' - u|| / (||w'|| + 1e-10) < tol, tested from the 4th iteration on
 #pragma unroll
-      for (int j = 0; j < S; ++j) {
-        const double u = fma(nstep, (double)g[j], w[j]);
-        const double d = fmin(fmax(u, -th), th);
-        wn[j] = fma(nb1, d, u);
-        const double diff = wn[j] - u;
-        num = fma(diff, diff, num);
-        den = fma(wn[j], wn[j], den);
+        for (int j = 0; j < S; ++j) {
+          const double u = fma(nstep, (double)g[j], w[j]);
+          const double d = fmin(fmax(u, -th), th);
+          const double wn = fma(nb1, d, u);
+          const double diff = wn - u;
+          num = fma(diff, diff, num);
+          den = fma(wn, wn, den);
+          w[j] = active ? wn : w[j];
+        }
+      } else {
+        // deconv window rule, wind = 6 (pybold/bold_signal.py:82-95): the stored
+        // iterates are [u_{k-4} .. u_k, w_{k+1}] (each stored w was overwritten in
+        // place by the next gradient step, :65/:72); old = mean of the first three,
+        // new = mean of the last three.  Sums are left unscaled (x3), so is the
+        // 1e-10 floor.  u_k lives in slot k mod 5; the switch makes slots static.
+        floor_eps = 3.0e-10;
+        auto crit = [&](auto slc) {
+          constexpr int sl = decltype(slc)::value;
+#pragma unroll
+          for (int j = 0; j < S; ++j) {
+            const double u = fma(nstep, (double)g[j], w[j]);
+            const double d = fmin(fmax(u, -th), th);
+            const double wn = fma(nb1, d, u);
+            const double so = (hist[(sl + 1) % HDEPTH][j] + hist[(sl + 2) % HDEPTH][j]) +
+                              hist[(sl + 3) % HDEPTH][j];
+            const double sn = (hist[(sl + 4) % HDEPTH][j] + u) + wn;
+            const double diff = sn - so;
+            num = fma(diff, diff, num);
+            den = fma(sn, sn, den);
+            hist[sl][j] = u;
+            w[j] = active ? wn : w[j];
+          }
+        };
+        switch (it % HDEPTH) {
+          case 0: crit(std::integral_constant<int, 0>{}); break;
+          case 1: crit(std::integral_constant<int, 1>{}); break;
+          case 2: crit(std::integral_constant<int, 2>{}); break;
+          case 3: crit(std::integral_constant<int, 3>{}); break;
+          default: crit(std::integral_constant<int, 4>{}); break;
+        }
       }
       // row all-reduce of the two float64 partial sums
       static_for<0, 4>([&](auto sc) {
@@ -292,10 +339,9 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
         den += rot(den);
       });
       if (active) {
-#pragma unroll
-        for (int j = 0; j < S; ++j) w[j] = wn[j];
         done = it + 1;
-        if (it > 2 && sqrt(num) / (sqrt(den) + 1.0e-10) < a.tol) active = false;
+        const int first_test = (STOP == 1) ? 3 : WIND + 1;
+        if (it >= first_test && sqrt(num) / (sqrt(den) + floor_eps) < a.tol) active = false;
       }
       if (__builtin_amdgcn_ballot_w64(active) == 0) n_stop = it + 1;
     }

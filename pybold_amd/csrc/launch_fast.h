@@ -16,9 +16,12 @@ int launch_fast(const FistaArgs& a, const double* taps, int K, bool with_j, int 
   if (stop == PB_STOP_NONE) {
     if (with_j) hipLaunchKernelGGL((fista_fast_kernel<S, KT, true, 0>), grid, block, 0, st, a, tp);
     else hipLaunchKernelGGL((fista_fast_kernel<S, KT, false, 0>), grid, block, 0, st, a, tp);
-  } else {
+  } else if (stop == PB_STOP_LOOPS) {
     if (with_j) hipLaunchKernelGGL((fista_fast_kernel<S, KT, true, 1>), grid, block, 0, st, a, tp);
     else hipLaunchKernelGGL((fista_fast_kernel<S, KT, false, 1>), grid, block, 0, st, a, tp);
+  } else {   // PB_STOP_WINDOW with wind = 6 (checked by the caller)
+    if (with_j) hipLaunchKernelGGL((fista_fast_kernel<S, KT, true, 2>), grid, block, 0, st, a, tp);
+    else hipLaunchKernelGGL((fista_fast_kernel<S, KT, false, 2>), grid, block, 0, st, a, tp);
   }
   return 0;
 }
