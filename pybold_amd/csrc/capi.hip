@@ -100,11 +100,11 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
                    const double* lbda_dev, const double* betas_dev, int n_iter, float* J_dev,
                    int64_t ldj, int stop_mode, double tol, int wind, int32_t* n_done_dev,
                    unsigned flags, void* stream) {
-  if (!y_dev || !w_dev || !taps_host || (n_iter > 0 && !betas_dev))
-    return fail(PB_ERR_INVALID, "pb_fista_solve: NULL pointer");
   if (P < 0 || N < 1 || K < 1 || n_iter < 0 || y_rep < 1)
     return fail(PB_ERR_INVALID, "pb_fista_solve: bad size (P=%d N=%d K=%d n_iter=%d y_rep=%d)", P,
                 N, K, n_iter, y_rep);
+  if (P > 0 && (!y_dev || !w_dev || !taps_host || (n_iter > 0 && !betas_dev)))
+    return fail(PB_ERR_INVALID, "pb_fista_solve: NULL pointer");
   if (ldy < N || ldw < N) return fail(PB_ERR_INVALID, "pb_fista_solve: leading dimension < N");
   if (J_dev && ldj < n_iter) return fail(PB_ERR_INVALID, "pb_fista_solve: ldj < n_iter");
   if (!(step > 0.0)) return fail(PB_ERR_INVALID, "pb_fista_solve: step must be positive");
@@ -149,6 +149,7 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
 
 int pb_fista_outputs(const double* w_dev, int64_t ldw, int P, int N, const double* taps_dev, int K,
                      double* z_dev, int64_t ldz, double* x_dev, int64_t ldx, void* stream) {
+  if (P == 0 && N >= 1 && K >= 1) return PB_OK;
   if (!w_dev || !taps_dev || P < 0 || N < 1 || K < 1 || ldw < N || (z_dev && ldz < N) ||
       (x_dev && ldx < N))
     return fail(PB_ERR_INVALID, "pb_fista_outputs: bad argument");

@@ -311,6 +311,58 @@ def test_bd_five_outer_iterations(pa, golden):
     assert rel_rows(x, g["x"]) < 1e-3
 
 
+def test_plan_is_graph_capture_safe(pa, golden):
+    """pb_fista_solve allocates nothing and never synchronises: a FistaPlan can be
+    captured in a HIP graph and replayed (launch-bound inner loops)."""
+    _, solver = pa
+    g, Y, hrf, lip = grid_inputs(golden)
+    plan = solver.FistaPlan(dev32(Y), hrf, 1.0, 1.0 / lip, 10)
+    plan.run()
+    torch.cuda.synchronize()
+    eager = plan.W.clone()
+    stream = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(stream):
+        plan.run()                       # warm the capture stream
+        stream.synchronize()
+        with torch.cuda.graph(graph, stream=stream):
+            plan.run()
+    plan.W.fill_(7.0)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(plan.W, eager)
+    ref = np.stack([g["dz_s%d_l1_n10" % s] for s in range(4)])
+    assert rel_rows(plan.W.cpu().numpy(), ref) < EPS
+
+
+def test_empty_batch_is_a_no_op(pa, golden):
+    _, solver = pa
+    g, Y, hrf, lip = grid_inputs(golden)
+    W, J, n_done = solver.fista_solve(dev32(Y[:0]), hrf, 1.0, 1.0 / lip, 5, want_J=True)
+    assert W.shape == (0, 300) and J.shape == (0, 5) and n_done.shape == (0,)
+    X, Z = solver.fista_outputs(W, hrf)
+    assert X.shape == (0, 300)
+
+
+def test_inputs_are_not_modified(pa, golden):
+    pybold_amd, solver = pa
+    g, Y, hrf, lip = grid_inputs(golden)
+    y0 = Y[0].copy()
+    np.random.seed(0)
+    pybold_amd.deconv(Y[0], 1.0, hrf, lbda=1.0, nb_iter=3, early_stopping=False)
+    np.testing.assert_array_equal(Y[0], y0)                      # y untouched (reference contract)
+    W0 = dev64(np.random.RandomState(0).randn(4, 300) * 0.01)
+    keep = W0.clone()
+    solver.fista_solve(dev32(Y), hrf, 1.0, 1.0 / lip, 3, W0=W0)
+    assert torch.equal(W0, keep)                                 # warm start is copied
+    # non-contiguous / float64 inputs are accepted through the reference-style API
+    Yt = np.asfortranarray(Y)
+    np.random.seed(0)
+    _, _, W, _, _, _ = pybold_amd.deconv(Yt, 1.0, hrf, lbda=1.0, nb_iter=10, early_stopping=False)
+    for s in range(4):
+        assert rel_rows(W[s], g["dz_s%d_l1_n10" % s]) < EPS
+
+
 def test_errors_are_loud(pa, golden):
     _, solver = pa
     from pybold_amd._lib import PyboldHipError
