@@ -167,6 +167,20 @@ def run(args):
                              "kernel is VALU-issue bound (see DESIGN.md)"},
     }
 
+    if rank == 0 and world == 1:
+        # BASELINE config 2 (10k voxels x 300 scans x 500 iterations) for reference
+        V2 = min(10000, V)
+        plan2 = solver.FistaPlan(Y[:V2].contiguous(), hrf, args.lbda, step, n_iter, force=None)
+        plan2.run()
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        for _ in range(5):
+            plan2.run()
+        torch.cuda.synchronize(dev)
+        dt2 = (time.perf_counter() - t2) / 5
+        out["other_configs"] = {"config2_%d_voxels" % V2: {
+            "value": V2 * n_iter / dt2, "unit": "voxel-iterations/s", "ms_per_solve": dt2 * 1e3}}
+
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"], out["parity"] = cpu_baseline(Y, plan.W, hrf, args.lbda, step, n_iter,
                                                           args.cpu_seconds)

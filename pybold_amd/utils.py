@@ -24,14 +24,22 @@ def spectral_radius_est(L, x_shape, nb_iter=30, tol=1.0e-6, verbose=False):
 
 def gram_frobenius(hrf, n):
     """``|| A^T A ||_F`` for ``A = toeplitz(hrf) @ tril(ones)``: the Lipschitz
-    constant ``_loops_deconv`` uses (pybold/bold_signal.py:249-253).  ``A`` is
-    itself lower-triangular Toeplitz with kernel ``cumsum(hrf)`` (the step
-    response), so it is assembled directly."""
+    constant ``_loops_deconv`` uses (pybold/bold_signal.py:249-253).
+
+    ``A`` is lower-triangular Toeplitz with kernel ``c = cumsum(hrf)`` (the step
+    response), so ``(A^T A)[j, j+d] = R_d(n-1-j-d)`` with the partial
+    autocorrelations ``R_d(T) = sum_{t<=T} c[t] c[t+d]``; the squared Frobenius
+    norm is ``sum_d (2 - [d=0]) sum_T R_d(T)^2`` -- O(n^2) instead of the
+    reference's two dense n^3 products, same value to rounding."""
     hrf = np.asarray(hrf, dtype=np.float64)
-    step_resp = np.cumsum(np.concatenate([hrf, np.zeros(max(0, n - len(hrf)))]))[:n]
-    lag = np.arange(n)[:, None] - np.arange(n)[None, :]
-    A = np.where(lag >= 0, step_resp[np.clip(lag, 0, n - 1)], 0.0)
-    return np.linalg.norm(A.T.dot(A))
+    c = np.cumsum(np.concatenate([hrf, np.zeros(max(0, n - len(hrf)))]))[:n]
+    d = np.arange(n)[:, None]
+    t = np.arange(n)[None, :]
+    cpad = np.concatenate([c, np.zeros(n)])
+    r = np.cumsum(c[None, :] * cpad[d + t], axis=1)          # r[d, T] = R_d(T)
+    r = np.where(t <= n - 1 - d, r, 0.0)
+    weight = np.where(d == 0, 1.0, 2.0)
+    return np.sqrt(np.sum(weight * r * r))
 
 
 def inf_norm(x):

@@ -1,0 +1,94 @@
+"""Full-size parity (BASELINE config 3: 100k voxels x 300 scans) through
+size-independent properties of the recurrence, plus an oracle check on a random
+sample.  The oracle cannot run 5e7 voxel-iterations in seconds; these
+properties hold for the exact recurrence and pin the batched kernel at scale:
+
+  * batch independence: a voxel's result does not depend on which batch it is
+    solved in (bitwise);
+  * odd symmetry: solve(-y) == -solve(y) (bitwise: fma, clamp and the scans are odd);
+  * positive homogeneity: solve(a*y, a*lbda) == a*solve(y, lbda);
+  * lambda = 0 linearity: solve(y1 + y2) == solve(y1) + solve(y2) without the prox.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle
+
+pytestmark = pytest.mark.gpu
+
+V, N, LIP = 100000, 300, 723876.2744579345
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from pybold_amd import data, solver
+    from pybold_amd.hrf_model import spm_hrf
+    hrf = spm_hrf(1.0, t_r=1.0, dur=30.)[0]
+    Y, _, _ = data.gen_rnd_bloc_bold_batch(V, dur=5, tr=1.0, hrf=hrf, nb_events=5, avg_dur=12.0,
+                                           std_dur=1.0, snr=1.0, seed=11)
+    return solver, hrf, Y
+
+
+def rel_rows_t(a, b):
+    return float(((a - b).norm(dim=1) / (b.norm(dim=1) + 1e-300)).max())
+
+
+def test_full_batch_properties(setup):
+    solver, hrf, Y = setup
+    step = 1.0 / LIP
+    W, _, n_done = solver.fista_solve(Y, hrf, 1.0, step, 60)
+    assert W.shape == (V, N) and bool(torch.isfinite(W).all()) and int(n_done.min()) == 60
+    # batch independence (bitwise): odd-sized slice, different workgroup packing
+    lo, hi = 31337, 31337 + 4099
+    Ws, _, _ = solver.fista_solve(Y[lo:hi].contiguous(), hrf, 1.0, step, 60)
+    assert torch.equal(Ws, W[lo:hi])
+    # odd symmetry (bitwise)
+    Wn, _, _ = solver.fista_solve(-Y, hrf, 1.0, step, 60)
+    assert torch.equal(Wn, -W)
+    # positive homogeneity
+    Wh, _, _ = solver.fista_solve(Y * 4.0, hrf, 4.0, step, 60)      # power of two: exact scaling
+    assert torch.equal(Wh, 4.0 * W)
+    Wh, _, _ = solver.fista_solve(Y * 3.0, hrf, 3.0, step, 60)
+    assert rel_rows_t(Wh, 3.0 * W) < 1e-5
+
+
+def test_full_batch_linearity_without_prox(setup):
+    solver, hrf, Y = setup
+    step = 1.0 / LIP
+    Y1, Y2 = Y[: V // 2], Y[V // 2:]
+    W1, _, _ = solver.fista_solve(Y1, hrf, 0.0, step, 40)
+    W2, _, _ = solver.fista_solve(Y2, hrf, 0.0, step, 40)
+    W12, _, _ = solver.fista_solve(Y1 + Y2, hrf, 0.0, step, 40)
+    assert rel_rows_t(W12, W1 + W2) < 1e-5
+
+
+def test_full_batch_sample_against_oracle(setup):
+    """500 iterations on all 100k voxels; 96 random voxels checked against the C oracle."""
+    solver, hrf, Y = setup
+    step = 1.0 / LIP
+    W, _, _ = solver.fista_solve(Y, hrf, 1.0, step, 500)
+    idx = np.random.RandomState(0).choice(V, 96, replace=False)
+    Ys = Y[torch.from_numpy(idx).cuda()].cpu().numpy().astype(np.float64)
+    Wo, _, _ = c_oracle.fista_batch(Ys, hrf, 1.0, step, 500, threads=8)
+    Wg = W[torch.from_numpy(idx).cuda()].cpu().numpy()
+    err = (np.linalg.norm(Wg - Wo, axis=1) / np.linalg.norm(Wo, axis=1)).max()
+    assert err < 1e-5, err
+    # z and x too
+    X, Z = solver.fista_outputs(W[torch.from_numpy(idx).cuda()].contiguous(), hrf)
+    Zo = np.cumsum(Wo, axis=1)
+    assert (np.linalg.norm(Z.cpu().numpy() - Zo, axis=1) / np.linalg.norm(Zo, axis=1)).max() < 1e-5
+
+
+def test_regularisation_path_config5_slice(setup):
+    """(voxel, lambda) problems sharing y rows: each equals its own single-lambda solve."""
+    solver, hrf, Y = setup
+    step = 1.0 / LIP
+    Ysub = Y[:2000].contiguous()
+    lbdas = np.logspace(-2, 0, 20)
+    lam = np.tile(lbdas, Ysub.shape[0])
+    Wp, _, _ = solver.fista_solve(Ysub, hrf, lam, step, 50, y_rep=20)
+    Wp = Wp.reshape(Ysub.shape[0], 20, N)
+    for i in (0, 7, 19):
+        Wi, _, _ = solver.fista_solve(Ysub, hrf, float(lbdas[i]), step, 50)
+        assert torch.equal(Wp[:, i, :], Wi)
