@@ -60,6 +60,8 @@ def deconv(y, t_r, hrf, lbda=None, early_stopping=True, tol=1.0e-6,  # noqa
         return _deconv_auto_lbda(y, hrf, early_stopping, tol, wind, nb_iter, nb_sub_iter, verbose)
     Y, one_d = _y_to_device(y)
     n = Y.shape[1]
+    if Y.shape[0] == 0:
+        raise ValueError("deconv: empty voxel batch")
     hrf = np.asarray(hrf, dtype=np.float64)
     H = ConvAndLinear(DiscretInteg(), hrf, dim_in=n, dim_out=n)
     grad_lipschitz_cst = 0.9 * spectral_radius_est(H, (n,))
@@ -188,6 +190,35 @@ def hrf_estim(z, y, t_r, dur, verbose=0):
     return h, f_cost.J
 
 
+class _BlindTrace:
+    """Normalised cost bookkeeping of ``bd`` (pybold/bold_signal.py:306-313,
+    :337-342, :371-380): residual ``r`` and cost ``J`` relative to their initial
+    values, sparsity ``g`` raw."""
+
+    def __init__(self, x, y, w, lbda):
+        self.y, self.lbda = y, lbda
+        self.r0 = float(np.sum(np.square(x - y)))
+        g0 = float(np.sum(np.abs(w)))
+        self.j0 = self.r0 + lbda * g0
+        self.J, self.r, self.g = [1.0], [1.0], [g0]
+
+    def record(self, x, w, eps):
+        r = float(np.sum(np.square(x - self.y)))
+        g = float(np.sum(np.abs(w)))
+        self.J.append((r + self.lbda * g) / self.j0 + eps)
+        self.r.append(r / self.r0 + eps)
+        self.g.append(g)
+
+    def stalled(self, wind, tol):
+        half = int(wind / 2)                          # rule of :350-356
+        older, newer = np.mean(self.J[:-half]), np.mean(self.J[-half:])
+        return (newer - older) / newer < tol
+
+    def as_dict(self):
+        return {'J': np.array(self.J), 'r': np.array(self.r), 'g': np.array(self.g),
+                'l_alpha': []}
+
+
 def _loops_deconv(y, diff_z, H, lbda, nb_iter, early_stopping, wind, tol):
     """Inner FISTA loop of the blind solver (pybold/bold_signal.py:246-278):
     warm start ``diff_z``, step ``1 / ||A^T A||_F`` with ``A = H tril(1)``.
@@ -215,68 +246,48 @@ def bd(y, t_r, lbda=1.0, theta_0=None, z_0=None, hrf_dur=20.0,  # noqa
     reference.  Returns ``(x, z, diff_z, h, d)``."""
     y = np.asarray(y).astype(np.float64)
     n = len(y)
+    dev = solver.device()
     theta = MAX_DELTA if theta_0 is None else theta_0
-    h, _ = spm_hrf(theta, t_r, hrf_dur, False)
-
-    def outputs(w, h):
-        Wd = torch.from_numpy(np.ascontiguousarray(w[None])).to(solver.device())
-        X, Z = solver.fista_outputs(Wd, h)
-        return X.cpu().numpy()[0], Z.cpu().numpy()[0]
-
-    if z_0 is None:
-        diff_z, z, x = np.zeros_like(y), np.zeros_like(y), np.zeros_like(y)
-    else:
-        z_0 = np.asarray(z_0, dtype=np.float64)
-        diff_z = np.append(0, z_0[1:] - z_0[:-1])
-        z = z_0
-        x = solver.conv(torch.from_numpy(z[None].copy()).to(solver.device()), h).cpu().numpy()[0]
+    h, _ = spm_hrf(theta, t_r, hrf_dur, False)       # may lie outside `bounds` (:291-292)
     if bounds is None:
         bounds = [(MIN_DELTA + 1.0e-1, MAX_DELTA - 1.0e-1)]
 
-    d = {}
-    r_0 = np.sum(np.square(x - y))
-    d['r'] = [1.0]
-    g_0 = np.sum(np.abs(diff_z))
-    d['g'] = [g_0]
-    j_0 = r_0 + lbda * g_0
-    d['J'] = [1.0]
-    d['l_alpha'] = []
+    def outputs(w, taps):
+        X, Z = solver.fista_outputs(torch.from_numpy(np.ascontiguousarray(w[None])).to(dev), taps)
+        return X.cpu().numpy()[0], Z.cpu().numpy()[0]
+
+    if z_0 is None:
+        diff_z = np.zeros(n)
+        x = np.zeros(n)
+    else:                                            # warm start from a block signal (:299-301)
+        z_0 = np.asarray(z_0, dtype=np.float64)
+        diff_z = np.concatenate([[0.0], np.diff(z_0)])
+        x = solver.conv(torch.from_numpy(z_0[None].copy()).to(dev), h).cpu().numpy()[0]
+
+    trace = _BlindTrace(x, y, diff_z, lbda)
     if verbose > 0:
-        print("normalized global cost-function (init): {0:.6f}".format(d['J'][-1]))
+        print("normalized global cost-function (init): {0:.6f}".format(trace.J[-1]))
+
+    def z_step(w, taps):
+        return _loops_deconv(y, w, toeplitz_from_kernel(taps, dim_in=n, dim_out=n), lbda, nb_iter,
+                             early_stopping, wind, tol)
 
     for idx in range(nb_iter):
-        H = toeplitz_from_kernel(h, dim_in=n, dim_out=n)
-        diff_z = _loops_deconv(y, diff_z, H, lbda, nb_iter, early_stopping, wind, tol)
+        diff_z = z_step(diff_z, h)
         z = np.cumsum(diff_z)
-        args = (z, y, t_r, hrf_dur)
-        theta, _, _ = fmin_l_bfgs_b(func=hrf_fit_err, x0=theta, args=args, bounds=bounds,
-                                    approx_grad=True, maxiter=999, pgtol=1.0e-12)
+        theta, _, _ = fmin_l_bfgs_b(func=hrf_fit_err, x0=theta, args=(z, y, t_r, hrf_dur),
+                                    bounds=bounds, approx_grad=True, maxiter=999, pgtol=1.0e-12)
         h, _ = spm_hrf(float(np.ravel(theta)[0]), t_r, hrf_dur, False)
         x, z = outputs(diff_z, h)
-        r = np.sum(np.square(x - y))
-        g = np.sum(np.abs(diff_z))
-        d['J'].append((r + lbda * g) / j_0 + 1.0e-30)
-        d['r'].append(r / r_0 + 1.0e-30)
-        d['g'].append(g)
+        trace.record(x, diff_z, eps=1.0e-30)
         if (verbose > 0) and ((idx + 1) % print_period == 0):
             print("normalized global cost-function ({0:03d}/{1:03d}): "
-                  "{2:.6f}".format(idx + 1, nb_iter, d['J'][-1]))
-        if early_stopping and idx > wind:
-            sub_wind_len = int(wind / 2)
-            old_j = np.mean(d['J'][:-sub_wind_len])
-            new_j = np.mean(d['J'][-sub_wind_len:])
-            if (new_j - old_j) / new_j < tol:
-                break
+                  "{2:.6f}".format(idx + 1, nb_iter, trace.J[-1]))
+        if early_stopping and idx > wind and trace.stalled(wind, tol):
+            break
 
-    H = toeplitz_from_kernel(h, dim_in=n, dim_out=n)
-    diff_z = _loops_deconv(y, diff_z, H, lbda, nb_iter, early_stopping, wind, tol)
+    diff_z = z_step(diff_z, h)                        # last solve with the final HRF (:365-369)
     x, z = outputs(diff_z, h)
-    r = np.sum(np.square(x - y))
-    g = np.sum(np.abs(diff_z))
-    d['J'].append((r + lbda * g) / j_0)
-    d['r'].append(r / r_0)
-    d['g'].append(g)
-    d['J'] = np.array(d['J'])
-    d['r'] = np.array(d['r'])
-    d['g'] = np.array(d['g'])
+    trace.record(x, diff_z, eps=0.0)
+    d = trace.as_dict()
     return x, z, diff_z, h, d

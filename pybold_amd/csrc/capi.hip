@@ -105,6 +105,7 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
                 N, K, n_iter, y_rep);
   if (P > 0 && (!y_dev || !w_dev || !taps_host || (n_iter > 0 && !betas_dev)))
     return fail(PB_ERR_INVALID, "pb_fista_solve: NULL pointer");
+  if (P > (1 << 27)) return fail(PB_ERR_INVALID, "pb_fista_solve: more than 2^27 problems per launch");
   if (ldy < N || ldw < N) return fail(PB_ERR_INVALID, "pb_fista_solve: leading dimension < N");
   if (J_dev && ldj < n_iter) return fail(PB_ERR_INVALID, "pb_fista_solve: ldj < n_iter");
   if (!(step > 0.0)) return fail(PB_ERR_INVALID, "pb_fista_solve: step must be positive");

@@ -27,7 +27,8 @@
 //   acc.lo += h[m] * Z[q],  acc.hi += h[m+1] * Z[q-1]
 // with the tap pair in an SGPR pair (kernel argument) and the window pair an
 // aligned VGPR pair swapped by op_sel; outputs whose pair would be misaligned
-// use a second, one-tap-shifted copy of the taps (free: it lives in SGPRs).
+// use a second, one-tap-shifted copy of the taps (loop-invariant, held in VGPRs:
+// two SGPR copies would spill the scalar file).
 #pragma once
 #include "common.h"
 

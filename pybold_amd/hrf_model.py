@@ -16,10 +16,9 @@ def spm_hrf(delta, t_r=1.0, dur=60.0, normalized_hrf=True, dt=0.001, p_delay=6,
             undershoot=16.0, p_disp=1.0, u_disp=1.0, p_u_ratio=0.167, onset=0.0):
     """Same signature and values as pybold/hrf_model.py:12-39; returns
     ``(hrf, t_hrf)``.  Raises ``ValueError`` for ``delta`` outside [0.5, 2]."""
-    if (delta < MIN_DELTA) or (delta > MAX_DELTA):
-        raise ValueError("delta should belong in [{0}, {1}]; wich correspond"
-                         " to a max FWHM of 10.52s and a min FWHM of 2.80s"
-                         ", got delta = {2}".format(MIN_DELTA, MAX_DELTA, delta))
+    if not (MIN_DELTA <= delta <= MAX_DELTA):
+        raise ValueError("HRF dilation delta=%r outside the supported range [%g, %g]"
+                         % (delta, MIN_DELTA, MAX_DELTA))
     n_fine = int(float(dur) / dt)
     dec = int(t_r / dt)
     shift = float(onset) / dt

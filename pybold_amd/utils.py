@@ -8,18 +8,19 @@ def spectral_radius_est(L, x_shape, nb_iter=30, tol=1.0e-6, verbose=False):
     pybold/utils.py:94-109, including the start vector drawn from NumPy's
     global RNG (seed it for reproducible runs).  ``L`` is any object with
     ``.op`` / ``.adj``; float64 on the host, the operator runs on the GPU."""
-    x_old = np.random.randn(*x_shape)
-    x_new = x_old
-    stopped = False
+    v = np.random.randn(*x_shape)            # global RNG, as the reference (:97)
+    nv = norm_2(v)
+    rho, converged = nv, False
     for _ in range(nb_iter):
-        x_new = L.adj(L.op(x_old)) / norm_2(x_old)
-        if np.abs(norm_2(x_new) - norm_2(x_old)) < tol:
-            stopped = True
+        v = L.adj(L.op(v)) / nv                # one step of the power method on L^T L
+        rho = norm_2(v)
+        converged = abs(rho - nv) < tol
+        if converged:
             break
-        x_old = x_new
-    if not stopped and verbose:
-        print("Spectral radius estimation did not converge")
-    return norm_2(x_new)
+        nv = rho
+    if verbose and not converged:
+        print("spectral_radius_est: no convergence after %d iterations" % nb_iter)
+    return rho
 
 
 def gram_frobenius(hrf, n):
