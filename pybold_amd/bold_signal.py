@@ -3,7 +3,8 @@
 Same function names, argument order, defaults and return tuples as the
 reference.  ``y`` may be 1-D (reference behaviour, NumPy in / NumPy float64 out)
 or a 2-D ``(V, N)`` batch of voxels solved in one kernel launch (the axis the
-reference fans out with joblib, examples/icassp_2019/simulation.py:62-72).
+reference fans out with joblib, examples/icassp_2019/simulation.py:62-72).  A
+CUDA tensor in gives CUDA tensors out (x, z, diff_z stay in HBM).
 
 Deviations from the reference, all deliberate:
   * the fixed-lambda ``deconv`` does not print one line per iteration
@@ -28,21 +29,37 @@ from .linear import ConvAndLinear, DiscretInteg
 from .utils import gram_frobenius, mad_daub_noise_est, spectral_radius_est
 
 
+class _Shape:
+    """How to hand results back: 1-D or batch, NumPy (reference behaviour) or the
+    caller's CUDA tensors (no host round trip)."""
+
+    def __init__(self, one_d, on_device):
+        self.one_d, self.on_device = one_d, on_device
+
+    def __bool__(self):             # truthiness = "input was 1-D"
+        return self.one_d
+
+
 def _y_to_device(y):
-    """-> (float32 CUDA (V, N), one_d flag)"""
+    """-> (float32 CUDA (V, N), _Shape)"""
     if torch.is_tensor(y):
         one_d = y.dim() == 1
+        on_device = y.is_cuda
         t = y.to(device=solver.device(y.device if y.is_cuda else None), dtype=torch.float32)
     else:
         a = np.asarray(y)
-        one_d = a.ndim == 1
+        one_d, on_device = a.ndim == 1, False
         t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(solver.device())
-    return (t.reshape(1, -1) if one_d else t), one_d
+    return (t.reshape(1, -1) if one_d else t), _Shape(one_d, on_device)
 
 
-def _host(t, one_d):
+def _host(t, shape):
+    """Result in the caller's world: float64 NumPy, or the CUDA tensor itself when
+    the input was one."""
+    if isinstance(shape, _Shape) and shape.on_device:
+        return t[0] if shape.one_d else t
     a = t.cpu().numpy()
-    return a[0] if one_d else a
+    return a[0] if shape else a
 
 
 def deconv(y, t_r, hrf, lbda=None, early_stopping=True, tol=1.0e-6,  # noqa
@@ -78,8 +95,8 @@ def deconv(y, t_r, hrf, lbda=None, early_stopping=True, tol=1.0e-6,  # noqa
               "{2:.6f}".format(Y.shape[0], int(n_done.max()),
                                float(np.nanmean(J[np.arange(len(n_done)), n_done - 1]))))
     if one_d:
-        return _host(X, True), _host(Z, True), _host(W, True), J[0, :n_done[0]], None, None
-    return _host(X, False), _host(Z, False), _host(W, False), J, None, None
+        return _host(X, one_d), _host(Z, one_d), _host(W, one_d), J[0, :n_done[0]], None, None
+    return _host(X, one_d), _host(Z, one_d), _host(W, one_d), J, None, None
 
 
 def _deconv_auto_lbda(y, hrf, early_stopping, tol, wind, nb_iter, nb_sub_iter, verbose):
@@ -148,9 +165,9 @@ def _deconv_auto_lbda(y, hrf, early_stopping, tol, wind, nb_iter, nb_sub_iter, v
     X, Z = solver.fista_outputs(W, hrf)
     if one_d:
         keep = [k for k in range(len(J)) if not np.isnan(J[k][0])]
-        return (_host(X, True), _host(Z, True), _host(W, True), [float(J[k][0]) for k in keep],
+        return (_host(X, one_d), _host(Z, one_d), _host(W, one_d), [float(J[k][0]) for k in keep],
                 [float(R[k][0]) for k in keep], [float(G[k][0]) for k in keep])
-    return (_host(X, False), _host(Z, False), _host(W, False), np.array(J), np.array(R),
+    return (_host(X, one_d), _host(Z, one_d), _host(W, one_d), np.array(J), np.array(R),
             np.array(G))
 
 

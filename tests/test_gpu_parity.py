@@ -237,6 +237,21 @@ def test_fista_stats(pa, golden):
     assert float(l1[0]) == pytest.approx(np.abs(g["diff_z"]).sum(), rel=1e-12)
 
 
+def test_device_tensors_in_device_tensors_out(pa, golden):
+    pybold_amd, _ = pa
+    g, Y, hrf, lip = grid_inputs(golden)
+    np.random.seed(0)
+    X, Z, W, J, _, _ = pybold_amd.deconv(dev32(Y), 1.0, hrf, lbda=1.0, nb_iter=10,
+                                         early_stopping=False)
+    assert all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float64 for t in (X, Z, W))
+    for s in range(4):
+        assert rel_rows(W[s].cpu().numpy(), g["dz_s%d_l1_n10" % s]) < EPS
+    np.random.seed(0)
+    x, z, w, J, _, _ = pybold_amd.deconv(dev32(Y[2]), 1.0, hrf, lbda=1.0, nb_iter=10,
+                                         early_stopping=False)
+    assert w.shape == (300,) and w.is_cuda and len(J) == 10
+
+
 def test_operator_surface_goldens(pa, golden):
     pybold_amd, _ = pa
     g = golden("operators")
