@@ -148,6 +148,42 @@ int pb_hrf_cost(const double* z_dev, int64_t ldz, const float* y_dev, int64_t ld
                 int V, int N, const double* taps_dev, int K, int n_hrf,
                 double* cost_dev, void* stream);
 
+/*
+ * Per-voxel HRFs (blind deconvolution with one HRF dilation per voxel, the loop
+ * the reference fans out over voxels: pybold/bold_signal.py:281-382,
+ * examples/icassp_2019/simulation.py:62-72).
+ *
+ * pb_fista_solve_pp   the solver of pb_fista_solve with per-problem taps
+ *                     taps_dev float64 [P][ldt] (K used) and per-problem step
+ *                     step_dev float64 [P]; stop rule NONE or LOOPS; no cost trace.
+ * pb_hrf_cost_pv      pb_hrf_cost with one HRF per (candidate, voxel):
+ *                     taps_dev float64 [n_hrf][V][K], cost_dev float64 [n_hrf][V].
+ * pb_gram_frobenius   out[p] = || A_p^T A_p ||_F with A_p = toeplitz(taps_p, N, N) tril(1):
+ *                     the step constant of _loops_deconv (pybold/bold_signal.py:249-254)
+ *                     for P different HRFs at once.
+ */
+int pb_fista_solve_pp(const float* y_dev, int64_t ldy, double* w_dev, int64_t ldw, int P, int N,
+                      const double* taps_dev, int64_t ldt, int K, const double* step_dev,
+                      double lbda, const double* lbda_dev, const double* betas_dev, int n_iter,
+                      int stop_mode, double tol, int32_t* n_done_dev, unsigned flags, void* stream);
+int pb_hrf_cost_pv(const double* z_dev, int64_t ldz, const float* y_dev, int64_t ldy,
+                   int V, int N, const double* taps_dev, int K, int n_hrf,
+                   double* cost_dev, void* stream);
+int pb_gram_frobenius(const double* taps_dev, int64_t ldt, int P, int K, int N,
+                      double* out_dev, void* stream);
+/* pb_fista_outputs with one HRF per row: taps_dev float64 [P][ldt]. */
+int pb_fista_outputs_pp(const double* w_dev, int64_t ldw, int P, int N,
+                        const double* taps_dev, int64_t ldt, int K,
+                        double* z_dev, int64_t ldz, double* x_dev, int64_t ldx, void* stream);
+/*
+ * Un-normalised two-gamma SPM HRF (pybold/hrf_model.py:25-31) for M dilations at
+ * the K sample times t_dev (seconds, already decimated): out_dev float64 [M][K] =
+ * gamma_pdf(d t; a_peak, loc_peak) - ratio * gamma_pdf(d t; a_under, loc_under).
+ */
+int pb_spm_hrf(const double* deltas_dev, int M, const double* t_dev, int K,
+               double a_peak, double loc_peak, double a_under, double loc_under,
+               double ratio, double* out_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

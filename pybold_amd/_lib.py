@@ -51,6 +51,18 @@ SIGNATURES = {
                                _c_int, _ptr, _c_int, _ptr]),
     "pb_hrf_cost": (_c_int, [_ptr, _c_i64, _ptr, _c_i64, _c_int, _c_int, _ptr,
                              _c_int, _c_int, _ptr, _ptr]),
+    "pb_fista_solve_pp": (_c_int, [
+        _ptr, _c_i64, _ptr, _c_i64, _c_int, _c_int,     # y, ldy, w, ldw, P, N
+        _ptr, _c_i64, _c_int, _ptr,                     # taps_dev, ldt, K, step_dev
+        _c_dbl, _ptr, _ptr, _c_int,                     # lbda, lbda_dev, betas_dev, n_iter
+        _c_int, _c_dbl, _ptr, ctypes.c_uint, _ptr]),    # stop_mode, tol, n_done, flags, stream
+    "pb_hrf_cost_pv": (_c_int, [_ptr, _c_i64, _ptr, _c_i64, _c_int, _c_int, _ptr,
+                                _c_int, _c_int, _ptr, _ptr]),
+    "pb_gram_frobenius": (_c_int, [_ptr, _c_i64, _c_int, _c_int, _c_int, _ptr, _ptr]),
+    "pb_fista_outputs_pp": (_c_int, [_ptr, _c_i64, _c_int, _c_int, _ptr, _c_i64, _c_int,
+                                     _ptr, _c_i64, _ptr, _c_i64, _ptr]),
+    "pb_spm_hrf": (_c_int, [_ptr, _c_int, _ptr, _c_int, _c_dbl, _c_dbl, _c_dbl, _c_dbl, _c_dbl,
+                            _ptr, _ptr]),
 }
 
 _lib = None

@@ -260,7 +260,18 @@ def bd(y, t_r, lbda=1.0, theta_0=None, z_0=None, hrf_dur=20.0,  # noqa
     iterations exactly like the reference's call at :324) with a bounded
     L-BFGS-B fit of the HRF dilation ``theta`` on the GPU-evaluated cost.
     ``nb_sub_iter`` and ``nb_last_iter`` are accepted and unused, as in the
-    reference.  Returns ``(x, z, diff_z, h, d)``."""
+    reference.  Returns ``(x, z, diff_z, h, d)``.
+
+    A 2-D ``y`` (voxels, scans) is solved for all voxels at once with one HRF
+    dilation per voxel (``pybold_amd.blind.bd_batch``; the theta-step is then a
+    batched section search instead of SciPy's L-BFGS-B, see that module)."""
+    if (torch.is_tensor(y) and y.dim() == 2) or (not torch.is_tensor(y) and np.ndim(y) == 2):
+        from .blind import bd_batch
+        Y, shape = _y_to_device(y)
+        X, Z, W, taps, d = bd_batch(Y, t_r, lbda=lbda, theta_0=theta_0, z_0=z_0, hrf_dur=hrf_dur,
+                                    bounds=bounds, nb_iter=nb_iter, early_stopping=early_stopping,
+                                    wind=wind, tol=tol, verbose=verbose)
+        return _host(X, shape), _host(Z, shape), _host(W, shape), _host(taps, shape), d
     y = np.asarray(y).astype(np.float64)
     n = len(y)
     dev = solver.device()

@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 
 #include "fista_fast.h"
@@ -34,25 +35,28 @@ constexpr int LDS_DOUBLES_MAX = 20000;  // 160 KB of LDS per workgroup
 // ---- register-resident specialisations --------------------------------------
 typedef int (*fast_launch_fn)(const pb::FistaArgs&, const double* taps, int K, bool with_j,
                               int stop, hipStream_t);
+typedef int (*fast_launch_pp_fn)(const pb::FistaArgs&, int stop, hipStream_t);
 
 struct FastEntry {
   int S, KT;
   fast_launch_fn fn;
+  fast_launch_pp_fn fn_pp;
 };
 
 }  // namespace
 
 // instantiated in fast_inst.hip, one translation unit per table entry
 namespace pb {
-#define PB_FAST(S, KT) \
-  extern template int launch_fast<S, KT>(const FistaArgs&, const double*, int, bool, int, hipStream_t);
+#define PB_FAST(S, KT)                                                                              \
+  extern template int launch_fast<S, KT>(const FistaArgs&, const double*, int, bool, int, hipStream_t); \
+  extern template int launch_fast_pp<S, KT>(const FistaArgs&, int, hipStream_t);
 #include "fast_table.inc"
 #undef PB_FAST
 }  // namespace pb
 
 namespace {
 
-#define PB_FAST(S, KT) {S, KT, &pb::launch_fast<S, KT>},
+#define PB_FAST(S, KT) {S, KT, &pb::launch_fast<S, KT>, &pb::launch_fast_pp<S, KT>},
 const FastEntry kFast[] = {
 #include "fast_table.inc"
 };
@@ -119,6 +123,7 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
   a.y = y_dev; a.ldy = ldy; a.w = w_dev; a.ldw = ldw; a.lbda_vec = lbda_dev; a.betas = betas_dev;
   a.J = J_dev; a.ldj = ldj; a.n_done = n_done_dev; a.step = step; a.lbda = lbda; a.tol = tol;
   a.y_rep = y_rep; a.P = P; a.N = N; a.n_iter = n_iter; a.stop_mode = stop_mode;
+  a.taps_pp = nullptr; a.ldt = 0; a.step_vec = nullptr; a.K = K;
 
   const FastEntry* fe = (flags & PB_FLAG_FORCE_GENERIC) ? nullptr : pick_fast(N, K);
   // the register-resident window rule keeps wind-1 = 5 iterates in VGPRs: wind = 6
@@ -159,8 +164,38 @@ int pb_fista_outputs(const double* w_dev, int64_t ldw, int P, int N, const doubl
   if (P == 0 || (!z_dev && !x_dev)) return PB_OK;
   const size_t lds = (size_t)(2 * N + K + 8) * sizeof(double);
   hipLaunchKernelGGL(pb::outputs_kernel, dim3(P), dim3(pb::GEN_THREADS), lds, (hipStream_t)stream,
-                     w_dev, ldw, N, taps_dev, K, z_dev, ldz, x_dev, ldx);
+                     w_dev, ldw, N, taps_dev, (int64_t)0, K, z_dev, ldz, x_dev, ldx);
   return check_launch("outputs_kernel");
+}
+
+int pb_fista_outputs_pp(const double* w_dev, int64_t ldw, int P, int N, const double* taps_dev,
+                        int64_t ldt, int K, double* z_dev, int64_t ldz, double* x_dev, int64_t ldx,
+                        void* stream) {
+  if (P == 0 && N >= 1 && K >= 1) return PB_OK;
+  if (!w_dev || !taps_dev || P < 0 || N < 1 || K < 1 || ldw < N || ldt < K ||
+      (z_dev && ldz < N) || (x_dev && ldx < N))
+    return fail(PB_ERR_INVALID, "pb_fista_outputs_pp: bad argument");
+  if (2 * (int64_t)N + K + 8 > LDS_DOUBLES_MAX)
+    return fail(PB_ERR_INVALID, "pb_fista_outputs_pp: N=%d K=%d exceeds LDS", N, K);
+  if (!z_dev && !x_dev) return PB_OK;
+  const size_t lds = (size_t)(2 * N + K + 8) * sizeof(double);
+  hipLaunchKernelGGL(pb::outputs_kernel, dim3(P), dim3(pb::GEN_THREADS), lds, (hipStream_t)stream,
+                     w_dev, ldw, N, taps_dev, ldt, K, z_dev, ldz, x_dev, ldx);
+  return check_launch("outputs_kernel(pp)");
+}
+
+int pb_spm_hrf(const double* deltas_dev, int M, const double* t_dev, int K, double a_peak,
+               double loc_peak, double a_under, double loc_under, double ratio, double* out_dev,
+               void* stream) {
+  if (!deltas_dev || !t_dev || !out_dev || M < 0 || K < 1 || !(a_peak > 0.0) || !(a_under > 0.0))
+    return fail(PB_ERR_INVALID, "pb_spm_hrf: bad argument");
+  if (M == 0) return PB_OK;
+  const int64_t total = (int64_t)M * K;
+  const unsigned blocks = (unsigned)((total + pb::GEN_THREADS - 1) / pb::GEN_THREADS);
+  hipLaunchKernelGGL(pb::spm_hrf_kernel, dim3(blocks), dim3(pb::GEN_THREADS), 0, (hipStream_t)stream,
+                     deltas_dev, M, t_dev, K, a_peak, loc_peak, lgamma(a_peak), a_under, loc_under,
+                     lgamma(a_under), ratio, out_dev);
+  return check_launch("spm_hrf_kernel");
 }
 
 int pb_fista_stats(const double* w_dev, int64_t ldw, const float* y_dev, int64_t ldy, int y_rep,
@@ -211,8 +246,67 @@ int pb_hrf_cost(const double* z_dev, int64_t ldz, const float* y_dev, int64_t ld
   if (V == 0) return PB_OK;
   const size_t lds = (size_t)(N + K + 8) * sizeof(double);
   hipLaunchKernelGGL(pb::hrf_cost_kernel, dim3(V, n_hrf), dim3(pb::GEN_THREADS), lds,
-                     (hipStream_t)stream, z_dev, ldz, y_dev, ldy, V, N, taps_dev, K, cost_dev);
+                     (hipStream_t)stream, z_dev, ldz, y_dev, ldy, V, N, taps_dev, K, cost_dev, 0);
   return check_launch("hrf_cost_kernel");
+}
+
+int pb_hrf_cost_pv(const double* z_dev, int64_t ldz, const float* y_dev, int64_t ldy, int V, int N,
+                   const double* taps_dev, int K, int n_hrf, double* cost_dev, void* stream) {
+  if (!z_dev || !y_dev || !taps_dev || !cost_dev || V < 0 || N < 1 || K < 1 || n_hrf < 1 ||
+      ldz < N || ldy < N)
+    return fail(PB_ERR_INVALID, "pb_hrf_cost_pv: bad argument");
+  if ((int64_t)N + K + 8 > LDS_DOUBLES_MAX) return fail(PB_ERR_INVALID, "pb_hrf_cost_pv: exceeds LDS");
+  if (V == 0) return PB_OK;
+  const size_t lds = (size_t)(N + K + 8) * sizeof(double);
+  hipLaunchKernelGGL(pb::hrf_cost_kernel, dim3(V, n_hrf), dim3(pb::GEN_THREADS), lds,
+                     (hipStream_t)stream, z_dev, ldz, y_dev, ldy, V, N, taps_dev, K, cost_dev, 1);
+  return check_launch("hrf_cost_kernel");
+}
+
+int pb_gram_frobenius(const double* taps_dev, int64_t ldt, int P, int K, int N, double* out_dev,
+                      void* stream) {
+  if (!taps_dev || !out_dev || P < 0 || K < 1 || N < 1 || ldt < K)
+    return fail(PB_ERR_INVALID, "pb_gram_frobenius: bad argument");
+  if ((int64_t)N + 8 > LDS_DOUBLES_MAX) return fail(PB_ERR_INVALID, "pb_gram_frobenius: exceeds LDS");
+  if (P == 0) return PB_OK;
+  const size_t lds = (size_t)(N + 8) * sizeof(double);
+  hipLaunchKernelGGL(pb::gram_frobenius_kernel, dim3(P), dim3(pb::GEN_THREADS), lds,
+                     (hipStream_t)stream, taps_dev, ldt, K < N ? K : N, N, out_dev);
+  return check_launch("gram_frobenius_kernel");
+}
+
+int pb_fista_solve_pp(const float* y_dev, int64_t ldy, double* w_dev, int64_t ldw, int P, int N,
+                      const double* taps_dev, int64_t ldt, int K, const double* step_dev,
+                      double lbda, const double* lbda_dev, const double* betas_dev, int n_iter,
+                      int stop_mode, double tol, int32_t* n_done_dev, unsigned flags, void* stream) {
+  if (P < 0 || N < 1 || K < 1 || n_iter < 0)
+    return fail(PB_ERR_INVALID, "pb_fista_solve_pp: bad size (P=%d N=%d K=%d n_iter=%d)", P, N, K, n_iter);
+  if (P > (1 << 27)) return fail(PB_ERR_INVALID, "pb_fista_solve_pp: more than 2^27 problems per launch");
+  if (P == 0) return PB_OK;
+  if (!y_dev || !w_dev || !taps_dev || !step_dev || (n_iter > 0 && !betas_dev))
+    return fail(PB_ERR_INVALID, "pb_fista_solve_pp: NULL pointer");
+  if (ldy < N || ldw < N || ldt < K) return fail(PB_ERR_INVALID, "pb_fista_solve_pp: leading dimension too small");
+  if (stop_mode != PB_STOP_NONE && stop_mode != PB_STOP_LOOPS)
+    return fail(PB_ERR_INVALID, "pb_fista_solve_pp: stop_mode must be PB_STOP_NONE or PB_STOP_LOOPS");
+
+  pb::FistaArgs a;
+  a.y = y_dev; a.ldy = ldy; a.w = w_dev; a.ldw = ldw; a.lbda_vec = lbda_dev; a.betas = betas_dev;
+  a.J = nullptr; a.ldj = 0; a.n_done = n_done_dev; a.step = 0.0; a.lbda = lbda; a.tol = tol;
+  a.y_rep = 1; a.P = P; a.N = N; a.n_iter = n_iter; a.stop_mode = stop_mode;
+  a.taps_pp = taps_dev; a.ldt = ldt; a.step_vec = step_dev; a.K = K;
+
+  const FastEntry* fe = (flags & PB_FLAG_FORCE_GENERIC) ? nullptr : pick_fast(N, K);
+  if (fe) {
+    fe->fn_pp(a, stop_mode, (hipStream_t)stream);
+    return check_launch("fista_fast_kernel(pp)");
+  }
+  if (flags & PB_FLAG_FORCE_FAST)
+    return fail(PB_ERR_INVALID, "pb_fista_solve_pp: no register-resident kernel for N=%d K=%d", N, K);
+  const int64_t nd = 3 * (int64_t)N + K + 2 * pb::GEN_WAVES;
+  if (nd > LDS_DOUBLES_MAX) return fail(PB_ERR_INVALID, "pb_fista_solve_pp: N=%d K=%d exceeds LDS", N, K);
+  hipLaunchKernelGGL((pb::fista_generic_kernel<false>), dim3(P), dim3(pb::GEN_THREADS),
+                     (size_t)nd * sizeof(double), (hipStream_t)stream, a, taps_dev, K, 0);
+  return check_launch("fista_generic_kernel(pp)");
 }
 
 }  // extern "C"

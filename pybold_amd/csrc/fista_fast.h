@@ -44,6 +44,9 @@ struct FistaArgs {
   float* J;               // [P][ldj] or nullptr
   int64_t ldj;
   int32_t* n_done;        // [P] or nullptr
+  const double* taps_pp;  // [P][ldt] per-problem HRF taps (K of them) or nullptr
+  int64_t ldt;
+  const double* step_vec; // [P] per-problem step (goes with taps_pp) or nullptr
   double step;
   double lbda;
   double tol;
@@ -52,6 +55,7 @@ struct FistaArgs {
   int N;
   int n_iter;
   int stop_mode;
+  int K;                  // number of taps actually used (<= KT)
 };
 
 // Tap pairs as kernel arguments (read with scalar loads, kept in SGPRs).
@@ -85,7 +89,9 @@ struct Window {
   }
 };
 
-template <int S, int KT, bool WITH_J, int STOP>
+// PP = per-problem taps and step (blind deconvolution with one HRF per voxel):
+// both tap-pair copies are then loaded from a.taps_pp into VGPRs.
+template <int S, int KT, bool WITH_J, int STOP, bool PP = false>
 __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<KT> taps) {
   constexpr int H = KT - 1;                 // halo length
   constexpr int D = (H + S - 1) / S;        // neighbour lanes that contribute halo
@@ -122,18 +128,33 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
     asm volatile("" : "+v"(mk[j]));
   }
   const double lb = a.lbda_vec ? a.lbda_vec[p] : a.lbda;
-  const double th = lb * a.step;
-  const double nstep = -a.step;
+  const double stp = PP ? a.step_vec[p] : a.step;
+  const double th = lb * stp;
+  const double nstep = -stp;
   const float lbf = (float)lb;
 
   // The one-tap-shifted copy of the taps lives in VGPRs (two SGPR copies would
   // spill); the empty asm makes the values opaque so they are not rematerialised.
   f2 odd_v[TP::NO];
+  f2 even_v[PP ? TP::NE : 1];
+  if constexpr (PP) {
+    const double* tp = a.taps_pp + (int64_t)p * a.ldt;
+    auto h = [&](int m) -> float { return (m >= 0 && m < a.K) ? (float)tp[m] : 0.0f; };
 #pragma unroll
-  for (int t = 0; t < TP::NO; ++t) {
-    odd_v[t] = taps.odd[t];
-    asm volatile("" : "+v"(odd_v[t]));
+    for (int t = 0; t < TP::NE; ++t) even_v[t] = f2{h(2 * t), h(2 * t + 1)};
+#pragma unroll
+    for (int t = 0; t < TP::NO; ++t) odd_v[t] = f2{h(2 * t - 1), h(2 * t)};
+  } else {
+#pragma unroll
+    for (int t = 0; t < TP::NO; ++t) {
+      odd_v[t] = taps.odd[t];
+      asm volatile("" : "+v"(odd_v[t]));
+    }
   }
+  auto even_tap = [&](auto tc) -> f2 {
+    constexpr int t = decltype(tc)::value;
+    if constexpr (PP) return even_v[t]; else return taps.even[t];
+  };
 
   // window rule: the last WIND-1 gradient-step points, float64, slot = iteration mod 5
   constexpr int WIND = 6;
@@ -194,7 +215,7 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
         static_for<0, TP::NE>([&](auto ac) {
           constexpr int t = decltype(ac)::value;
           constexpr int pi = (q - 2 * t - 1) / 2;
-          acc = __builtin_elementwise_fma(taps.even[t], Z.p[pi].yx, acc);
+          acc = __builtin_elementwise_fma(even_tap(ac), Z.p[pi].yx, acc);
         });
       } else {
         static_for<0, TP::NO>([&](auto ac) {
@@ -246,7 +267,7 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
       if constexpr (j % 2 == 0) {
         static_for<0, TP::NE>([&](auto ac) {
           constexpr int t = decltype(ac)::value;
-          acc = __builtin_elementwise_fma(taps.even[t], R.p[(j + 2 * t) / 2], acc);
+          acc = __builtin_elementwise_fma(even_tap(ac), R.p[(j + 2 * t) / 2], acc);
         });
       } else {
         static_for<0, TP::NO>([&](auto ac) {

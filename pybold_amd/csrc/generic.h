@@ -130,16 +130,18 @@ __global__ __launch_bounds__(GEN_THREADS) void op_kernel(const double* x, int64_
 
 // z = cumsum(w), x = k * z
 __global__ __launch_bounds__(GEN_THREADS) void outputs_kernel(const double* w, int64_t ldw, int N,
-                                                              const double* taps, int K, double* z,
-                                                              int64_t ldz, double* x, int64_t ldx) {
+                                                              const double* taps, int64_t ldt, int K,
+                                                              double* z, int64_t ldz, double* x,
+                                                              int64_t ldx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* a = reinterpret_cast<double*>(smem);
   double* b = a + N;
   double* k = b + N;
   double* red = k + K;
   const double* wr = w + (int64_t)blockIdx.x * ldw;
+  const double* tp = taps + (int64_t)blockIdx.x * ldt;     // ldt = 0: taps shared by all rows
   for (int i = threadIdx.x; i < N; i += GEN_THREADS) a[i] = wr[i];
-  for (int i = threadIdx.x; i < K; i += GEN_THREADS) k[i] = taps[i];
+  for (int i = threadIdx.x; i < K; i += GEN_THREADS) k[i] = tp[i];
   __syncthreads();
   block_cumsum<false>(a, a, N, red);
   if (z) {
@@ -153,11 +155,57 @@ __global__ __launch_bounds__(GEN_THREADS) void outputs_kernel(const double* w, i
   }
 }
 
-// cost[c][v] = 0.5 || y_v - taps_c * z_v ||^2 ; grid = (V, n_hrf)
+// Two-gamma SPM HRF sampled at K given times for M dilations (pybold/hrf_model.py:25-31,
+// un-normalised): out[m][k] = pdf(d_m t_k; a1, loc1) - ratio * pdf(d_m t_k; a2, loc2) with the
+// gamma density pdf(x; a, loc) = exp((a-1) log(x-loc) - (x-loc) - lgamma(a)) for x > loc, else 0.
+__global__ __launch_bounds__(GEN_THREADS) void spm_hrf_kernel(const double* deltas, int M,
+                                                              const double* t, int K, double a1,
+                                                              double loc1, double lg1, double a2,
+                                                              double loc2, double lg2, double ratio,
+                                                              double* out) {
+  const int64_t idx = (int64_t)blockIdx.x * GEN_THREADS + threadIdx.x;
+  if (idx >= (int64_t)M * K) return;
+  const int m = (int)(idx / K), k = (int)(idx % K);
+  const double x = deltas[m] * t[k];
+  auto pdf = [](double v, double a, double lg) {
+    return v > 0.0 ? exp((a - 1.0) * log(v) - v - lg) : 0.0;
+  };
+  out[idx] = pdf(x - loc1, a1, lg1) - ratio * pdf(x - loc2, a2, lg2);
+}
+
+// L[p] = || A^T A ||_F, A = toeplitz(h_p) tril(1): the _loops_deconv Lipschitz constant
+// (pybold/bold_signal.py:249-253) for P different HRFs.  A is lower-triangular
+// Toeplitz with kernel c = cumsum(h); (A^T A)[j, j+d] = R_d(N-1-j-d) with the
+// partial autocorrelations R_d(T) = sum_{t<=T} c[t] c[t+d]; thread d walks diagonal d.
+__global__ __launch_bounds__(GEN_THREADS) void gram_frobenius_kernel(const double* taps, int64_t ldt,
+                                                                     int K, int N, double* out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* c = reinterpret_cast<double*>(smem);
+  double* red = c + N;
+  const double* h = taps + (int64_t)blockIdx.x * ldt;
+  for (int i = threadIdx.x; i < N; i += GEN_THREADS) c[i] = (i < K) ? h[i] : 0.0;
+  __syncthreads();
+  block_cumsum<false>(c, c, N, red);
+  double part = 0.0;
+  for (int d = threadIdx.x; d < N; d += GEN_THREADS) {
+    double r = 0.0, acc = 0.0;
+    for (int t = 0; t < N - d; ++t) {
+      r = fma(c[t], c[t + d], r);
+      acc = fma(r, r, acc);
+    }
+    part += (d == 0 ? 1.0 : 2.0) * acc;
+  }
+  const double tot = block_sum(part, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = sqrt(tot);
+}
+
+// cost[c][v] = 0.5 || y_v - taps * z_v ||^2 ; grid = (V, n_hrf).  taps index:
+// shared candidates taps[c][K] (per_voxel = 0) or one HRF per (candidate, voxel)
+// taps[c][v][K] (per_voxel = 1).
 __global__ __launch_bounds__(GEN_THREADS) void hrf_cost_kernel(const double* z, int64_t ldz,
                                                                const float* y, int64_t ldy, int V,
                                                                int N, const double* taps, int K,
-                                                               double* cost) {
+                                                               double* cost, int per_voxel) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* a = reinterpret_cast<double*>(smem);
   double* k = a + N;
@@ -165,7 +213,7 @@ __global__ __launch_bounds__(GEN_THREADS) void hrf_cost_kernel(const double* z, 
   const int v = blockIdx.x, c = blockIdx.y;
   const double* zr = z + (int64_t)v * ldz;
   const float* yr = y + (int64_t)v * ldy;
-  const double* tc = taps + (int64_t)c * K;
+  const double* tc = taps + (per_voxel ? ((int64_t)c * V + v) * K : (int64_t)c * K);
   for (int i = threadIdx.x; i < N; i += GEN_THREADS) a[i] = zr[i];
   for (int i = threadIdx.x; i < K; i += GEN_THREADS) k[i] = tc[i];
   __syncthreads();
@@ -233,11 +281,13 @@ __global__ __launch_bounds__(GEN_THREADS) void fista_generic_kernel(FistaArgs a_
   const int p = blockIdx.x;
   const float* yr = a_.y + (int64_t)(p / a_.y_rep) * a_.ldy;
   double* wrow = a_.w + (int64_t)p * a_.ldw;
+  const double* tp = a_.taps_pp ? a_.taps_pp + (int64_t)p * a_.ldt : taps;
+  const double stp = a_.step_vec ? a_.step_vec[p] : a_.step;
   for (int i = threadIdx.x; i < N; i += GEN_THREADS) w[i] = wrow[i];
-  for (int i = threadIdx.x; i < K; i += GEN_THREADS) k[i] = taps[i];
+  for (int i = threadIdx.x; i < K; i += GEN_THREADS) k[i] = tp[i];
   __syncthreads();
   const double lb = a_.lbda_vec ? a_.lbda_vec[p] : a_.lbda;
-  const double th = lb * a_.step;
+  const double th = lb * stp;
   const int stop = a_.stop_mode;
   float* Jrow = WITH_J ? a_.J + (int64_t)p * a_.ldj : nullptr;
 
@@ -268,7 +318,7 @@ __global__ __launch_bounds__(GEN_THREADS) void fista_generic_kernel(FistaArgs a_
     const double nb1 = -(1.0 + beta);
     double num = 0.0, den = 0.0;
     for (int i = threadIdx.x; i < N; i += GEN_THREADS) {
-      const double u = fma(-a_.step, a[i], w[i]);
+      const double u = fma(-stp, a[i], w[i]);
       const double d = fmin(fmax(u, -th), th);
       const double wn = fma(nb1, d, u);
       w[i] = wn;

@@ -26,4 +26,16 @@ int launch_fast(const FistaArgs& a, const double* taps, int K, bool with_j, int 
   return 0;
 }
 
+// per-problem taps/step variant (a.taps_pp, a.step_vec set); no cost trace
+template <int S, int KT>
+int launch_fast_pp(const FistaArgs& a, int stop, hipStream_t st) {
+  const TapPairs<KT> tp{};
+  const dim3 grid((unsigned)(((int64_t)a.P * 16 + 255) / 256)), block(256);
+  if (stop == PB_STOP_NONE)
+    hipLaunchKernelGGL((fista_fast_kernel<S, KT, false, 0, true>), grid, block, 0, st, a, tp);
+  else
+    hipLaunchKernelGGL((fista_fast_kernel<S, KT, false, 1, true>), grid, block, 0, st, a, tp);
+  return 0;
+}
+
 }  // namespace pb

@@ -283,3 +283,109 @@ def hrf_cost(Z, Y, taps):
                              t_dev.data_ptr(), K, C, cost.data_ptr(), _stream_ptr(dev))
     _lib.check(rc, "pb_hrf_cost")
     return cost
+
+
+# ---- per-voxel HRFs (batched blind deconvolution) ---------------------------
+def fista_solve_pp(Y, taps, steps, lbda, n_iter, W0=None, stop=None, tol=0.0, force=None):
+    """:func:`fista_solve` with one HRF and one step per problem: ``taps`` float64
+    CUDA ``(V, K)``, ``steps`` float64 CUDA ``(V,)``.  Returns ``(W, n_done)``."""
+    lib = _lib.load()
+    Y = _rows(Y, torch.float32, "Y")
+    taps = _rows(taps, torch.float64, "taps")
+    dev = Y.device
+    V, N = Y.shape
+    if taps.shape[0] != V:
+        raise ValueError("taps must have one row per voxel")
+    steps = steps.to(device=dev, dtype=torch.float64).contiguous().ravel()
+    if steps.numel() != V:
+        raise ValueError("steps must have one entry per voxel")
+    W = torch.zeros((V, N), dtype=torch.float64, device=dev) if W0 is None else \
+        _rows(W0, torch.float64, "W0").clone()
+    lbda_dev, lbda_scalar = None, 0.0
+    if np.ndim(lbda) == 0 and not torch.is_tensor(lbda):
+        lbda_scalar = float(lbda)
+    else:
+        lbda_dev = torch.as_tensor(lbda, dtype=torch.float64).to(dev).contiguous().ravel()
+    betas = _betas_on(dev, n_iter)
+    n_done = torch.empty((V,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.pb_fista_solve_pp(
+            Y.data_ptr(), _ld(Y), W.data_ptr(), _ld(W), V, N, taps.data_ptr(), _ld(taps),
+            taps.shape[1], steps.data_ptr(), lbda_scalar,
+            lbda_dev.data_ptr() if lbda_dev is not None else None, betas.data_ptr(), int(n_iter),
+            _STOP[stop], float(tol), n_done.data_ptr(), _FORCE[force], _stream_ptr(dev))
+    _lib.check(rc, "pb_fista_solve_pp")
+    return W, n_done
+
+
+def fista_outputs_pp(W, taps):
+    """``z = cumsum(w)``, ``x = taps_v * z`` with one HRF per row."""
+    lib = _lib.load()
+    W = _rows(W, torch.float64, "W")
+    taps = _rows(taps, torch.float64, "taps")
+    dev = W.device
+    P, N = W.shape
+    Z = torch.empty_like(W)
+    X = torch.empty_like(W)
+    with torch.cuda.device(dev):
+        rc = lib.pb_fista_outputs_pp(W.data_ptr(), _ld(W), P, N, taps.data_ptr(), _ld(taps),
+                                     taps.shape[1], Z.data_ptr(), _ld(Z), X.data_ptr(), _ld(X),
+                                     _stream_ptr(dev))
+    _lib.check(rc, "pb_fista_outputs_pp")
+    return X, Z
+
+
+def hrf_cost_pv(Z, Y, taps):
+    """``0.5 ||y_v - taps[c, v] * z_v||^2``: ``taps`` float64 CUDA ``(C, V, K)`` ->
+    float64 ``(C, V)``."""
+    lib = _lib.load()
+    Z = _rows(Z, torch.float64, "Z")
+    Y = _rows(Y, torch.float32, "Y")
+    dev = Z.device
+    V, N = Z.shape
+    if taps.dim() != 3 or taps.shape[1] != V or taps.dtype != torch.float64:
+        raise ValueError("taps must be float64 (C, V, K)")
+    taps = taps.contiguous()
+    C, _, K = taps.shape
+    cost = torch.empty((C, V), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.pb_hrf_cost_pv(Z.data_ptr(), _ld(Z), Y.data_ptr(), _ld(Y), V, N, taps.data_ptr(),
+                                K, C, cost.data_ptr(), _stream_ptr(dev))
+    _lib.check(rc, "pb_hrf_cost_pv")
+    return cost
+
+
+def gram_frobenius_batch(taps, n):
+    """``||A^T A||_F`` per row of ``taps`` (float64 CUDA ``(P, K)``), ``A =
+    toeplitz(taps_p, n, n) tril(1)`` (pybold/bold_signal.py:249-253)."""
+    lib = _lib.load()
+    taps = _rows(taps, torch.float64, "taps")
+    dev = taps.device
+    P, K = taps.shape
+    out = torch.empty((P,), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.pb_gram_frobenius(taps.data_ptr(), _ld(taps), P, K, int(n), out.data_ptr(),
+                                   _stream_ptr(dev))
+    _lib.check(rc, "pb_gram_frobenius")
+    return out
+
+
+def spm_hrf_batch(deltas, t_r, dur, dt=0.001, p_delay=6, undershoot=16.0, p_disp=1.0, u_disp=1.0,
+                  p_u_ratio=0.167):
+    """Un-normalised SPM HRFs for a CUDA vector of dilations (any shape), sampled
+    like ``spm_hrf(delta, t_r, dur, normalized_hrf=False)`` (pybold/hrf_model.py:12-39).
+    Returns float64 CUDA ``deltas.shape + (K,)``."""
+    lib = _lib.load()
+    dev = deltas.device
+    d = deltas.to(torch.float64).contiguous()
+    n_fine = int(float(dur) / dt)
+    t = np.linspace(0, dur, n_fine)[::int(t_r / dt)]
+    t_dev = torch.from_numpy(np.ascontiguousarray(t)).to(dev)
+    M, K = d.numel(), len(t)
+    out = torch.empty((M, K), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.pb_spm_hrf(d.data_ptr(), M, t_dev.data_ptr(), K, p_delay / p_disp, dt / p_disp,
+                            undershoot / u_disp, dt / u_disp, p_u_ratio, out.data_ptr(),
+                            _stream_ptr(dev))
+    _lib.check(rc, "pb_spm_hrf")
+    return out.reshape(tuple(deltas.shape) + (K,))
