@@ -180,6 +180,27 @@ def run(args):
         dt2 = (time.perf_counter() - t2) / 5
         out["other_configs"] = {"config2_%d_voxels" % V2: {
             "value": V2 * n_iter / dt2, "unit": "voxel-iterations/s", "ms_per_solve": dt2 * 1e3}}
+        # host-buffer variant of the boundary: y starts in pinned host memory and the
+        # iterate is copied back (never the headline value)
+        Yh = Y.cpu().pin_memory()
+        Wh = torch.empty(plan.W.shape, dtype=torch.float64).pin_memory()
+        Yd = torch.empty_like(Y)
+        planp = solver.FistaPlan(Yd, hrf, args.lbda, step, n_iter, force=None)
+        def pcie_step():
+            Yd.copy_(Yh, non_blocking=True)
+            planp.run()
+            Wh.copy_(planp.W, non_blocking=True)
+        pcie_step()
+        torch.cuda.synchronize(dev)
+        t3 = time.perf_counter()
+        for _ in range(3):
+            pcie_step()
+        torch.cuda.synchronize(dev)
+        dt3 = (time.perf_counter() - t3) / 3
+        out["pcie_inclusive"] = {"value": V * n_iter / dt3, "unit": "voxel-iterations/s",
+                                 "ms_per_solve": dt3 * 1e3,
+                                 "note": "H2D of y (fp32) + solve + D2H of diff_z (fp64), pinned host buffers"}
+        del Yh, Wh, Yd, planp
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"], out["parity"] = cpu_baseline(Y, plan.W, hrf, args.lbda, step, n_iter,
@@ -210,8 +231,14 @@ def cpu_baseline(Y, W_gpu, hrf, lbda, step, n_iter, target_s):
     dt = time.perf_counter() - t0
     Wg = W_gpu[:n_sample].cpu().numpy()
     err = float((np.linalg.norm(Wg - Wc, axis=1) / (np.linalg.norm(Wc, axis=1) + 1e-300)).max())
+    # the reference's own formulation (dense Toeplitz mat-vecs, NumPy float64, as
+    # pybold/linear.py:73-113) on ONE core, for context next to the matrix-free C port
+    from oracle import pybold_oracle as orc
+    t1 = time.perf_counter()
+    orc.fista_batch(Yh[:4], hrf, lbda, step, n_iter, dense=True)
+    dense_rate = 4 * n_iter / (time.perf_counter() - t1)
     base = {"value": n_sample * n_iter / dt, "unit": "voxel-iterations/s", "cores": int(used),
-            "kind": "port",
+            "kind": "port", "numpy_dense_toeplitz_1core": dense_rate,
             "sample": "first %d voxels of the same batch x %d iterations, C/OpenMP float64 "
                       "matrix-free port (oracle/fista_oracle.c), %.1f s" % (n_sample, n_iter, dt)}
     parity = {"max_rel_l2_diff_z_vs_cpu_oracle": err, "voxels_checked": n_sample, "tolerance": 1e-5}
