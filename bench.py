@@ -42,6 +42,10 @@ def parse():
     ap.add_argument("--scans", type=int, default=300)
     ap.add_argument("--iters", type=int, default=500)
     ap.add_argument("--lbda", type=float, default=1.0)
+    ap.add_argument("--extras", action="store_true",
+                    help="also time BASELINE config 2 (10k voxels) and the PCIe-inclusive solve "
+                         "(extra launches of the same kernel; off by default so that a rocprof "
+                         "summary of the default command holds only the timed launches)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="target CPU time of the cpu_baseline sample (0 = skip)")
     return ap.parse_args()
@@ -167,7 +171,7 @@ def run(args):
                              "kernel is VALU-issue bound (see DESIGN.md)"},
     }
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and args.extras:
         # BASELINE config 2 (10k voxels x 300 scans x 500 iterations) for reference
         V2 = min(10000, V)
         plan2 = solver.FistaPlan(Y[:V2].contiguous(), hrf, args.lbda, step, n_iter, force=None)
