@@ -149,6 +149,15 @@ int pb_hrf_cost(const double* z_dev, int64_t ldz, const float* y_dev, int64_t ld
                 double* cost_dev, void* stream);
 
 /*
+ * Spectral radius of H^T H for H = toeplitz(taps, N, N) . cumsum by the power
+ * iteration of spectral_radius_est (pybold/utils.py:94-109), fused in one launch:
+ * x0_dev float64 [N] start vector (the caller draws it, as the reference does with
+ * np.random.randn), out_dev float64 [2] = { ||x_new||, iterations done }.
+ */
+int pb_spectral_radius(const double* x0_dev, int N, const double* taps_dev, int K,
+                       int nb_iter, double tol, double* out_dev, void* stream);
+
+/*
  * Per-voxel HRFs (blind deconvolution with one HRF dilation per voxel, the loop
  * the reference fans out over voxels: pybold/bold_signal.py:281-382,
  * examples/icassp_2019/simulation.py:62-72).

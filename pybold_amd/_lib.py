@@ -52,6 +52,7 @@ SIGNATURES = {
                                _c_int, _ptr, _c_int, _ptr]),
     "pb_hrf_cost": (_c_int, [_ptr, _c_i64, _ptr, _c_i64, _c_int, _c_int, _ptr,
                              _c_int, _c_int, _ptr, _ptr]),
+    "pb_spectral_radius": (_c_int, [_ptr, _c_int, _ptr, _c_int, _c_int, _c_dbl, _ptr, _ptr]),
     "pb_fista_solve_pp": (_c_int, [
         _ptr, _c_i64, _ptr, _c_i64, _c_int, _c_int,     # y, ldy, w, ldw, P, N
         _ptr, _c_i64, _c_int, _ptr,                     # taps_dev, ldt, K, step_dev

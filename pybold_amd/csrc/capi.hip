@@ -213,6 +213,18 @@ int pb_fista_stats(const double* w_dev, int64_t ldw, const float* y_dev, int64_t
   return check_launch("stats_kernel");
 }
 
+int pb_spectral_radius(const double* x0_dev, int N, const double* taps_dev, int K, int nb_iter,
+                       double tol, double* out_dev, void* stream) {
+  if (!x0_dev || !taps_dev || !out_dev || N < 1 || K < 1 || nb_iter < 0)
+    return fail(PB_ERR_INVALID, "pb_spectral_radius: bad argument");
+  if (3 * (int64_t)N + K + 8 > LDS_DOUBLES_MAX)
+    return fail(PB_ERR_INVALID, "pb_spectral_radius: N=%d K=%d exceeds LDS", N, K);
+  const size_t lds = (size_t)(3 * N + K + 8) * sizeof(double);
+  hipLaunchKernelGGL(pb::power_iter_kernel, dim3(1), dim3(pb::GEN_THREADS), lds, (hipStream_t)stream,
+                     x0_dev, N, taps_dev, K, nb_iter, tol, out_dev);
+  return check_launch("power_iter_kernel");
+}
+
 int pb_integ_op(const double* x, int64_t ldx, double* out, int64_t ldo, int V, int N, void* st) {
   return launch_op<pb::OP_INTEG>(x, ldx, out, ldo, V, N, N, nullptr, 0, st, "pb_integ_op");
 }

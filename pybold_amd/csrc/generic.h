@@ -229,6 +229,48 @@ __global__ __launch_bounds__(GEN_THREADS) void hrf_cost_kernel(const double* z, 
   if (threadIdx.x == 0) cost[(int64_t)c * V + v] = 0.5 * tot;
 }
 
+// Power iteration of pybold/utils.py:94-109 on H^T H, H = toeplitz(taps) . cumsum, entirely in
+// one workgroup: x <- H^T H x / ||x||, stop when | ||x_new|| - ||x_old|| | < tol or after nb_iter
+// steps; out[0] = ||x_new||, out[1] = steps done.  LDS: x[N] a[N] b[N] k[K] red[8].
+__global__ __launch_bounds__(GEN_THREADS) void power_iter_kernel(const double* x0, int N,
+                                                                 const double* taps, int K,
+                                                                 int nb_iter, double tol,
+                                                                 double* out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* x = reinterpret_cast<double*>(smem);
+  double* a = x + N;
+  double* b = a + N;
+  double* k = b + N;
+  double* red = k + K;
+  double part = 0.0;
+  for (int i = threadIdx.x; i < N; i += GEN_THREADS) {
+    x[i] = x0[i];
+    part = fma(x[i], x[i], part);
+  }
+  for (int i = threadIdx.x; i < K; i += GEN_THREADS) k[i] = taps[i];
+  double n_old = sqrt(block_sum(part, red));
+  double n_new = n_old;
+  int it = 0;
+  for (; it < nb_iter; ++it) {
+    block_cumsum<false>(x, a, N, red);
+    block_conv(a, N, b, N, k, K);
+    block_corr(b, N, a, N, k, K);
+    block_cumsum<true>(a, a, N, red);
+    part = 0.0;
+    for (int i = threadIdx.x; i < N; i += GEN_THREADS) {
+      x[i] = a[i] / n_old;
+      part = fma(x[i], x[i], part);
+    }
+    n_new = sqrt(block_sum(part, red));
+    if (fabs(n_new - n_old) < tol) { ++it; break; }
+    n_old = n_new;
+  }
+  if (threadIdx.x == 0) {
+    out[0] = n_new;
+    out[1] = (double)it;
+  }
+}
+
 // r2[p] = || taps * cumsum(w_p) - y_p ||^2 , l1[p] = || w_p ||_1
 // (the quantities R, G the lambda search tracks, pybold/bold_signal.py:141-157)
 __global__ __launch_bounds__(GEN_THREADS) void stats_kernel(const double* w, int64_t ldw,

@@ -212,6 +212,23 @@ def fista_stats(W, Y, hrf, y_rep=1):
     return r2, l1
 
 
+def spectral_radius(x0, hrf, nb_iter=30, tol=1.0e-6):
+    """Power iteration of pybold/utils.py:94-109 for ``H = toeplitz(hrf) . cumsum``
+    from the start vector ``x0`` (1-D float64 array), in one kernel launch.
+    Returns ``(rho, iterations done)``."""
+    lib = _lib.load()
+    dev = device()
+    x = torch.from_numpy(np.ascontiguousarray(x0, dtype=np.float64).ravel()).to(dev)
+    t = torch.from_numpy(_as_taps(hrf)).to(dev)
+    out = torch.empty((2,), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.pb_spectral_radius(x.data_ptr(), x.numel(), t.data_ptr(), t.numel(), int(nb_iter),
+                                    float(tol), out.data_ptr(), _stream_ptr(dev))
+    _lib.check(rc, "pb_spectral_radius")
+    rho, n_it = out.cpu().numpy()
+    return float(rho), int(n_it)
+
+
 def _apply(fn_name, X, n_out, taps=None, n_in=None):
     lib = _lib.load()
     X = _rows(X, torch.float64, "x")

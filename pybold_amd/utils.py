@@ -9,6 +9,12 @@ def spectral_radius_est(L, x_shape, nb_iter=30, tol=1.0e-6, verbose=False):
     global RNG (seed it for reproducible runs).  ``L`` is any object with
     ``.op`` / ``.adj``; float64 on the host, the operator runs on the GPU."""
     v = np.random.randn(*x_shape)            # global RNG, as the reference (:97)
+    fused = _fused_radius(L, v, nb_iter, tol)
+    if fused is not None:
+        rho, n_it = fused
+        if verbose and n_it >= nb_iter:
+            print("spectral_radius_est: no convergence after %d iterations" % nb_iter)
+        return rho
     nv = norm_2(v)
     rho, converged = nv, False
     for _ in range(nb_iter):
@@ -21,6 +27,18 @@ def spectral_radius_est(L, x_shape, nb_iter=30, tol=1.0e-6, verbose=False):
     if verbose and not converged:
         print("spectral_radius_est: no convergence after %d iterations" % nb_iter)
     return rho
+
+
+def _fused_radius(L, v, nb_iter, tol):
+    """The standard operator of the solvers (square ``ConvAndLinear`` over
+    ``DiscretInteg``) runs the whole iteration in one kernel launch instead of
+    2 * nb_iter operator calls with host round trips; any other ``.op/.adj`` object
+    takes the generic host loop."""
+    from . import linear, solver
+    if (type(L) is linear.ConvAndLinear and type(L.M) is linear.DiscretInteg
+            and L.dim_in == L.dim_out and v.ndim == 1 and v.shape[0] == L.dim_in):
+        return solver.spectral_radius(v, L.k, nb_iter, tol)
+    return None
 
 
 def gram_frobenius(hrf, n):

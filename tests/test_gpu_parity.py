@@ -305,6 +305,38 @@ def test_spectral_radius_matches_golden(pa, golden):
     assert 0.9 * rho == pytest.approx(float(g["lipschitz"]), rel=1e-10)
 
 
+def test_fused_power_iteration_equals_host_loop(pa, golden):
+    pybold_amd, solver = pa
+    g = golden("case1")
+    n = len(g["y"])
+    rho, n_it = solver.spectral_radius(g["x0"], g["hrf"])
+    assert 0.9 * rho == pytest.approx(float(g["lipschitz"]), rel=1e-12)
+    ref = orc.spectral_radius_est(orc.DenseH(g["hrf"], n, n), g["x0"])
+    assert rho == pytest.approx(ref, rel=1e-12) and 1 <= n_it <= 30
+
+    class Wrapped:                       # a foreign .op/.adj object takes the generic host loop
+        def __init__(self, H):
+            self.H = H
+
+        def op(self, x):
+            return self.H.op(x)
+
+        def adj(self, x):
+            return self.H.adj(x)
+    H = pybold_amd.ConvAndLinear(pybold_amd.DiscretInteg(), g["hrf"], n, n)
+    np.random.seed(0)
+    a = pybold_amd.spectral_radius_est(H, (n,))
+    np.random.seed(0)
+    b = pybold_amd.spectral_radius_est(Wrapped(H), (n,))
+    assert a == pytest.approx(b, rel=1e-12)
+    # not converged within nb_iter: still returns the last norm, like the reference
+    np.random.seed(0)
+    c = pybold_amd.spectral_radius_est(H, (n,), nb_iter=2)
+    np.random.seed(0)
+    d = pybold_amd.spectral_radius_est(Wrapped(H), (n,), nb_iter=2)
+    assert c == pytest.approx(d, rel=1e-12)
+
+
 def test_hrf_fit_err_and_estim(pa, golden):
     pybold_amd, _ = pa
     g = golden("hrf_estim")
