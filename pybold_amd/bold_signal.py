@@ -302,7 +302,7 @@ def bd(y, t_r, lbda=1.0, theta_0=None, z_0=None, hrf_dur=20.0,  # noqa
 
     for idx in range(nb_iter):
         diff_z = z_step(diff_z, h)
-        z = np.cumsum(diff_z)
+        z = DiscretInteg().op(diff_z)                 # block signal of this iterate (:326)
         theta, _, _ = fmin_l_bfgs_b(func=hrf_fit_err, x0=theta, args=(z, y, t_r, hrf_dur),
                                     bounds=bounds, approx_grad=True, maxiter=999, pgtol=1.0e-12)
         h, _ = spm_hrf(float(np.ravel(theta)[0]), t_r, hrf_dur, False)
