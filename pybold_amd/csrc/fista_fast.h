@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
       for (int j = 0; j < S; ++j) hist[q][j] = 0.0;
   }
 
-  bool active = true;                       // per-problem (row-uniform) early-stop state
+  bool active = live;                       // per-problem (row-uniform) early-stop state; idle rows never hold a wave
   int done = 0;
   float* Jrow = WITH_J ? a.J + (int64_t)p * a.ldj : nullptr;
 
