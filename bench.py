@@ -46,6 +46,9 @@ def parse():
                     help="also time BASELINE config 2 (10k voxels) and the PCIe-inclusive solve "
                          "(extra launches of the same kernel; off by default so that a rocprof "
                          "summary of the default command holds only the timed launches)")
+    ap.add_argument("--kernel", choices=["auto", "fast1", "generic"], default="auto",
+                    help="auto = library dispatch; fast1 = one problem per DPP row "
+                         "(fista_fast_kernel) even where the pair kernel applies")
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="target CPU time of the cpu_baseline sample (0 = skip)")
     return ap.parse_args()
@@ -102,8 +105,10 @@ def run(args):
     H = ConvAndLinear(DiscretInteg(), hrf, dim_in=N, dim_out=N)
     lipschitz = 0.9 * spectral_radius_est(H, (N,))              # pybold/bold_signal.py:52
     step = 1.0 / lipschitz
-    plan = solver.FistaPlan(Y, hrf, args.lbda, step, n_iter, force=None)
-    fast = solver.has_fast_path(N, len(hrf))
+    plan = solver.FistaPlan(Y, hrf, args.lbda, step, n_iter,
+                            force=None if args.kernel == "auto" else args.kernel)
+    kernel_name = (solver.which_kernel(N, len(hrf), V) if args.kernel == "auto" else
+                   {"fast1": solver.KERNEL_NAMES[1], "generic": solver.KERNEL_NAMES[0]}[args.kernel])
 
     def barrier():
         if dist is not None:
@@ -160,7 +165,7 @@ def run(args):
                                "deconv, fixed canonical HRF (K=%d), lambda=%g, %d FISTA iterations "
                                "per step" % (V, N, len(hrf), args.lbda, n_iter),
                    "voxels_per_gpu": V, "scans": N, "taps": int(len(hrf)), "iters_per_step": n_iter,
-                   "kernel": "fista_fast_kernel (register-resident)" if fast else "fista_generic_kernel",
+                   "kernel": kernel_name,
                    "parallelism": "voxel-shard x%d, no data-path collective" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

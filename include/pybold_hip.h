@@ -39,6 +39,11 @@ extern "C" {
 #define PB_FLAG_FORCE_GENERIC 1u  /* use the any-size LDS kernel even when a
                                      register-resident specialisation exists */
 #define PB_FLAG_FORCE_FAST 2u     /* fail instead of using the generic kernel */
+#define PB_FLAG_NO_PAIR 4u        /* plain solves: always one problem per DPP row
+                                     (fista_fast_kernel) */
+#define PB_FLAG_FORCE_PAIR 8u     /* plain solves: always two problems per DPP row
+                                     (fista_pair_kernel); default = whichever the dispatch
+                                     model expects to finish first for this problem count */
 
 /* early-stop rules (evaluated per problem, inside the kernel) */
 #define PB_STOP_NONE 0
@@ -54,6 +59,11 @@ const char* pb_last_error(void);
 /* 1 if a register-resident specialisation exists for (N scans, K taps),
  * else 0 (the generic kernel is used).  Host-only query. */
 int pb_fista_has_fast_path(int N, int K);
+
+/* Which kernel pb_fista_solve will run for this call shape (no flags): 0 = generic
+ * LDS kernel, 1 = register-resident, one problem per 16-lane row (fista_fast_kernel),
+ * 2 = register-resident, two problems per row (fista_pair_kernel).  Host-only query. */
+int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mode, int wind);
 
 /*
  * Fused FISTA-like solver: n_iter iterations of the recurrence of

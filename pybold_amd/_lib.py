@@ -13,6 +13,8 @@ LIB_PATH = os.environ.get("PYBOLD_HIP_LIB") or os.path.join(_HERE, "libpybold_hi
 
 PB_FLAG_FORCE_GENERIC = 1
 PB_FLAG_FORCE_FAST = 2
+PB_FLAG_NO_PAIR = 4
+PB_FLAG_FORCE_PAIR = 8
 PB_STOP_NONE = 0
 PB_STOP_LOOPS = 1
 PB_STOP_WINDOW = 2
@@ -27,6 +29,7 @@ SIGNATURES = {
     "pb_version": (_c_int, []),
     "pb_last_error": (ctypes.c_char_p, []),
     "pb_fista_has_fast_path": (_c_int, [_c_int, _c_int]),
+    "pb_fista_which_kernel": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int]),
     "pb_fista_solve": (_c_int, [
         _ptr, _c_i64, _c_int,            # y_dev, ldy, y_rep
         _ptr, _c_i64, _c_int, _c_int,    # w_dev, ldw, P, N

@@ -10,6 +10,7 @@
 #include "fista_fast.h"
 #include "generic.h"
 #include "launch_fast.h"
+#include "fista_pair.h"
 
 namespace {
 
@@ -36,11 +37,13 @@ constexpr int LDS_DOUBLES_MAX = 20000;  // 160 KB of LDS per workgroup
 typedef int (*fast_launch_fn)(const pb::FistaArgs&, const double* taps, int K, bool with_j,
                               int stop, hipStream_t);
 typedef int (*fast_launch_pp_fn)(const pb::FistaArgs&, int stop, hipStream_t);
+typedef int (*pair_launch_fn)(const pb::FistaArgs&, const double* taps, int K, hipStream_t);
 
 struct FastEntry {
   int S, KT;
   fast_launch_fn fn;
   fast_launch_pp_fn fn_pp;
+  pair_launch_fn fn_pair;     // two-problems-per-row kernel (S <= 20 only), else nullptr
 };
 
 }  // namespace
@@ -49,14 +52,19 @@ struct FastEntry {
 namespace pb {
 #define PB_FAST(S, KT)                                                                              \
   extern template int launch_fast<S, KT>(const FistaArgs&, const double*, int, bool, int, hipStream_t); \
-  extern template int launch_fast_pp<S, KT>(const FistaArgs&, int, hipStream_t);
+  extern template int launch_fast_pp<S, KT>(const FistaArgs&, int, hipStream_t);            \
+  extern template int launch_pair<S, KT>(const FistaArgs&, const double*, int, hipStream_t);
 #include "fast_table.inc"
 #undef PB_FAST
 }  // namespace pb
 
 namespace {
 
-#define PB_FAST(S, KT) {S, KT, &pb::launch_fast<S, KT>, &pb::launch_fast_pp<S, KT>},
+template <int S, int KT>
+constexpr pair_launch_fn pair_or_null() {
+  if constexpr (S <= 20) return &pb::launch_pair<S, KT>; else return nullptr;
+}
+#define PB_FAST(S, KT) {S, KT, &pb::launch_fast<S, KT>, &pb::launch_fast_pp<S, KT>, pair_or_null<S, KT>()},
 const FastEntry kFast[] = {
 #include "fast_table.inc"
 };
@@ -70,6 +78,28 @@ const FastEntry* pick_fast(int N, int K) {
     if (!best || (int64_t)e.S * e.KT < (int64_t)best->S * best->KT) best = &e;
   }
   return best;
+}
+
+// Which of the two register-resident kernels finishes a plain solve of P problems first.
+// Both keep two waves per SIMD; a wave of the pair kernel carries 8 problems at ~0.905 of
+// the per-problem cost, a wave of the single-row kernel 4.  The last, partially filled
+// round of waves costs about 0.55 of a round when at most half full (the waves then run
+// alone on their SIMDs) and a full round otherwise (measured crossovers:
+// tools/ab_pair_sizes.py).
+bool pair_is_faster(int P) {
+  static const double slots = [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+      return 2048.0;
+    return (double)prop.multiProcessorCount * 4.0 * 2.0;
+  }();
+  auto finish = [&](double waves, double wave_cost) {
+    const double r = waves / slots;
+    const double whole = std::floor(r), part = r - whole;
+    return wave_cost * (whole + (part == 0.0 ? 0.0 : (part <= 0.5 ? 0.55 : 1.0)));
+  };
+  return finish(std::ceil(P / 8.0), 2.0 * 0.905) < finish(std::ceil(P / 4.0), 1.0);
 }
 
 template <int KIND>
@@ -97,6 +127,16 @@ int pb_version(void) { return 100; }
 const char* pb_last_error(void) { return g_err; }
 
 int pb_fista_has_fast_path(int N, int K) { return (N >= 1 && K >= 1 && pick_fast(N, K)) ? 1 : 0; }
+
+int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mode, int wind) {
+  if (N < 1 || K < 1 || P < 1) return 0;
+  const FastEntry* fe = pick_fast(N, K);
+  if (fe && stop_mode == PB_STOP_WINDOW && (wind != 6 || fe->S > 20)) fe = nullptr;
+  if (!fe) return 0;
+  if (fe->fn_pair && !with_cost_trace && stop_mode == PB_STOP_NONE && P >= 2 && pair_is_faster(P))
+    return 2;
+  return 1;
+}
 
 int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, int64_t ldw, int P,
                    int N, const double* taps_host, const double* taps_dev, int K, double step,
@@ -130,6 +170,12 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
   // (the reference default) on entries small enough to hold them; else LDS kernel
   if (fe && stop_mode == PB_STOP_WINDOW && (wind != 6 || fe->S > 20)) fe = nullptr;
   if (fe) {
+    // plain solve (no cost trace, no stop rule): two problems per DPP row
+    if (fe->fn_pair && !J_dev && stop_mode == PB_STOP_NONE && P >= 2 && !(flags & PB_FLAG_NO_PAIR) &&
+        ((flags & PB_FLAG_FORCE_PAIR) || pair_is_faster(P))) {
+      fe->fn_pair(a, taps_host, K, (hipStream_t)stream);
+      return check_launch("fista_pair_kernel");
+    }
     fe->fn(a, taps_host, K, J_dev != nullptr, stop_mode, (hipStream_t)stream);
     return check_launch("fista_fast_kernel");
   }

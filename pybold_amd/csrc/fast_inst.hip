@@ -6,4 +6,5 @@
 namespace pb {
 template int launch_fast<PB_S, PB_KT>(const FistaArgs&, const double*, int, bool, int, hipStream_t);
 template int launch_fast_pp<PB_S, PB_KT>(const FistaArgs&, int, hipStream_t);
+
 }

@@ -1,0 +1,262 @@
+// Register-resident fused FISTA kernel, "pair" form: TWO problems per 16-lane DPP
+// row, every per-sample quantity held as a float2 (problem A, problem B).
+//
+// Same recurrence, data layout and numerics as fista_fast.h (float64 iterate and
+// update, float32 scans/FIR); what changes is the packing of v_pk_fma_f32:
+//   fista_fast.h  packs over TAPS   acc = (sum even taps, sum odd taps) -> needs a
+//                 combine add per output and a shifted tap copy for alignment;
+//   here          packs over VOXELS acc = (x_A[j], x_B[j]) += h[m] * (z_A, z_B)[q-m]
+//                 with the tap broadcast from an SGPR (op_sel): no combine, no
+//                 alignment cases, scan chains and offsets are packed adds.
+// Instruction budget per voxel-iteration at S=19, K=30: ~800 against ~905.
+// Used for the plain solve (no cost trace, no stop rule, shared taps); the other
+// modes stay on fista_fast.h.  An odd problem count pads the last row with a copy
+// of the last problem (computed, never stored).
+#pragma once
+#include "common.h"
+#include "fista_fast.h"
+
+namespace pb {
+
+// taps as aligned pairs (h[2i], h[2i+1]); tap m is broadcast to both problems with an
+// op_sel swizzle of pair m/2, so the 30 taps cost 30 SGPRs
+template <int KT>
+struct TapsF {
+  static constexpr int NP = (KT + 1) / 2;
+  f2 pr[NP];
+};
+
+template <int KT>
+inline TapsF<KT> make_taps_f(const double* taps, int K) {
+  TapsF<KT> t;
+  auto h = [&](int m) -> float { return (m < K) ? (float)taps[m] : 0.0f; };
+  for (int i = 0; i < TapsF<KT>::NP; ++i) t.pr[i] = f2{h(2 * i), h(2 * i + 1)};
+  return t;
+}
+
+template <int CTRL>
+__device__ __forceinline__ f2 dpp_zero2(f2 v) {
+  return f2{dpp_zero<CTRL>(v.x), dpp_zero<CTRL>(v.y)};
+}
+
+template <int S, int KT>
+__global__ __launch_bounds__(256, 2) void fista_pair_kernel(FistaArgs a, TapsF<KT> taps) {
+  constexpr int H = KT - 1;
+  constexpr int D = (H + S - 1) / S;
+  constexpr int G = 5;                      // outputs per accumulator group
+  static_assert(D <= 15, "halo spans more than one DPP row");
+
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int sub = threadIdx.x & 15;
+  const int row = gid >> 4;
+  const int base = sub * S;
+  const int pA0 = 2 * row, pB0 = 2 * row + 1;
+  const bool liveA = pA0 < a.P, liveB = pB0 < a.P;
+  const int pA = liveA ? pA0 : a.P - 1;
+  const int pB = liveB ? pB0 : a.P - 1;
+
+  double wA[S], wB[S];
+  // y (both problems) and the padding mask live in LDS, not in registers (two problems
+  // per row leave no room).  Each lane re-reads only what it wrote itself, one
+  // ds_read_b64 + ds_read_b32 per sample and iteration on the otherwise idle LDS pipe,
+  // so no barrier is ever needed.  Layout [row of the workgroup][sample][lane of the row].
+  extern __shared__ __attribute__((aligned(16))) char pair_smem[];
+  f2* ly = reinterpret_cast<f2*>(pair_smem) + ((threadIdx.x >> 4) * S * 16 + sub);
+  float* lm = reinterpret_cast<float*>(pair_smem + (size_t)16 * S * 16 * sizeof(f2)) +
+              ((threadIdx.x >> 4) * S * 16 + sub);
+  {
+    const float* yA = a.y + (int64_t)(pA / a.y_rep) * a.ldy;
+    const float* yB = a.y + (int64_t)(pB / a.y_rep) * a.ldy;
+    const double* rA = a.w + (int64_t)pA * a.ldw;
+    const double* rB = a.w + (int64_t)pB * a.ldw;
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      const bool ok = base + j < a.N;
+      wA[j] = ok ? rA[base + j] : 0.0;
+      wB[j] = ok ? rB[base + j] : 0.0;
+      ly[j * 16] = f2{ok ? yA[base + j] : 0.0f, ok ? yB[base + j] : 0.0f};
+      lm[j * 16] = ok ? 1.0f : 0.0f;
+    }
+  }
+  const double lbA = a.lbda_vec ? a.lbda_vec[pA] : a.lbda;
+  const double lbB = a.lbda_vec ? a.lbda_vec[pB] : a.lbda;
+  const double thA = lbA * a.step, thB = lbB * a.step;
+  const double nstep = -a.step;
+
+  for (int it = 0; it < a.n_iter; ++it) {
+    asm volatile("" ::: "memory");          // keep the LDS reads inside the loop
+    // This translation unit keeps program order (Makefile: PAIRFLAGS), so loads are
+    // placed by hand well ahead of their use: the momentum factor here, y and the mask
+    // one output group ahead inside the FIR.
+    const double beta = a.betas[it];
+    // ---- z = cumsum(w) for both problems -----------------------------------
+    f2 z[S];
+    z[0] = f2{(float)wA[0], (float)wB[0]};
+#pragma unroll
+    for (int j = 1; j < S; ++j) z[j] = z[j - 1] + f2{(float)wA[j], (float)wB[j]};
+    {
+      const f2 off = f2{row_from_below<1>(row_prefix_incl(z[S - 1].x)),
+                        row_from_below<1>(row_prefix_incl(z[S - 1].y))};
+#pragma unroll
+      for (int j = 0; j < S; ++j) z[j] += off;
+    }
+
+    // ---- window of z: halo [0, H) from the lanes below, own samples [H, H+S) ----
+    f2 Z[H + S];
+    static_for<0, S>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      Z[H + j] = z[j];
+    });
+    static_for<1, D + 1>([&](auto dc) {
+      constexpr int d = decltype(dc)::value;
+      static_for<0, S>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int e = H - d * S + j;
+        if constexpr (e >= 0) Z[e] = dpp_zero2<DPP_ROW_SHR + d>(z[j]);
+      });
+    });
+
+    // ---- r = h * z - y ------------------------------------------------------
+    // Outputs are produced in groups of G with the tap loop outside, so that G
+    // independent accumulator chains sit next to each other in program order (a
+    // dependent v_pk_fma_f32 straight after its producer costs a wait state).
+    f2 r[S];
+    f2 ypre[G];                               // -y and mask of the group about to start
+    float mpre[G];
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+      ypre[q] = ly[(q < S ? q : S - 1) * 16];
+      mpre[q] = lm[(q < S ? q : S - 1) * 16];
+    }
+    static_for<0, (S + G - 1) / G>([&](auto gc) {
+      constexpr int j0 = decltype(gc)::value * G;
+      constexpr int gn = (S - j0 < G) ? S - j0 : G;
+      f2 acc[gn];
+      float mcur[gn];
+#pragma unroll
+      for (int q = 0; q < gn; ++q) {
+        acc[q] = -ypre[q];
+        mcur[q] = mpre[q];
+      }
+      if constexpr (j0 + G < S) {             // issue the next group's LDS reads now
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+          constexpr int dummy = 0;
+          const int jn = (j0 + G + q < S) ? j0 + G + q : S - 1;
+          ypre[q] = ly[jn * 16];
+          mpre[q] = lm[jn * 16];
+          (void)dummy;
+        }
+      }
+      static_for<0, KT>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        const f2 tp = taps.pr[m / 2];
+        const f2 tb = (m % 2 == 0) ? tp.xx : tp.yy;
+        static_for<0, gn>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          acc[q] = __builtin_elementwise_fma(tb, Z[H + j0 + q - m], acc[q]);
+        });
+      });
+#pragma unroll
+      for (int q = 0; q < gn; ++q) r[j0 + q] = acc[q] * f2{mcur[q], mcur[q]};
+    });
+
+    // ---- window of r: own samples [0, S), halo [S, S+H) from the lanes above ----
+    f2 R[S + H];
+    static_for<0, S>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      R[j] = r[j];
+    });
+    static_for<1, D + 1>([&](auto dc) {
+      constexpr int d = decltype(dc)::value;
+      static_for<0, S>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int e = d * S + j;
+        if constexpr (e < S + H) R[e] = dpp_zero2<DPP_ROW_SHL + d>(r[j]);
+      });
+    });
+
+    // ---- g = reverse-cumsum(K^T r) -------------------------------------------
+    f2 g[S];
+    static_for<0, (S + G - 1) / G>([&](auto gc) {
+      constexpr int j0 = decltype(gc)::value * G;
+      constexpr int gn = (S - j0 < G) ? S - j0 : G;
+      f2 acc[gn];
+#pragma unroll
+      for (int q = 0; q < gn; ++q) acc[q] = f2{0.f, 0.f};
+      static_for<0, KT>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        const f2 tp = taps.pr[m / 2];
+        const f2 tb = (m % 2 == 0) ? tp.xx : tp.yy;
+        static_for<0, gn>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          acc[q] = __builtin_elementwise_fma(tb, R[j0 + q + m], acc[q]);
+        });
+      });
+#pragma unroll
+      for (int q = 0; q < gn; ++q) g[j0 + q] = acc[q];
+    });
+#pragma unroll
+    for (int j = S - 2; j >= 0; --j) g[j] += g[j + 1];
+    {
+      const f2 off = f2{row_from_above<1>(row_suffix_incl(g[0].x)),
+                        row_from_above<1>(row_suffix_incl(g[0].y))};
+#pragma unroll
+      for (int j = 0; j < S; ++j) g[j] += off;
+    }
+
+    // ---- gradient step, prox, momentum (float64), per problem ------------------
+    // staged over all samples so that no instruction directly follows its producer
+    // (program order is kept in this translation unit)
+    const double nb1 = -(1.0 + beta);
+    {
+      double uA[S], uB[S], dA[S], dB[S];
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        uA[j] = fma(nstep, (double)g[j].x, wA[j]);
+        uB[j] = fma(nstep, (double)g[j].y, wB[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        dA[j] = fmax(uA[j], -thA);
+        dB[j] = fmax(uB[j], -thB);
+      }
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        dA[j] = fmin(dA[j], thA);
+        dB[j] = fmin(dB[j], thB);
+      }
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        wA[j] = fma(nb1, dA[j], uA[j]);
+        wB[j] = fma(nb1, dB[j], uB[j]);
+      }
+    }
+  }
+
+  double* oA = a.w + (int64_t)pA * a.ldw;
+  double* oB = a.w + (int64_t)pB * a.ldw;
+#pragma unroll
+  for (int j = 0; j < S; ++j) {
+    if (base + j < a.N) {
+      if (liveA) oA[base + j] = wA[j];
+      if (liveB) oB[base + j] = wB[j];
+    }
+  }
+  if (a.n_done && sub == 0) {
+    if (liveA) a.n_done[pA] = a.n_iter;
+    if (liveB) a.n_done[pB] = a.n_iter;
+  }
+}
+
+template <int S, int KT>
+int launch_pair(const FistaArgs& a, const double* taps, int K, hipStream_t st) {
+  const auto tf = make_taps_f<KT>(taps, K);
+  const int64_t rows = ((int64_t)a.P + 1) / 2;
+  const dim3 grid((unsigned)((rows * 16 + 255) / 256)), block(256);
+  const size_t lds = (size_t)16 * S * 16 * (sizeof(f2) + sizeof(float));
+  hipLaunchKernelGGL((fista_pair_kernel<S, KT>), grid, block, lds, st, a, tf);
+  return 0;
+}
+
+}  // namespace pb

@@ -1,0 +1,11 @@
+// One (PB_S, PB_KT) specialisation of the two-problems-per-row kernel.  Separate
+// translation unit: it is compiled with -mllvm -enable-misched=0 (see Makefile).
+#include "fista_pair.h"
+#ifndef PB_S
+#error "compile with -DPB_S=<samples per lane> -DPB_KT=<taps>"
+#endif
+namespace pb {
+#if PB_S <= 20
+template int launch_pair<PB_S, PB_KT>(const FistaArgs&, const double*, int, hipStream_t);
+#endif
+}

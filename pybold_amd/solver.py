@@ -9,12 +9,16 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (PB_FLAG_FORCE_FAST, PB_FLAG_FORCE_GENERIC, PB_STOP_LOOPS,
-                   PB_STOP_NONE, PB_STOP_WINDOW)
+from ._lib import (PB_FLAG_FORCE_FAST, PB_FLAG_FORCE_GENERIC, PB_FLAG_FORCE_PAIR, PB_FLAG_NO_PAIR,
+                   PB_STOP_LOOPS, PB_STOP_NONE, PB_STOP_WINDOW)
 
 _STOP = {None: PB_STOP_NONE, "none": PB_STOP_NONE, "loops": PB_STOP_LOOPS,
          "window": PB_STOP_WINDOW}
-_FORCE = {None: 0, "generic": PB_FLAG_FORCE_GENERIC, "fast": PB_FLAG_FORCE_FAST}
+# "fast" = a register-resident kernel (library picks single-row or pair form);
+# "fast1" / "fast2" pin the single-row / two-problems-per-row form
+_FORCE = {None: 0, "generic": PB_FLAG_FORCE_GENERIC, "fast": PB_FLAG_FORCE_FAST,
+          "fast1": PB_FLAG_FORCE_FAST | PB_FLAG_NO_PAIR,
+          "fast2": PB_FLAG_FORCE_FAST | PB_FLAG_FORCE_PAIR}
 
 
 def device(dev=None):
@@ -78,6 +82,16 @@ def _ld(t):
 
 def has_fast_path(n_scans, n_taps):
     return bool(_lib.load().pb_fista_has_fast_path(int(n_scans), int(n_taps)))
+
+
+KERNEL_NAMES = {0: "fista_generic_kernel (LDS)", 1: "fista_fast_kernel (register-resident)",
+                2: "fista_pair_kernel (register-resident, two problems per row)"}
+
+
+def which_kernel(n_scans, n_taps, n_problems, want_J=False, stop=None, wind=6):
+    """Name of the kernel :func:`fista_solve` dispatches to for this call shape."""
+    return KERNEL_NAMES[_lib.load().pb_fista_which_kernel(
+        int(n_scans), int(n_taps), int(n_problems), int(bool(want_J)), _STOP[stop], int(wind))]
 
 
 def fista_solve(Y, hrf, lbda, step, n_iter, W0=None, want_J=False, stop=None,

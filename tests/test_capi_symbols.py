@@ -43,6 +43,15 @@ def test_version_and_dispatch_table(lib):
     assert lib.pb_fista_has_fast_path(100000, 30) == 0
     assert lib.pb_fista_has_fast_path(300, 5000) == 0
     assert lib.pb_fista_has_fast_path(0, 30) == 0
+    # dispatch of a plain solve: pair kernel for machine-filling batches, single-row
+    # kernel for small ones and whenever a cost trace or a stop rule is requested
+    assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 0, 6) == 2
+    assert lib.pb_fista_which_kernel(300, 30, 100000, 1, 0, 6) == 1
+    assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 2, 6) == 1
+    assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 2, 4) == 0
+    assert lib.pb_fista_which_kernel(300, 30, 1, 0, 0, 6) == 1
+    assert lib.pb_fista_which_kernel(600, 30, 100000, 0, 0, 6) == 1      # S = 38: no pair form
+    assert lib.pb_fista_which_kernel(5000, 30, 10, 0, 0, 6) == 0
 
 
 def test_argument_errors_do_not_reach_the_gpu(lib):

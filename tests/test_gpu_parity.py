@@ -44,7 +44,7 @@ def grid_inputs(golden):
     return g, Y, g["hrf"], float(g["lip_s0"])
 
 
-@pytest.mark.parametrize("force", ["fast", "generic"])
+@pytest.mark.parametrize("force", ["fast1", "fast2", "generic"])
 def test_fista_vs_golden_grid(pa, golden, force):
     """lambda x iterations grid of SURVEY 8c case 3 (captures k=0 and the aliasing)."""
     _, solver = pa
@@ -113,8 +113,8 @@ def test_edge_shapes_fast_and_generic_agree_with_oracle(pa, N, K):
     H = orc.DenseH(hrf, N, N)
     lip = 1.1 * np.linalg.norm(H.K.dot(np.tril(np.ones((N, N)))), 2) ** 2 + 1e-12
     Wo = orc.fista_batch(Y.astype(np.float32).astype(np.float64), hrf, 0.05, 1.0 / lip, 40)
-    for force in ("fast", "generic"):
-        if force == "fast" and not solver.has_fast_path(N, K):
+    for force in ("fast1", "fast2", "generic"):
+        if force != "generic" and not solver.has_fast_path(N, K):
             continue
         W, _, _ = solver.fista_solve(dev32(Y), hrf, 0.05, 1.0 / lip, 40, force=force)
         err = np.abs(W.cpu().numpy() - Wo).max() / (np.abs(Wo).max() + 1e-30)
@@ -129,7 +129,7 @@ def test_lambda_zero_and_huge(pa, golden):
     g, Y, hrf, lip = grid_inputs(golden)
     Y32 = Y.astype(np.float32).astype(np.float64)
     for lbda in (0.0, 1e9):
-        for force in ("fast", "generic"):
+        for force in ("fast1", "fast2", "generic"):
             W, _, _ = solver.fista_solve(dev32(Y), hrf, lbda, 1.0 / lip, 20, force=force)
             Wo = orc.fista_batch(Y32, hrf, lbda, 1.0 / lip, 20)
             assert rel_rows(W.cpu().numpy(), Wo) < EPS, (lbda, force)
@@ -138,13 +138,21 @@ def test_lambda_zero_and_huge(pa, golden):
 
 
 def test_many_problems_partial_last_block(pa, golden):
-    """P not a multiple of 16: the last workgroup has idle rows."""
+    """P not a multiple of 16 (nor of 2): idle rows in the last workgroup, and an
+    unpaired last problem in the two-problems-per-row kernel."""
     _, solver = pa
     g, Y, hrf, lip = grid_inputs(golden)
     Yb = np.tile(Y, (9, 1))[:35] * np.linspace(0.5, 1.5, 35)[:, None]
-    W, _, _ = solver.fista_solve(dev32(Yb), hrf, 1.0, 1.0 / lip, 25)
     Wo = orc.fista_batch(Yb.astype(np.float32).astype(np.float64), hrf, 1.0, 1.0 / lip, 25)
-    assert rel_rows(W.cpu().numpy(), Wo) < EPS
+    for force in ("fast1", "fast2"):
+        W, _, n_done = solver.fista_solve(dev32(Yb), hrf, 1.0, 1.0 / lip, 25, force=force)
+        assert rel_rows(W.cpu().numpy(), Wo) < EPS, force
+        assert (n_done.cpu().numpy() == 25).all()
+    # per-problem lambda and shared y rows through the pair kernel
+    lam = np.tile([0.1, 1.0, 10.0], 35)
+    W, _, _ = solver.fista_solve(dev32(Yb), hrf, lam, 1.0 / lip, 10, y_rep=3, force="fast2")
+    W1, _, _ = solver.fista_solve(dev32(Yb), hrf, lam, 1.0 / lip, 10, y_rep=3, force="fast1")
+    assert rel_rows(W.cpu().numpy(), W1.cpu().numpy()) < 1e-6
 
 
 def test_loops_deconv_goldens(pa, golden):
