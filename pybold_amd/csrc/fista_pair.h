@@ -56,26 +56,66 @@ __global__ __launch_bounds__(256, 2) void fista_pair_kernel(FistaArgs a, TapsF<K
   const int pB = liveB ? pB0 : a.P - 1;
 
   double wA[S], wB[S];
-  // y (both problems) and the padding mask live in LDS, not in registers (two problems
-  // per row leave no room).  Each lane re-reads only what it wrote itself, one
-  // ds_read_b64 + ds_read_b32 per sample and iteration on the otherwise idle LDS pipe,
-  // so no barrier is ever needed.  Layout [row of the workgroup][sample][lane of the row].
+  // LDS, per 16-lane row: [S*16] float2 then [S*16] float.  During the solve it holds y
+  // (both problems) and the padding mask, which two problems per row leave no registers
+  // for: each lane re-reads only what it wrote itself (one ds_read_b64 + ds_read_b32 per
+  // sample and iteration, on the otherwise idle LDS pipe).  In the prologue and epilogue
+  // the same space transposes rows between the coalesced global layout (lane = sample mod
+  // 16: every cache line is requested once) and the strip layout of the solver (lane owns
+  // S consecutive samples); with 8 rows in flight per wave, strided per-lane global
+  // accesses overflow the 4 MB L2 and re-fetch lines (measured 4x the bytes).  A row is
+  // only ever touched by its own 16 lanes, i.e. by one wave: LDS operations of a wave
+  // execute in order, so wave-level fences are enough and no workgroup barrier is needed.
   extern __shared__ __attribute__((aligned(16))) char pair_smem[];
-  f2* ly = reinterpret_cast<f2*>(pair_smem) + ((threadIdx.x >> 4) * S * 16 + sub);
-  float* lm = reinterpret_cast<float*>(pair_smem + (size_t)16 * S * 16 * sizeof(f2)) +
-              ((threadIdx.x >> 4) * S * 16 + sub);
+  const int rslot = (threadIdx.x >> 4) * S * 16;
+  f2* ly = reinterpret_cast<f2*>(pair_smem) + (rslot + sub);
+  float* lm = reinterpret_cast<float*>(pair_smem + (size_t)16 * S * 16 * sizeof(f2)) + (rslot + sub);
+  double* stage_d = reinterpret_cast<double*>(reinterpret_cast<f2*>(pair_smem) + rslot);
+  float* stage_f = reinterpret_cast<float*>(pair_smem + (size_t)16 * S * 16 * sizeof(f2)) + rslot;
+  auto lds_sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
   {
     const float* yA = a.y + (int64_t)(pA / a.y_rep) * a.ldy;
     const float* yB = a.y + (int64_t)(pB / a.y_rep) * a.ldy;
     const double* rA = a.w + (int64_t)pA * a.ldw;
     const double* rB = a.w + (int64_t)pB * a.ldw;
+    // w of A, then of B: coalesced read -> LDS (natural order) -> strips
+    auto load_w = [&](const double* row, double* strip) {
+#pragma unroll
+      for (int k = 0; k < S; ++k) {
+        const int i = k * 16 + sub;
+        stage_d[i] = (i < a.N) ? row[i] : 0.0;
+      }
+      lds_sync();
+#pragma unroll
+      for (int j = 0; j < S; ++j) strip[j] = stage_d[base + j];
+      lds_sync();
+    };
+    load_w(rA, wA);
+    load_w(rB, wB);
+    // y of A and B: the float region stages one row at a time, the float2 region gets
+    // the final (A, B) pairs in strip layout
+    float ya[S], yb[S];
+    auto load_y = [&](const float* row, float* strip) {
+#pragma unroll
+      for (int k = 0; k < S; ++k) {
+        const int i = k * 16 + sub;
+        stage_f[i] = (i < a.N) ? row[i] : 0.0f;
+      }
+      lds_sync();
+#pragma unroll
+      for (int j = 0; j < S; ++j) strip[j] = stage_f[base + j];
+      lds_sync();
+    };
+    load_y(yA, ya);
+    load_y(yB, yb);
 #pragma unroll
     for (int j = 0; j < S; ++j) {
-      const bool ok = base + j < a.N;
-      wA[j] = ok ? rA[base + j] : 0.0;
-      wB[j] = ok ? rB[base + j] : 0.0;
-      ly[j * 16] = f2{ok ? yA[base + j] : 0.0f, ok ? yB[base + j] : 0.0f};
-      lm[j * 16] = ok ? 1.0f : 0.0f;
+      ly[j * 16] = f2{ya[j], yb[j]};
+      lm[j * 16] = (base + j < a.N) ? 1.0f : 0.0f;
     }
   }
   const double lbA = a.lbda_vec ? a.lbda_vec[pA] : a.lbda;
@@ -234,15 +274,22 @@ __global__ __launch_bounds__(256, 2) void fista_pair_kernel(FistaArgs a, TapsF<K
     }
   }
 
-  double* oA = a.w + (int64_t)pA * a.ldw;
-  double* oB = a.w + (int64_t)pB * a.ldw;
+  // epilogue: strips -> LDS -> coalesced stores (the y/mask contents are dead now)
+  auto store_w = [&](const double* strip, double* row, bool live) {
+    lds_sync();
 #pragma unroll
-  for (int j = 0; j < S; ++j) {
-    if (base + j < a.N) {
-      if (liveA) oA[base + j] = wA[j];
-      if (liveB) oB[base + j] = wB[j];
+    for (int j = 0; j < S; ++j) stage_d[base + j] = strip[j];
+    lds_sync();
+    if (live) {
+#pragma unroll
+      for (int k = 0; k < S; ++k) {
+        const int i = k * 16 + sub;
+        if (i < a.N) row[i] = stage_d[i];
+      }
     }
-  }
+  };
+  store_w(wA, a.w + (int64_t)pA * a.ldw, liveA);
+  store_w(wB, a.w + (int64_t)pB * a.ldw, liveB);
   if (a.n_done && sub == 0) {
     if (liveA) a.n_done[pA] = a.n_iter;
     if (liveB) a.n_done[pB] = a.n_iter;
