@@ -156,15 +156,19 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
     if constexpr (PP) return even_v[t]; else return taps.even[t];
   };
 
-  // window rule: the last WIND-1 gradient-step points, float64, slot = iteration mod 5
+  // window rule (wind = 6): the criterion is a function of the current u_k, w_{k+1} and of
+  // the last four INCREMENTS delta_i = u_i - u_{i-1} only (see the update below).  u_{k-1}
+  // stays in float64 registers; the increments, small numbers, are stored as float32 in an
+  // LDS ring [slot = i mod 4][sample][lane] (relative accuracy 6e-8 of the increments, i.e.
+  // of the criterion itself).  Each lane reads back only what it wrote: no barrier.
   constexpr int WIND = 6;
-  constexpr int HDEPTH = WIND - 1;
-  double hist[STOP == 2 ? HDEPTH : 1][STOP == 2 ? S : 1];
+  double uprev[STOP == 2 ? S : 1];
+  float* ring = nullptr;
   if constexpr (STOP == 2) {
+    extern __shared__ __attribute__((aligned(16))) char fast_smem[];
+    ring = reinterpret_cast<float*>(fast_smem) + ((threadIdx.x >> 4) * 4 * S * 16 + sub);
 #pragma unroll
-    for (int q = 0; q < HDEPTH; ++q)
-#pragma unroll
-      for (int j = 0; j < S; ++j) hist[q][j] = 0.0;
+    for (int j = 0; j < S; ++j) uprev[j] = 0.0;
   }
 
   bool active = live;                       // per-problem (row-uniform) early-stop state; idle rows never hold a wave
@@ -317,35 +321,33 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
           w[j] = active ? wn : w[j];
         }
       } else {
-        // deconv window rule, wind = 6 (pybold/bold_signal.py:82-95): the stored
-        // iterates are [u_{k-4} .. u_k, w_{k+1}] (each stored w was overwritten in
-        // place by the next gradient step, :65/:72); old = mean of the first three,
-        // new = mean of the last three.  Sums are left unscaled (x3), so is the
-        // 1e-10 floor.  u_k lives in slot k mod 5; the switch makes slots static.
+        // deconv window rule, wind = 6 (pybold/bold_signal.py:82-95): the stored iterates
+        // are [u_{k-4} .. u_k, w_{k+1}] (each stored w was overwritten in place by the next
+        // gradient step, :65/:72); old = mean of the first three, new = mean of the last
+        // three.  With delta_i = u_i - u_{i-1} and e = w_{k+1} - u_k:
+        //   3 (new - old) = delta_{k-3} + 2 delta_{k-2} + 3 delta_{k-1} + 2 delta_k + e
+        //   3 new         = 3 u_k - delta_k + e
+        // (sums left unscaled, so is the 1e-10 floor).
         floor_eps = 3.0e-10;
-        auto crit = [&](auto slc) {
-          constexpr int sl = decltype(slc)::value;
+        const float* r1 = ring + ((it + 3) & 3) * S * 16;    // delta_{k-1}
+        const float* r2 = ring + ((it + 2) & 3) * S * 16;    // delta_{k-2}
+        const float* r3 = ring + ((it + 1) & 3) * S * 16;    // delta_{k-3}
+        float* r0 = ring + (it & 3) * S * 16;                // delta_k goes here
 #pragma unroll
-          for (int j = 0; j < S; ++j) {
-            const double u = fma(nstep, (double)g[j], w[j]);
-            const double d = fmin(fmax(u, -th), th);
-            const double wn = fma(nb1, d, u);
-            const double so = (hist[(sl + 1) % HDEPTH][j] + hist[(sl + 2) % HDEPTH][j]) +
-                              hist[(sl + 3) % HDEPTH][j];
-            const double sn = (hist[(sl + 4) % HDEPTH][j] + u) + wn;
-            const double diff = sn - so;
-            num = fma(diff, diff, num);
-            den = fma(sn, sn, den);
-            hist[sl][j] = u;
-            w[j] = active ? wn : w[j];
-          }
-        };
-        switch (it % HDEPTH) {
-          case 0: crit(std::integral_constant<int, 0>{}); break;
-          case 1: crit(std::integral_constant<int, 1>{}); break;
-          case 2: crit(std::integral_constant<int, 2>{}); break;
-          case 3: crit(std::integral_constant<int, 3>{}); break;
-          default: crit(std::integral_constant<int, 4>{}); break;
+        for (int j = 0; j < S; ++j) {
+          const double u = fma(nstep, (double)g[j], w[j]);
+          const double d = fmin(fmax(u, -th), th);
+          const double wn = fma(nb1, d, u);
+          const float dk = (float)(u - uprev[j]);
+          const float dsum = fmaf(2.0f, dk, fmaf(3.0f, r1[j * 16], fmaf(2.0f, r2[j * 16], r3[j * 16])));
+          const double e = wn - u;
+          const double diff = (double)dsum + e;
+          const double sn = fma(3.0, u, e - (double)dk);
+          num = fma(diff, diff, num);
+          den = fma(sn, sn, den);
+          r0[j * 16] = dk;
+          uprev[j] = u;
+          w[j] = active ? wn : w[j];
         }
       }
       // row all-reduce of the two float64 partial sums

@@ -19,9 +19,10 @@ int launch_fast(const FistaArgs& a, const double* taps, int K, bool with_j, int 
   } else if (stop == PB_STOP_LOOPS) {
     if (with_j) hipLaunchKernelGGL((fista_fast_kernel<S, KT, true, 1>), grid, block, 0, st, a, tp);
     else hipLaunchKernelGGL((fista_fast_kernel<S, KT, false, 1>), grid, block, 0, st, a, tp);
-  } else {   // PB_STOP_WINDOW with wind = 6 (checked by the caller)
-    if (with_j) hipLaunchKernelGGL((fista_fast_kernel<S, KT, true, 2>), grid, block, 0, st, a, tp);
-    else hipLaunchKernelGGL((fista_fast_kernel<S, KT, false, 2>), grid, block, 0, st, a, tp);
+  } else {   // PB_STOP_WINDOW with wind = 6 (checked by the caller): LDS ring of 4 increments
+    const size_t lds = (size_t)16 * 4 * S * 16 * sizeof(float);
+    if (with_j) hipLaunchKernelGGL((fista_fast_kernel<S, KT, true, 2>), grid, block, lds, st, a, tp);
+    else hipLaunchKernelGGL((fista_fast_kernel<S, KT, false, 2>), grid, block, lds, st, a, tp);
   }
   return 0;
 }
