@@ -11,7 +11,8 @@ from pybold_amd.hrf_model import spm_hrf
 hrf = spm_hrf(1.0, t_r=1.0, dur=30.)[0]
 torch.manual_seed(0)
 Y = torch.randn(100000, 300, device="cuda", dtype=torch.float32)
-plan = solver.FistaPlan(Y, hrf, 1.0, 1.0 / 723876.27, 500, force="fast")
+import os
+plan = solver.FistaPlan(Y, hrf, 1.0, 1.0 / 723876.27, 500, force=os.environ.get("PYBOLD_AB_FORCE", "fast1"))
 for _ in range(3): plan.run()
 torch.cuda.synchronize()
 ts = []
