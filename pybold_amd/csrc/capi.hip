@@ -37,7 +37,7 @@ constexpr int LDS_DOUBLES_MAX = 20000;  // 160 KB of LDS per workgroup
 typedef int (*fast_launch_fn)(const pb::FistaArgs&, const double* taps, int K, bool with_j,
                               int stop, hipStream_t);
 typedef int (*fast_launch_pp_fn)(const pb::FistaArgs&, int stop, hipStream_t);
-typedef int (*pair_launch_fn)(const pb::FistaArgs&, const double* taps, int K, hipStream_t);
+typedef int (*pair_launch_fn)(const pb::FistaArgs&, const double* taps, int K, bool with_j, hipStream_t);
 
 struct FastEntry {
   int S, KT;
@@ -53,7 +53,7 @@ namespace pb {
 #define PB_FAST(S, KT)                                                                              \
   extern template int launch_fast<S, KT>(const FistaArgs&, const double*, int, bool, int, hipStream_t); \
   extern template int launch_fast_pp<S, KT>(const FistaArgs&, int, hipStream_t);            \
-  extern template int launch_pair<S, KT>(const FistaArgs&, const double*, int, hipStream_t);
+  extern template int launch_pair<S, KT>(const FistaArgs&, const double*, int, bool, hipStream_t);
 #include "fast_table.inc"
 #undef PB_FAST
 }  // namespace pb
@@ -170,10 +170,12 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
   // (the reference default) on entries small enough to hold them; else LDS kernel
   if (fe && stop_mode == PB_STOP_WINDOW && (wind != 6 || fe->S > 20)) fe = nullptr;
   if (fe) {
-    // plain solve (no cost trace, no stop rule): two problems per DPP row
-    if (fe->fn_pair && !J_dev && stop_mode == PB_STOP_NONE && P >= 2 && !(flags & PB_FLAG_NO_PAIR) &&
-        ((flags & PB_FLAG_FORCE_PAIR) || pair_is_faster(P))) {
-      fe->fn_pair(a, taps_host, K, (hipStream_t)stream);
+    // no stop rule: two problems per DPP row when that form finishes first.  With the
+    // cost trace the pair form spills a few registers and only ties the single-row
+    // kernel (measured 21.5 vs 21.7 ms), so it is used for it only on request.
+    if (fe->fn_pair && stop_mode == PB_STOP_NONE && P >= 2 && !(flags & PB_FLAG_NO_PAIR) &&
+        ((flags & PB_FLAG_FORCE_PAIR) || (!J_dev && pair_is_faster(P)))) {
+      fe->fn_pair(a, taps_host, K, J_dev != nullptr, (hipStream_t)stream);
       return check_launch("fista_pair_kernel");
     }
     fe->fn(a, taps_host, K, J_dev != nullptr, stop_mode, (hipStream_t)stream);

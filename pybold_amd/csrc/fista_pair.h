@@ -9,8 +9,8 @@
 //                 with the tap broadcast from an SGPR (op_sel): no combine, no
 //                 alignment cases, scan chains and offsets are packed adds.
 // Instruction budget per voxel-iteration at S=19, K=30: ~800 against ~905.
-// Used for the plain solve (no cost trace, no stop rule, shared taps); the other
-// modes stay on fista_fast.h.  An odd problem count pads the last row with a copy
+// Used for solves without a stop rule and with shared taps (cost trace optional); the
+// other modes stay on fista_fast.h.  An odd problem count pads the last row with a copy
 // of the last problem (computed, never stored).
 #pragma once
 #include "common.h"
@@ -39,7 +39,7 @@ __device__ __forceinline__ f2 dpp_zero2(f2 v) {
   return f2{dpp_zero<CTRL>(v.x), dpp_zero<CTRL>(v.y)};
 }
 
-template <int S, int KT>
+template <int S, int KT, bool WITH_J = false>
 __global__ __launch_bounds__(256, 2) void fista_pair_kernel(FistaArgs a, TapsF<KT> taps) {
   constexpr int H = KT - 1;
   constexpr int D = (H + S - 1) / S;
@@ -123,17 +123,28 @@ __global__ __launch_bounds__(256, 2) void fista_pair_kernel(FistaArgs a, TapsF<K
   const double thA = lbA * a.step, thB = lbB * a.step;
   const double nstep = -a.step;
 
-  for (int it = 0; it < a.n_iter; ++it) {
+  const float lbfA = (float)lbA, lbfB = (float)lbB;
+  float* JA = WITH_J ? a.J + (int64_t)pA * a.ldj : nullptr;
+  float* JB = WITH_J ? a.J + (int64_t)pB * a.ldj : nullptr;
+  // with WITH_J one more forward pass follows the last iteration to price its iterate
+  for (int it = 0;; ++it) {
+    if (!WITH_J && it >= a.n_iter) break;
     asm volatile("" ::: "memory");          // keep the LDS reads inside the loop
     // This translation unit keeps program order (Makefile: PAIRFLAGS), so loads are
     // placed by hand well ahead of their use: the momentum factor here, y and the mask
     // one output group ahead inside the FIR.
-    const double beta = a.betas[it];
+    const double beta = (it < a.n_iter) ? a.betas[it] : 0.0;
     // ---- z = cumsum(w) for both problems -----------------------------------
     f2 z[S];
+    f2 l1 = f2{0.f, 0.f};                     // ||w||_1 of the iterate this pass starts from
     z[0] = f2{(float)wA[0], (float)wB[0]};
+    if constexpr (WITH_J) l1 = __builtin_elementwise_abs(z[0]);
 #pragma unroll
-    for (int j = 1; j < S; ++j) z[j] = z[j - 1] + f2{(float)wA[j], (float)wB[j]};
+    for (int j = 1; j < S; ++j) {
+      const f2 wj = f2{(float)wA[j], (float)wB[j]};
+      z[j] = z[j - 1] + wj;
+      if constexpr (WITH_J) l1 += __builtin_elementwise_abs(wj);
+    }
     {
       const f2 off = f2{row_from_below<1>(row_prefix_incl(z[S - 1].x)),
                         row_from_below<1>(row_prefix_incl(z[S - 1].y))};
@@ -161,6 +172,7 @@ __global__ __launch_bounds__(256, 2) void fista_pair_kernel(FistaArgs a, TapsF<K
     // independent accumulator chains sit next to each other in program order (a
     // dependent v_pk_fma_f32 straight after its producer costs a wait state).
     f2 r[S];
+    f2 sq = f2{0.f, 0.f};                      // ||r||^2, accumulated as the residual is produced
     f2 ypre[G];                               // -y and mask of the group about to start
     float mpre[G];
 #pragma unroll
@@ -198,8 +210,23 @@ __global__ __launch_bounds__(256, 2) void fista_pair_kernel(FistaArgs a, TapsF<K
         });
       });
 #pragma unroll
-      for (int q = 0; q < gn; ++q) r[j0 + q] = acc[q] * f2{mcur[q], mcur[q]};
+      for (int q = 0; q < gn; ++q) {
+        r[j0 + q] = acc[q] * f2{mcur[q], mcur[q]};
+        if constexpr (WITH_J) sq = __builtin_elementwise_fma(r[j0 + q], r[j0 + q], sq);
+      }
     });
+
+    if constexpr (WITH_J) {
+      if (it > 0) {
+        const float cA = row_allsum(fmaf(0.5f, sq.x, lbfA * l1.x));
+        const float cB = row_allsum(fmaf(0.5f, sq.y, lbfB * l1.y));
+        if (sub == 0) {
+          if (liveA) JA[it - 1] = cA;
+          if (liveB) JB[it - 1] = cB;
+        }
+      }
+      if (it >= a.n_iter) break;
+    }
 
     // ---- window of r: own samples [0, S), halo [S, S+H) from the lanes above ----
     f2 R[S + H];
@@ -297,12 +324,13 @@ __global__ __launch_bounds__(256, 2) void fista_pair_kernel(FistaArgs a, TapsF<K
 }
 
 template <int S, int KT>
-int launch_pair(const FistaArgs& a, const double* taps, int K, hipStream_t st) {
+int launch_pair(const FistaArgs& a, const double* taps, int K, bool with_j, hipStream_t st) {
   const auto tf = make_taps_f<KT>(taps, K);
   const int64_t rows = ((int64_t)a.P + 1) / 2;
   const dim3 grid((unsigned)((rows * 16 + 255) / 256)), block(256);
   const size_t lds = (size_t)16 * S * 16 * (sizeof(f2) + sizeof(float));
-  hipLaunchKernelGGL((fista_pair_kernel<S, KT>), grid, block, lds, st, a, tf);
+  if (with_j) hipLaunchKernelGGL((fista_pair_kernel<S, KT, true>), grid, block, lds, st, a, tf);
+  else hipLaunchKernelGGL((fista_pair_kernel<S, KT, false>), grid, block, lds, st, a, tf);
   return 0;
 }
 

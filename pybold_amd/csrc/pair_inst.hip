@@ -6,6 +6,6 @@
 #endif
 namespace pb {
 #if PB_S <= 20
-template int launch_pair<PB_S, PB_KT>(const FistaArgs&, const double*, int, hipStream_t);
+template int launch_pair<PB_S, PB_KT>(const FistaArgs&, const double*, int, bool, hipStream_t);
 #endif
 }

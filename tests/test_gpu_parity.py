@@ -61,12 +61,16 @@ def test_fista_vs_golden_grid(pa, golden, force):
             assert rel_rows(W, Wo) < EPS
 
 
-@pytest.mark.parametrize("force", ["fast", "generic"])
+@pytest.mark.parametrize("force", ["fast1", "fast2", "generic"])
 def test_outputs_and_cost_trace(pa, golden, force):
     _, solver = pa
     g = golden("case1")
     y, hrf, lip = g["y"], g["hrf"], float(g["lipschitz"])
-    W, J, _ = solver.fista_solve(dev32(y[None]), hrf, 1.0, 1.0 / lip, 500, want_J=True, force=force)
+    Yb = np.stack([y, 0.5 * y, y])           # voxel 0 and 2 = the golden case (A and B slots)
+    W, J, _ = solver.fista_solve(dev32(Yb), hrf, 1.0, 1.0 / lip, 500, want_J=True, force=force)
+    Jall = J.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(Jall[2] / Jall[2][0], g["J"], rtol=2e-5)
+    W, J = W[:1].contiguous(), J[:1]
     X, Z = solver.fista_outputs(W, hrf)
     assert rel_rows(W.cpu().numpy(), g["diff_z"]) < EPS
     assert rel_rows(Z.cpu().numpy(), g["z"]) < EPS
