@@ -422,6 +422,29 @@ def test_inputs_are_not_modified(pa, golden):
         assert rel_rows(W[s], g["dz_s%d_l1_n10" % s]) < EPS
 
 
+@pytest.mark.parametrize("force", ["fast1", "fast2", "generic"])
+def test_bad_voxels_do_not_contaminate_neighbours(pa, golden, force):
+    """Voxels are independent problems: NaN / Inf / huge values in one of them must
+    leave every other voxel of the wave, row pair and workgroup bit-identical."""
+    _, solver = pa
+    g, Y, hrf, lip = grid_inputs(golden)
+    Yb = np.tile(Y, (5, 1)).astype(np.float32)            # 20 voxels
+    clean, _, _ = solver.fista_solve(dev32(Yb), hrf, 1.0, 1.0 / lip, 30, force=force)
+    bad = Yb.copy()
+    bad[3, 17] = np.nan
+    bad[8, :] = np.inf
+    bad[13, :] *= 1e30
+    W, _, _ = solver.fista_solve(dev32(bad), hrf, 1.0, 1.0 / lip, 30, force=force)
+    keep = [i for i in range(20) if i not in (3, 8, 13)]
+    assert torch.equal(W[keep], clean[keep])
+    assert bool(torch.isnan(W[3]).any()) and not bool(torch.isfinite(W[8]).all())
+    # scale equivariance at extreme amplitudes (float32 range of y, float64 iterate)
+    for scale in (1e-20, 1e12):
+        Ws, _, _ = solver.fista_solve(dev32(Yb * np.float32(scale)), hrf, scale, 1.0 / lip, 30, force=force)
+        rel = ((Ws / scale - clean).norm(dim=1) / clean.norm(dim=1)).max()
+        assert float(rel) < 1e-5, (scale, float(rel))
+
+
 def test_errors_are_loud(pa, golden):
     _, solver = pa
     from pybold_amd._lib import PyboldHipError
