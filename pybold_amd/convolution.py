@@ -8,6 +8,7 @@ hot path's sizes they equal the causal truncated convolution implemented by
 the kernels.
 """
 import numpy as np
+import torch
 
 
 def toeplitz_from_kernel(k, dim_in, dim_out=None):
@@ -41,3 +42,31 @@ def kernel_from_toeplitz(H):
         raise ValueError("H is not a causal Toeplitz (convolution) matrix; the "
                          "matrix-free GPU solver cannot represent it")
     return taps
+
+
+def _rows_on_device(x):
+    from . import solver
+    a = np.asarray(x, dtype=np.float64)
+    one_d = a.ndim == 1
+    t = torch.from_numpy(np.ascontiguousarray(a.reshape(1, -1) if one_d else a)).to(solver.device())
+    return t, one_d
+
+
+def simple_convolve(k, x, dim_out=None):
+    """``out[i] = sum_m k[m] x[i - m]`` truncated to ``dim_out`` samples -- the
+    loop-form definition of pybold/convolution.py:135-164 (== ``toeplitz_from_kernel(k,
+    len(x), dim_out) @ x``), evaluated by the GPU Toeplitz-product kernel.  1-D ``x``
+    like the reference, or a 2-D batch of rows."""
+    from . import solver
+    t, one_d = _rows_on_device(x)
+    out = solver.conv(t, k, dim_out=t.shape[1] if dim_out is None else int(dim_out)).cpu().numpy()
+    return out[0] if one_d else out
+
+
+def simple_retro_convolve(k, x, dim_out=None):
+    """Adjoint form ``out[j] = sum_m k[m] x[j + m]`` (pybold/convolution.py:167-196,
+    == ``toeplitz_from_kernel(k, dim_out, len(x)).T @ x``)."""
+    from . import solver
+    t, one_d = _rows_on_device(x)
+    out = solver.corr(t, k, dim_in=t.shape[1] if dim_out is None else int(dim_out)).cpu().numpy()
+    return out[0] if one_d else out

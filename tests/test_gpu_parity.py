@@ -287,6 +287,25 @@ def test_operator_surface_goldens(pa, golden):
     np.testing.assert_allclose(out, g["rect_T"].T.dot(r), rtol=1e-12, atol=1e-12)
 
 
+def test_simple_convolve_definitions(pa, golden):
+    """simple_convolve / simple_retro_convolve against the reference's loop-form values
+    (the ground truth of pybold/tests/test_convolution.py) incl. the rectangular case."""
+    pybold_amd, _ = pa
+    g = golden("operators")
+    for tag in "abcde":
+        k, x = g[tag + "_k"], g[tag + "_x"]
+        np.testing.assert_allclose(pybold_amd.simple_convolve(k, x), g[tag + "_conv"],
+                                   rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(pybold_amd.simple_retro_convolve(k, x), g[tag + "_retro"],
+                                   rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(
+        pybold_amd.simple_convolve(g["rect_sig"], g["rect_k"], dim_out=len(g["rect_sig"])),
+        g["rect_conv"], rtol=1e-12, atol=1e-12)
+    X = np.stack([g["a_x"], -g["a_x"]])
+    out = pybold_amd.simple_convolve(g["a_k"], X)
+    np.testing.assert_allclose(out[1], -g["a_conv"], rtol=1e-12, atol=1e-12)
+
+
 def test_operator_identities_like_reference_tests(pa):
     """toeplitz @ x == conv, toeplitz.T @ x == retro-conv, adjointness
     (pybold/tests/test_convolution.py:29-36,95-102; test_linear.py:12-28)."""
