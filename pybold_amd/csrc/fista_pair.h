@@ -39,7 +39,9 @@ __device__ __forceinline__ f2 dpp_zero2(f2 v) {
   return f2{dpp_zero<CTRL>(v.x), dpp_zero<CTRL>(v.y)};
 }
 
-template <int S, int KT, bool WITH_J = false>
+// SKIP0: tap 0 is exactly zero (true of every SPM HRF: the gamma densities vanish at
+// t = 0, pybold/hrf_model.py:25-31) and is left out of both FIRs at compile time.
+template <int S, int KT, bool WITH_J = false, bool SKIP0 = false>
 __global__ __launch_bounds__(256, 2) void fista_pair_kernel(FistaArgs a, TapsF<KT> taps) {
   constexpr int H = KT - 1;
   constexpr int D = (H + S - 1) / S;
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void fista_pair_kernel(FistaArgs a, TapsF<K
           (void)dummy;
         }
       }
-      static_for<0, KT>([&](auto mc) {
+      static_for<(SKIP0 ? 1 : 0), KT>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
         const f2 tp = taps.pr[m / 2];
         const f2 tb = (m % 2 == 0) ? tp.xx : tp.yy;
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void fista_pair_kernel(FistaArgs a, TapsF<K
       f2 acc[gn];
 #pragma unroll
       for (int q = 0; q < gn; ++q) acc[q] = f2{0.f, 0.f};
-      static_for<0, KT>([&](auto mc) {
+      static_for<(SKIP0 ? 1 : 0), KT>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
         const f2 tp = taps.pr[m / 2];
         const f2 tb = (m % 2 == 0) ? tp.xx : tp.yy;
@@ -329,8 +331,10 @@ int launch_pair(const FistaArgs& a, const double* taps, int K, bool with_j, hipS
   const int64_t rows = ((int64_t)a.P + 1) / 2;
   const dim3 grid((unsigned)((rows * 16 + 255) / 256)), block(256);
   const size_t lds = (size_t)16 * S * 16 * (sizeof(f2) + sizeof(float));
-  if (with_j) hipLaunchKernelGGL((fista_pair_kernel<S, KT, true>), grid, block, lds, st, a, tf);
-  else hipLaunchKernelGGL((fista_pair_kernel<S, KT, false>), grid, block, lds, st, a, tf);
+  const bool skip0 = KT > 1 && tf.pr[0].x == 0.0f;      // leading tap exactly zero
+  if (with_j) hipLaunchKernelGGL((fista_pair_kernel<S, KT, true, false>), grid, block, lds, st, a, tf);
+  else if (skip0) hipLaunchKernelGGL((fista_pair_kernel<S, KT, false, true>), grid, block, lds, st, a, tf);
+  else hipLaunchKernelGGL((fista_pair_kernel<S, KT, false, false>), grid, block, lds, st, a, tf);
   return 0;
 }
 
