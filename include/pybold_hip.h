@@ -56,13 +56,15 @@ int pb_version(void);
 /* Text of the last error on the calling thread ("" if none). */
 const char* pb_last_error(void);
 
-/* 1 if a register-resident specialisation exists for (N scans, K taps),
- * else 0 (the generic kernel is used).  Host-only query. */
+/* 1 if a register-resident specialisation exists for (N scans, K taps) -- for plain
+ * solves and the cost trace; stop rules need N <= 608 -- else 0 (the generic kernel is
+ * used).  Host-only query. */
 int pb_fista_has_fast_path(int N, int K);
 
 /* Which kernel pb_fista_solve will run for this call shape (no flags): 0 = generic
  * LDS kernel, 1 = register-resident, one problem per 16-lane row (fista_fast_kernel),
- * 2 = register-resident, two problems per row (fista_pair_kernel).  Host-only query. */
+ * 2 = register-resident, two problems per row (fista_pair_kernel), 3 = register-resident,
+ * one problem per wave (long series).  Host-only query. */
 int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mode, int wind);
 
 /*

@@ -60,6 +60,36 @@ namespace pb {
 
 namespace {
 
+}  // namespace
+namespace pb {
+#define PB_WIDE(S, KT) \
+  extern template int launch_wide<S, KT>(const FistaArgs&, const double*, int, bool, hipStream_t);
+#include "wide_table.inc"
+#undef PB_WIDE
+}  // namespace pb
+namespace {
+
+typedef int (*wide_launch_fn)(const pb::FistaArgs&, const double* taps, int K, bool with_j, hipStream_t);
+struct WideEntry {
+  int S, KT;
+  wide_launch_fn fn;
+};
+#define PB_WIDE(S, KT) {S, KT, &pb::launch_wide<S, KT>},
+const WideEntry kWide[] = {
+#include "wide_table.inc"
+};
+#undef PB_WIDE
+
+const WideEntry* pick_wide(int N, int K) {
+  const WideEntry* best = nullptr;
+  const int s_need = (N + 63) / 64;
+  for (const WideEntry& e : kWide) {
+    if (e.S < s_need || e.KT < K) continue;
+    if (!best || (int64_t)e.S * e.KT < (int64_t)best->S * best->KT) best = &e;
+  }
+  return best;
+}
+
 template <int S, int KT>
 constexpr pair_launch_fn pair_or_null() {
   if constexpr (S <= 20) return &pb::launch_pair<S, KT>; else return nullptr;
@@ -126,13 +156,15 @@ int pb_version(void) { return 100; }
 
 const char* pb_last_error(void) { return g_err; }
 
-int pb_fista_has_fast_path(int N, int K) { return (N >= 1 && K >= 1 && pick_fast(N, K)) ? 1 : 0; }
+int pb_fista_has_fast_path(int N, int K) {
+  return (N >= 1 && K >= 1 && (pick_fast(N, K) || pick_wide(N, K))) ? 1 : 0;
+}
 
 int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mode, int wind) {
   if (N < 1 || K < 1 || P < 1) return 0;
   const FastEntry* fe = pick_fast(N, K);
   if (fe && stop_mode == PB_STOP_WINDOW && (wind != 6 || fe->S > 20)) fe = nullptr;
-  if (!fe) return 0;
+  if (!fe) return (stop_mode == PB_STOP_NONE && pick_wide(N, K)) ? 3 : 0;
   if (fe->fn_pair && !with_cost_trace && stop_mode == PB_STOP_NONE && P >= 2 && pair_is_faster(P))
     return 2;
   return 1;
@@ -180,6 +212,13 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
     }
     fe->fn(a, taps_host, K, J_dev != nullptr, stop_mode, (hipStream_t)stream);
     return check_launch("fista_fast_kernel");
+  }
+  // long series: one problem per wave (no stop rule in this form)
+  if (!(flags & PB_FLAG_FORCE_GENERIC) && stop_mode == PB_STOP_NONE) {
+    if (const WideEntry* we = pick_wide(N, K)) {
+      we->fn(a, taps_host, K, J_dev != nullptr, (hipStream_t)stream);
+      return check_launch("fista_fast_kernel(wide)");
+    }
   }
   if (flags & PB_FLAG_FORCE_FAST)
     return fail(PB_ERR_INVALID, "pb_fista_solve: no register-resident kernel for N=%d K=%d stop=%d",

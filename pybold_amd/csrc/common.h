@@ -70,4 +70,77 @@ __device__ __forceinline__ float row_suffix_incl(float t) {
   return t;
 }
 
+// ---- segments of LPV lanes (16 = one DPP row, 64 = the whole wave) ---------------
+constexpr int DPP_WAVE_SHL1 = 0x130;   // lane i reads lane i+1 of the wave (0 past the end)
+constexpr int DPP_WAVE_SHR1 = 0x138;   // lane i reads lane i-1 of the wave (0 before lane 0)
+constexpr int DPP_ROW_BCAST15 = 0x142; // lane 15 of each row -> every lane of the next row
+constexpr int DPP_ROW_BCAST31 = 0x143; // lane 31 -> every lane of rows 2 and 3
+
+// value of lane (i - d) of the same segment, 0 outside it
+template <int LPV, int d>
+__device__ __forceinline__ float seg_from_below(float v) {
+  if constexpr (LPV == 16) {
+    return row_from_below<d>(v);
+  } else {
+    static_assert(LPV == 64, "segments are one DPP row or one wave");
+#pragma unroll
+    for (int k = 0; k < d; ++k) v = dpp_zero<DPP_WAVE_SHR1>(v);
+    return v;
+  }
+}
+template <int LPV, int d>
+__device__ __forceinline__ float seg_from_above(float v) {
+  if constexpr (LPV == 16) {
+    return row_from_above<d>(v);
+  } else {
+#pragma unroll
+    for (int k = 0; k < d; ++k) v = dpp_zero<DPP_WAVE_SHL1>(v);
+    return v;
+  }
+}
+
+// inclusive prefix sum over the lanes of a segment
+template <int LPV>
+__device__ __forceinline__ float seg_prefix_incl(float t) {
+  t = row_prefix_incl(t);
+  if constexpr (LPV == 64) {
+    // rows 1 and 3 add the total of the row before them, then rows 2 and 3 the total of
+    // the first half (disabled rows receive `old` = 0)
+    t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+             0, __builtin_bit_cast(int, t), DPP_ROW_BCAST15, 0xa, 0xf, false));
+    t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+             0, __builtin_bit_cast(int, t), DPP_ROW_BCAST31, 0xc, 0xf, false));
+  }
+  return t;
+}
+// sum of the lanes strictly below / strictly above this one in its segment
+template <int LPV>
+__device__ __forceinline__ float seg_sum_below(float tot) {
+  return seg_from_below<LPV, 1>(seg_prefix_incl<LPV>(tot));
+}
+template <int LPV>
+__device__ __forceinline__ float seg_sum_above(float tot) {
+  if constexpr (LPV == 16) {
+    return row_from_above<1>(row_suffix_incl(tot));
+  } else {
+    const float incl = seg_prefix_incl<64>(tot);
+    const float total = __builtin_bit_cast(
+        float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, incl), 63));
+    return total - incl;
+  }
+}
+// sum over the segment, result in every lane
+template <int LPV>
+__device__ __forceinline__ float seg_allsum(float v) {
+  v = row_allsum(v);
+  if constexpr (LPV == 64) {
+    const int b = __builtin_bit_cast(int, v);
+    v = (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) +
+         __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))) +
+        (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) +
+         __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
+  }
+  return v;
+}
+
 }  // namespace pb

@@ -91,8 +91,12 @@ struct Window {
 
 // PP = per-problem taps and step (blind deconvolution with one HRF per voxel):
 // both tap-pair copies are then loaded from a.taps_pp into VGPRs.
-template <int S, int KT, bool WITH_J, int STOP, bool PP = false>
+// LPV = lanes per problem: 16 (one DPP row, four problems per wave; series up to 16*S
+// scans) or 64 (one problem per wave for long series, up to 64*S scans: halo through
+// wave_shr/shl:1 chains, scans with the row_bcast steps; plain solves and cost trace only).
+template <int S, int KT, bool WITH_J, int STOP, bool PP = false, int LPV = 16>
 __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<KT> taps) {
+  static_assert(LPV == 16 || (LPV == 64 && STOP == 0), "stop rules exist for LPV = 16 only");
   constexpr int H = KT - 1;                 // halo length
   constexpr int D = (H + S - 1) / S;        // neighbour lanes that contribute halo
   constexpr int NPAIR = (H + S + 2) / 2;    // window pairs (>= H+S+1 elements)
@@ -100,8 +104,8 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
   using TP = TapPairs<KT>;
 
   const int gid = blockIdx.x * 256 + threadIdx.x;
-  const int sub = threadIdx.x & 15;         // lane within the 16-lane row
-  const int prob = gid >> 4;
+  const int sub = threadIdx.x & (LPV - 1);  // lane within the problem's segment
+  const int prob = gid / LPV;
   const bool live = prob < a.P;
   const int p = live ? prob : a.P - 1;
   const int base = sub * S;
@@ -166,6 +170,7 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
   float* ring = nullptr;
   if constexpr (STOP == 2) {
     extern __shared__ __attribute__((aligned(16))) char fast_smem[];
+    static_assert(LPV == 16 || STOP != 2, "window rule: LPV = 16");
     ring = reinterpret_cast<float*>(fast_smem) + ((threadIdx.x >> 4) * 4 * S * 16 + sub);
 #pragma unroll
     for (int j = 0; j < S; ++j) uprev[j] = 0.0;
@@ -186,8 +191,7 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
 #pragma unroll
     for (int j = 1; j < S; ++j) z[j] = z[j - 1] + (float)w[j];
     {
-      const float incl = row_prefix_incl(z[S - 1]);
-      const float off = row_from_below<1>(incl);
+      const float off = seg_sum_below<LPV>(z[S - 1]);
 #pragma unroll
       for (int j = 0; j < S; ++j) z[j] += off;
     }
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
       static_for<0, S>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         constexpr int e = H - d * S + j;
-        if constexpr (e >= 0) Z.template set<e>(row_from_below<d>(z[j]));
+        if constexpr (e >= 0) Z.template set<e>(seg_from_below<LPV, d>(z[j]));
       });
     });
 
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
           sq = fmaf(r[j], r[j], sq);
           l1 += fabsf((float)w[j]);
         }
-        const float cost = row_allsum(fmaf(0.5f, sq, lbf * l1));
+        const float cost = seg_allsum<LPV>(fmaf(0.5f, sq, lbf * l1));
         if (live && sub == 0 && (STOP == 0 || it <= done)) Jrow[it - 1] = cost;
       }
       if (it >= n_stop) break;
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
       static_for<0, S>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         constexpr int e = d * S + j;
-        if constexpr (e < S + H) R.template set<e>(row_from_above<d>(r[j]));
+        if constexpr (e < S + H) R.template set<e>(seg_from_above<LPV, d>(r[j]));
       });
     });
 
@@ -284,8 +288,7 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
 #pragma unroll
     for (int j = S - 2; j >= 0; --j) g[j] += g[j + 1];
     {
-      const float incl = row_suffix_incl(g[0]);
-      const float off = row_from_above<1>(incl);
+      const float off = seg_sum_above<LPV>(g[0]);
 #pragma unroll
       for (int j = 0; j < S; ++j) g[j] += off;
     }

@@ -27,6 +27,16 @@ int launch_fast(const FistaArgs& a, const double* taps, int K, bool with_j, int 
   return 0;
 }
 
+// one problem per wave (long series): plain solve or cost trace
+template <int S, int KT>
+int launch_wide(const FistaArgs& a, const double* taps, int K, bool with_j, hipStream_t st) {
+  const auto tp = make_tap_pairs<KT>(taps, K);
+  const dim3 grid((unsigned)(((int64_t)a.P * 64 + 255) / 256)), block(256);
+  if (with_j) hipLaunchKernelGGL((fista_fast_kernel<S, KT, true, 0, false, 64>), grid, block, 0, st, a, tp);
+  else hipLaunchKernelGGL((fista_fast_kernel<S, KT, false, 0, false, 64>), grid, block, 0, st, a, tp);
+  return 0;
+}
+
 // per-problem taps/step variant (a.taps_pp, a.step_vec set); no cost trace
 template <int S, int KT>
 int launch_fast_pp(const FistaArgs& a, int stop, hipStream_t st) {

@@ -85,7 +85,8 @@ def has_fast_path(n_scans, n_taps):
 
 
 KERNEL_NAMES = {0: "fista_generic_kernel (LDS)", 1: "fista_fast_kernel (register-resident)",
-                2: "fista_pair_kernel (register-resident, two problems per row)"}
+                2: "fista_pair_kernel (register-resident, two problems per row)",
+                3: "fista_fast_kernel (register-resident, one problem per wave)"}
 
 
 def which_kernel(n_scans, n_taps, n_problems, want_J=False, stop=None, wind=6):

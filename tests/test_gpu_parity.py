@@ -125,6 +125,32 @@ def test_edge_shapes_fast_and_generic_agree_with_oracle(pa, N, K):
         assert err < EPS, (force, N, K, err)
 
 
+@pytest.mark.parametrize("N,K", [(609, 30), (700, 30), (1200, 28), (1216, 30), (1217, 32), (2000, 5),
+                                 (2432, 32), (768, 32), (650, 1)])
+def test_long_series_one_problem_per_wave(pa, N, K):
+    """Series longer than 608 scans (e.g. HCP runs of 1 200 frames): the 64-lane form of the
+    register-resident kernel (wave_shr/shl:1 halo chains, row_bcast scans) vs the oracle
+    and vs the generic kernel, plain and with the cost trace."""
+    _, solver = pa
+    assert solver.has_fast_path(N, K)
+    assert "one problem per wave" in solver.which_kernel(N, K, 7)
+    rng = np.random.RandomState(N + K)
+    hrf = rng.randn(K) * 0.3
+    Y = rng.randn(7, N)
+    Y32 = Y.astype(np.float32).astype(np.float64)
+    A = orc.toeplitz_from_kernel(hrf, N, N).dot(np.tril(np.ones((N, N))))
+    lip = 1.05 * np.linalg.norm(A, 2) ** 2
+    lam = 0.05 * (0.5 + rng.rand(7))
+    ref = orc.fista_batch(Y32, hrf, lam, 1.0 / lip, 30)
+    W, J, n_done = solver.fista_solve(dev32(Y), hrf, lam, 1.0 / lip, 30, want_J=True, force="fast")
+    assert np.abs(W.cpu().numpy() - ref).max() / np.abs(ref).max() < EPS
+    assert (n_done.cpu().numpy() == 30).all()
+    Wg, Jg, _ = solver.fista_solve(dev32(Y), hrf, lam, 1.0 / lip, 30, want_J=True, force="generic")
+    np.testing.assert_allclose(J.cpu().numpy(), Jg.cpu().numpy(), rtol=2e-5)
+    W2, _, _ = solver.fista_solve(dev32(Y), hrf, lam, 1.0 / lip, 30, force="fast")
+    assert np.abs(W2.cpu().numpy() - ref).max() / np.abs(ref).max() < EPS
+
+
 def test_lambda_zero_and_huge(pa, golden):
     """lambda = 0 (no prox) and a lambda that thresholds everything: because the
     momentum uses the gradient-step point the iterate is then
