@@ -56,9 +56,8 @@ int pb_version(void);
 /* Text of the last error on the calling thread ("" if none). */
 const char* pb_last_error(void);
 
-/* 1 if a register-resident specialisation exists for (N scans, K taps) -- for plain
- * solves and the cost trace; stop rules need N <= 608 -- else 0 (the generic kernel is
- * used).  Host-only query. */
+/* 1 if a register-resident specialisation exists for (N scans, K taps), else 0 (the
+ * generic kernel is used).  Host-only query. */
 int pb_fista_has_fast_path(int N, int K);
 
 /* Which kernel pb_fista_solve will run for this call shape (no flags): 0 = generic

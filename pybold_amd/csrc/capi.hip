@@ -63,13 +63,14 @@ namespace {
 }  // namespace
 namespace pb {
 #define PB_WIDE(S, KT) \
-  extern template int launch_wide<S, KT>(const FistaArgs&, const double*, int, bool, hipStream_t);
+  extern template int launch_wide<S, KT>(const FistaArgs&, const double*, int, bool, int, hipStream_t);
 #include "wide_table.inc"
 #undef PB_WIDE
 }  // namespace pb
 namespace {
 
-typedef int (*wide_launch_fn)(const pb::FistaArgs&, const double* taps, int K, bool with_j, hipStream_t);
+typedef int (*wide_launch_fn)(const pb::FistaArgs&, const double* taps, int K, bool with_j, int stop,
+                              hipStream_t);
 struct WideEntry {
   int S, KT;
   wide_launch_fn fn;
@@ -164,7 +165,11 @@ int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mod
   if (N < 1 || K < 1 || P < 1) return 0;
   const FastEntry* fe = pick_fast(N, K);
   if (fe && stop_mode == PB_STOP_WINDOW && (wind != 6 || fe->S > 20)) fe = nullptr;
-  if (!fe) return (stop_mode == PB_STOP_NONE && pick_wide(N, K)) ? 3 : 0;
+  if (!fe) {
+    const WideEntry* we = pick_wide(N, K);
+    if (we && stop_mode == PB_STOP_WINDOW && (wind != 6 || we->S > 20)) we = nullptr;
+    return we ? 3 : 0;
+  }
   if (fe->fn_pair && !with_cost_trace && stop_mode == PB_STOP_NONE && P >= 2 && pair_is_faster(P))
     return 2;
   return 1;
@@ -213,10 +218,12 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
     fe->fn(a, taps_host, K, J_dev != nullptr, stop_mode, (hipStream_t)stream);
     return check_launch("fista_fast_kernel");
   }
-  // long series: one problem per wave (no stop rule in this form)
-  if (!(flags & PB_FLAG_FORCE_GENERIC) && stop_mode == PB_STOP_NONE) {
-    if (const WideEntry* we = pick_wide(N, K)) {
-      we->fn(a, taps_host, K, J_dev != nullptr, (hipStream_t)stream);
+  // long series: one problem per wave (window rule: wind = 6 and S <= 20, as above)
+  if (!(flags & PB_FLAG_FORCE_GENERIC)) {
+    const WideEntry* we = pick_wide(N, K);
+    if (we && stop_mode == PB_STOP_WINDOW && (wind != 6 || we->S > 20)) we = nullptr;
+    if (we) {
+      we->fn(a, taps_host, K, J_dev != nullptr, stop_mode, (hipStream_t)stream);
       return check_launch("fista_fast_kernel(wide)");
     }
   }

@@ -143,4 +143,26 @@ __device__ __forceinline__ float seg_allsum(float v) {
   return v;
 }
 
+// float64 sum over the segment, result in every lane (two 32-bit DPP rotations per step)
+template <int LPV>
+__device__ __forceinline__ double seg_allsum_f64(double v) {
+  static_for<0, 4>([&](auto sc) {
+    constexpr int sh = 8 >> decltype(sc)::value;
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, DPP_ROW_ROR + sh, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), DPP_ROW_ROR + sh, 0xf, 0xf, true);
+    v += __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+  });
+  if constexpr (LPV == 64) {
+    const long long b = __builtin_bit_cast(long long, v);
+    auto lane = [&](int l) {
+      const int lo = __builtin_amdgcn_readlane((int)b, l);
+      const int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+      return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+    };
+    v = (lane(0) + lane(16)) + (lane(32) + lane(48));
+  }
+  return v;
+}
+
 }  // namespace pb

@@ -93,10 +93,10 @@ struct Window {
 // both tap-pair copies are then loaded from a.taps_pp into VGPRs.
 // LPV = lanes per problem: 16 (one DPP row, four problems per wave; series up to 16*S
 // scans) or 64 (one problem per wave for long series, up to 64*S scans: halo through
-// wave_shr/shl:1 chains, scans with the row_bcast steps; plain solves and cost trace only).
+// wave_shr/shl:1 chains, scans with the row_bcast steps).
 template <int S, int KT, bool WITH_J, int STOP, bool PP = false, int LPV = 16>
 __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<KT> taps) {
-  static_assert(LPV == 16 || (LPV == 64 && STOP == 0), "stop rules exist for LPV = 16 only");
+  static_assert(LPV == 16 || LPV == 64, "a problem occupies one DPP row or one wave");
   constexpr int H = KT - 1;                 // halo length
   constexpr int D = (H + S - 1) / S;        // neighbour lanes that contribute halo
   constexpr int NPAIR = (H + S + 2) / 2;    // window pairs (>= H+S+1 elements)
@@ -170,8 +170,7 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
   float* ring = nullptr;
   if constexpr (STOP == 2) {
     extern __shared__ __attribute__((aligned(16))) char fast_smem[];
-    static_assert(LPV == 16 || STOP != 2, "window rule: LPV = 16");
-    ring = reinterpret_cast<float*>(fast_smem) + ((threadIdx.x >> 4) * 4 * S * 16 + sub);
+    ring = reinterpret_cast<float*>(fast_smem) + ((threadIdx.x / LPV) * 4 * S * LPV + sub);
 #pragma unroll
     for (int j = 0; j < S; ++j) uprev[j] = 0.0;
   }
@@ -332,39 +331,29 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
         //   3 new         = 3 u_k - delta_k + e
         // (sums left unscaled, so is the 1e-10 floor).
         floor_eps = 3.0e-10;
-        const float* r1 = ring + ((it + 3) & 3) * S * 16;    // delta_{k-1}
-        const float* r2 = ring + ((it + 2) & 3) * S * 16;    // delta_{k-2}
-        const float* r3 = ring + ((it + 1) & 3) * S * 16;    // delta_{k-3}
-        float* r0 = ring + (it & 3) * S * 16;                // delta_k goes here
+        const float* r1 = ring + ((it + 3) & 3) * S * LPV;   // delta_{k-1}
+        const float* r2 = ring + ((it + 2) & 3) * S * LPV;   // delta_{k-2}
+        const float* r3 = ring + ((it + 1) & 3) * S * LPV;   // delta_{k-3}
+        float* r0 = ring + (it & 3) * S * LPV;               // delta_k goes here
 #pragma unroll
         for (int j = 0; j < S; ++j) {
           const double u = fma(nstep, (double)g[j], w[j]);
           const double d = fmin(fmax(u, -th), th);
           const double wn = fma(nb1, d, u);
           const float dk = (float)(u - uprev[j]);
-          const float dsum = fmaf(2.0f, dk, fmaf(3.0f, r1[j * 16], fmaf(2.0f, r2[j * 16], r3[j * 16])));
+          const float dsum = fmaf(2.0f, dk, fmaf(3.0f, r1[j * LPV], fmaf(2.0f, r2[j * LPV], r3[j * LPV])));
           const double e = wn - u;
           const double diff = (double)dsum + e;
           const double sn = fma(3.0, u, e - (double)dk);
           num = fma(diff, diff, num);
           den = fma(sn, sn, den);
-          r0[j * 16] = dk;
+          r0[j * LPV] = dk;
           uprev[j] = u;
           w[j] = active ? wn : w[j];
         }
       }
-      // row all-reduce of the two float64 partial sums
-      static_for<0, 4>([&](auto sc) {
-        constexpr int sh = 8 >> decltype(sc)::value;
-        auto rot = [&](double v) {
-          const long long b = __builtin_bit_cast(long long, v);
-          const int lo = __builtin_amdgcn_update_dpp(0, (int)b, DPP_ROW_ROR + sh, 0xf, 0xf, true);
-          const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), DPP_ROW_ROR + sh, 0xf, 0xf, true);
-          return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
-        };
-        num += rot(num);
-        den += rot(den);
-      });
+      num = seg_allsum_f64<LPV>(num);
+      den = seg_allsum_f64<LPV>(den);
       if (active) {
         done = it + 1;
         const int first_test = (STOP == 1) ? 3 : WIND + 1;

@@ -27,13 +27,24 @@ int launch_fast(const FistaArgs& a, const double* taps, int K, bool with_j, int 
   return 0;
 }
 
-// one problem per wave (long series): plain solve or cost trace
+// one problem per wave (long series)
 template <int S, int KT>
-int launch_wide(const FistaArgs& a, const double* taps, int K, bool with_j, hipStream_t st) {
+int launch_wide(const FistaArgs& a, const double* taps, int K, bool with_j, int stop, hipStream_t st) {
   const auto tp = make_tap_pairs<KT>(taps, K);
   const dim3 grid((unsigned)(((int64_t)a.P * 64 + 255) / 256)), block(256);
-  if (with_j) hipLaunchKernelGGL((fista_fast_kernel<S, KT, true, 0, false, 64>), grid, block, 0, st, a, tp);
-  else hipLaunchKernelGGL((fista_fast_kernel<S, KT, false, 0, false, 64>), grid, block, 0, st, a, tp);
+  if (stop == PB_STOP_NONE) {
+    if (with_j) hipLaunchKernelGGL((fista_fast_kernel<S, KT, true, 0, false, 64>), grid, block, 0, st, a, tp);
+    else hipLaunchKernelGGL((fista_fast_kernel<S, KT, false, 0, false, 64>), grid, block, 0, st, a, tp);
+  } else if (stop == PB_STOP_LOOPS) {
+    if (with_j) hipLaunchKernelGGL((fista_fast_kernel<S, KT, true, 1, false, 64>), grid, block, 0, st, a, tp);
+    else hipLaunchKernelGGL((fista_fast_kernel<S, KT, false, 1, false, 64>), grid, block, 0, st, a, tp);
+  } else {   // PB_STOP_WINDOW, wind = 6 and S <= 20 (checked by the caller)
+    if constexpr (S <= 20) {
+      const size_t lds = (size_t)4 * 4 * S * 64 * sizeof(float);
+      if (with_j) hipLaunchKernelGGL((fista_fast_kernel<S, KT, true, 2, false, 64>), grid, block, lds, st, a, tp);
+      else hipLaunchKernelGGL((fista_fast_kernel<S, KT, false, 2, false, 64>), grid, block, lds, st, a, tp);
+    }
+  }
   return 0;
 }
 

@@ -5,5 +5,5 @@
 #error "compile with -DPB_S=<samples per lane> -DPB_KT=<taps>"
 #endif
 namespace pb {
-template int launch_wide<PB_S, PB_KT>(const FistaArgs&, const double*, int, bool, hipStream_t);
+template int launch_wide<PB_S, PB_KT>(const FistaArgs&, const double*, int, bool, int, hipStream_t);
 }

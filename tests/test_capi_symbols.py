@@ -43,7 +43,9 @@ def test_version_and_dispatch_table(lib):
     assert lib.pb_fista_has_fast_path(1200, 28) == 1    # HCP-length runs: one problem per wave
     assert lib.pb_fista_which_kernel(1200, 28, 5000, 0, 0, 6) == 3
     assert lib.pb_fista_which_kernel(1200, 28, 5000, 1, 0, 6) == 3
-    assert lib.pb_fista_which_kernel(1200, 28, 5000, 0, 1, 6) == 0      # stop rules: LDS kernel
+    assert lib.pb_fista_which_kernel(1200, 28, 5000, 0, 1, 6) == 3
+    assert lib.pb_fista_which_kernel(1200, 28, 5000, 1, 2, 6) == 3      # default deconv path
+    assert lib.pb_fista_which_kernel(2400, 28, 5000, 1, 2, 6) == 0      # S = 38: ring too large
     assert lib.pb_fista_has_fast_path(100000, 30) == 0
     assert lib.pb_fista_has_fast_path(300, 5000) == 0
     assert lib.pb_fista_has_fast_path(0, 30) == 0

@@ -149,6 +149,15 @@ def test_long_series_one_problem_per_wave(pa, N, K):
     np.testing.assert_allclose(J.cpu().numpy(), Jg.cpu().numpy(), rtol=2e-5)
     W2, _, _ = solver.fista_solve(dev32(Y), hrf, lam, 1.0 / lip, 30, force="fast")
     assert np.abs(W2.cpu().numpy() - ref).max() / np.abs(ref).max() < EPS
+    # stop rules in the one-problem-per-wave form agree with the LDS kernel (float64)
+    for stop, tol in (("loops", 0.3), ("window", 0.05)):
+        if stop == "window" and N > 1216:
+            continue                     # needs the S = 38 entry: window rule stays on the LDS kernel
+        Wf, _, nf = solver.fista_solve(dev32(Y), hrf, lam, 1.0 / lip, 60, stop=stop, tol=tol, force="fast")
+        Wr, _, nr = solver.fista_solve(dev32(Y), hrf, lam, 1.0 / lip, 60, stop=stop, tol=tol, force="generic")
+        assert torch.equal(nf, nr), (stop, nf, nr)
+        assert np.abs(Wf.cpu().numpy() - Wr.cpu().numpy()).max() / np.abs(ref).max() < EPS
+        assert int(nf.min()) < 60        # the rule actually fired
 
 
 def test_lambda_zero_and_huge(pa, golden):
