@@ -62,8 +62,9 @@ namespace {
 
 }  // namespace
 namespace pb {
-#define PB_WIDE(S, KT) \
-  extern template int launch_wide<S, KT>(const FistaArgs&, const double*, int, bool, int, hipStream_t);
+#define PB_WIDE(S, KT)                                                                            \
+  extern template int launch_wide<S, KT>(const FistaArgs&, const double*, int, bool, int, hipStream_t); \
+  extern template int launch_wide_pp<S, KT>(const FistaArgs&, int, hipStream_t);
 #include "wide_table.inc"
 #undef PB_WIDE
 }  // namespace pb
@@ -74,8 +75,9 @@ typedef int (*wide_launch_fn)(const pb::FistaArgs&, const double* taps, int K, b
 struct WideEntry {
   int S, KT;
   wide_launch_fn fn;
+  fast_launch_pp_fn fn_pp;
 };
-#define PB_WIDE(S, KT) {S, KT, &pb::launch_wide<S, KT>},
+#define PB_WIDE(S, KT) {S, KT, &pb::launch_wide<S, KT>, &pb::launch_wide_pp<S, KT>},
 const WideEntry kWide[] = {
 #include "wide_table.inc"
 };
@@ -405,6 +407,12 @@ int pb_fista_solve_pp(const float* y_dev, int64_t ldy, double* w_dev, int64_t ld
   if (fe) {
     fe->fn_pp(a, stop_mode, (hipStream_t)stream);
     return check_launch("fista_fast_kernel(pp)");
+  }
+  if (!(flags & PB_FLAG_FORCE_GENERIC)) {
+    if (const WideEntry* we = pick_wide(N, K)) {
+      we->fn_pp(a, stop_mode, (hipStream_t)stream);
+      return check_launch("fista_fast_kernel(wide, pp)");
+    }
   }
   if (flags & PB_FLAG_FORCE_FAST)
     return fail(PB_ERR_INVALID, "pb_fista_solve_pp: no register-resident kernel for N=%d K=%d", N, K);

@@ -60,4 +60,16 @@ int launch_fast_pp(const FistaArgs& a, int stop, hipStream_t st) {
   return 0;
 }
 
+// per-problem taps/step, one problem per wave
+template <int S, int KT>
+int launch_wide_pp(const FistaArgs& a, int stop, hipStream_t st) {
+  const TapPairs<KT> tp{};
+  const dim3 grid((unsigned)(((int64_t)a.P * 64 + 255) / 256)), block(256);
+  if (stop == PB_STOP_NONE)
+    hipLaunchKernelGGL((fista_fast_kernel<S, KT, false, 0, true, 64>), grid, block, 0, st, a, tp);
+  else
+    hipLaunchKernelGGL((fista_fast_kernel<S, KT, false, 1, true, 64>), grid, block, 0, st, a, tp);
+  return 0;
+}
+
 }  // namespace pb

@@ -6,4 +6,5 @@
 #endif
 namespace pb {
 template int launch_wide<PB_S, PB_KT>(const FistaArgs&, const double*, int, bool, int, hipStream_t);
+template int launch_wide_pp<PB_S, PB_KT>(const FistaArgs&, int, hipStream_t);
 }

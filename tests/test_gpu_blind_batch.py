@@ -86,6 +86,23 @@ def test_solver_with_per_problem_taps(golden, force):
     assert np.linalg.norm(W2.cpu().numpy()[0] - ref) / np.linalg.norm(ref) < 1e-5
 
 
+def test_per_problem_taps_long_series():
+    """pb_fista_solve_pp on a 1 000-scan series: one-problem-per-wave form vs LDS kernel vs oracle."""
+    from pybold_amd import solver
+    rng = np.random.RandomState(4)
+    V, n = 5, 1000
+    thetas = np.array([0.6, 0.9, 1.2, 1.5, 1.9])
+    H = np.stack([orc.spm_hrf(t, 0.72, 20.0, False)[0] for t in thetas])
+    Y = rng.randn(V, n)
+    steps = 1.0 / np.array([orc.gram_lipschitz(h, n) for h in H])
+    Wf, _ = solver.fista_solve_pp(d32(Y), d64(H), d64(steps), 0.5, 40, force="fast")
+    Wg, _ = solver.fista_solve_pp(d32(Y), d64(H), d64(steps), 0.5, 40, force="generic")
+    for v in range(V):
+        ref = orc.fista_batch(Y[v:v + 1].astype(np.float32).astype(np.float64), H[v], 0.5, steps[v], 40)[0]
+        assert np.linalg.norm(Wf.cpu().numpy()[v] - ref) / np.linalg.norm(ref) < 1e-5
+        assert np.linalg.norm(Wg.cpu().numpy()[v] - ref) / np.linalg.norm(ref) < 1e-9
+
+
 def test_section_search_finds_the_scipy_minimiser(golden):
     from pybold_amd import blind
     g = golden("hrf_estim")
