@@ -43,7 +43,7 @@ struct FastEntry {
   int S, KT;
   fast_launch_fn fn;
   fast_launch_pp_fn fn_pp;
-  pair_launch_fn fn_pair;     // two-problems-per-row kernel (S <= 20 only), else nullptr
+  pair_launch_fn fn_pair;     // two-problems-per-row kernel (S <= 20, KT <= 32 only), else nullptr
 };
 
 }  // namespace
@@ -95,7 +95,7 @@ const WideEntry* pick_wide(int N, int K) {
 
 template <int S, int KT>
 constexpr pair_launch_fn pair_or_null() {
-  if constexpr (S <= 20) return &pb::launch_pair<S, KT>; else return nullptr;
+  if constexpr (S <= 20 && KT <= 32) return &pb::launch_pair<S, KT>; else return nullptr;
 }
 #define PB_FAST(S, KT) {S, KT, &pb::launch_fast<S, KT>, &pb::launch_fast_pp<S, KT>, pair_or_null<S, KT>()},
 const FastEntry kFast[] = {

@@ -5,7 +5,7 @@
 #error "compile with -DPB_S=<samples per lane> -DPB_KT=<taps>"
 #endif
 namespace pb {
-#if PB_S <= 20
+#if PB_S <= 20 && PB_KT <= 32
 template int launch_pair<PB_S, PB_KT>(const FistaArgs&, const double*, int, bool, hipStream_t);
 #endif
 }

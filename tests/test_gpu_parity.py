@@ -108,7 +108,7 @@ def test_warm_start_chunks_equal_one_run(pa, golden):
 @pytest.mark.parametrize("N,K", [(300, 30), (290, 30), (304, 30), (17, 5), (40, 30), (300, 1),
                                  (33, 27), (1, 1), (16, 2), (600, 30), (284, 28), (384, 32),
                                  (240, 27), (160, 30), (128, 16), (300, 27), (300, 32), (608, 29),
-                                 (700, 30), (300, 40)])
+                                 (700, 30), (300, 40), (300, 48), (150, 45), (1000, 41), (300, 49)])
 def test_edge_shapes_fast_and_generic_agree_with_oracle(pa, N, K):
     _, solver = pa
     rng = np.random.RandomState(N * 100 + K)
