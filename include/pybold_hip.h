@@ -78,7 +78,7 @@ int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mod
  *
  * y_dev      float32 [ceil(P / y_rep)][ldy]: observed series; problem p reads
  *            row p / y_rep (y_rep > 1 = several lambdas per voxel).
- * w_dev      float64 [P][ldw]: in = warm start (w_0), out = final iterate.
+ * w_dev      float64 [P][ldw]: in = warm start (w_0), out = final iterate.  P <= 2^25.
  * taps_host  float64 [K]: HRF taps (shared by all problems), host copy: the
  *            register-resident kernel receives them as kernel arguments.
  * taps_dev   the same taps in device memory (used by the generic LDS kernel;
@@ -176,6 +176,9 @@ int pb_spectral_radius(const double* x0_dev, int N, const double* taps_dev, int 
  * pb_fista_solve_pp   the solver of pb_fista_solve with per-problem taps
  *                     taps_dev float64 [P][ldt] (K used) and per-problem step
  *                     step_dev float64 [P]; stop rule NONE or LOOPS; no cost trace.
+ *                     ldt = 0: ONE HRF (taps_dev [K]) and ONE step (step_dev [1]) in device
+ *                     memory shared by every problem -- the shared-HRF blind step, whose
+ *                     taps come out of pb_theta_fit without passing through the host.
  * pb_hrf_cost_pv      pb_hrf_cost with one HRF per (candidate, voxel):
  *                     taps_dev float64 [n_hrf][V][K], cost_dev float64 [n_hrf][V].
  * pb_gram_frobenius   out[p] = || A_p^T A_p ||_F with A_p = toeplitz(taps_p, N, N) tril(1):
@@ -203,6 +206,87 @@ int pb_fista_outputs_pp(const double* w_dev, int64_t ldw, int P, int N,
 int pb_spm_hrf(const double* deltas_dev, int M, const double* t_dev, int K,
                double a_peak, double loc_peak, double a_under, double loc_under,
                double ratio, double* out_dev, void* stream);
+
+/*
+ * Float64-`y` forms (suffix _d).  pb_fista_solve stores y as float32 in HBM (the batch
+ * layout); the entry points below take y as float64 and compute in float64 end to end --
+ * the reference's own arithmetic -- for the single-voxel / small-batch calls of the
+ * reference's API (deconv, _loops_deconv, bd, hrf_fit_err on 1-D arrays) and for the
+ * theta-step, whose finite-difference L-BFGS-B is sensitive to the last digits of the cost
+ * (pybold/bold_signal.py:217-222, :329-333).
+ *
+ * pb_fista_solve_d    pb_fista_solve on the any-size LDS kernel, all float64: y float64,
+ *                     cost trace J float64 [P][ldj]; taps from device memory.
+ * pb_fista_stats_d, pb_hrf_cost_d, pb_hrf_cost_pv_d   as their float32-y namesakes.
+ */
+int pb_fista_solve_d(const double* y_dev, int64_t ldy, int y_rep, double* w_dev, int64_t ldw,
+                     int P, int N, const double* taps_dev, int K, double step, double lbda,
+                     const double* lbda_dev, const double* betas_dev, int n_iter,
+                     double* J_dev, int64_t ldj, int stop_mode, double tol, int wind,
+                     int32_t* n_done_dev, void* stream);
+int pb_fista_stats_d(const double* w_dev, int64_t ldw, const double* y_dev, int64_t ldy,
+                     int y_rep, int P, int N, const double* taps_dev, int K,
+                     double* r2_dev, double* l1_dev, void* stream);
+int pb_hrf_cost_d(const double* z_dev, int64_t ldz, const double* y_dev, int64_t ldy,
+                  int V, int N, const double* taps_dev, int K, int n_hrf,
+                  double* cost_dev, void* stream);
+int pb_hrf_cost_pv_d(const double* z_dev, int64_t ldz, const double* y_dev, int64_t ldy,
+                     int V, int N, const double* taps_dev, int K, int n_hrf,
+                     double* cost_dev, void* stream);
+
+/*
+ * out[v] = || H^T y_v ||_inf with H = toeplitz(taps, N, N) . cumsum (ConvAndLinear.adj,
+ * pybold/linear.py:95-113, followed by max|.|): the smallest lambda whose solution is
+ * diff_z = 0, i.e. the top of a per-voxel regularisation path `lambda = c * lambda_max,v`.
+ * The reference hard-codes its lambda lists (examples/icassp_2019/simulation.py:113-114).
+ */
+int pb_lambda_max(const float* y_dev, int64_t ldy, int V, int N, const double* taps_dev, int K,
+                  double* out_dev, void* stream);
+int pb_lambda_max_d(const double* y_dev, int64_t ldy, int V, int N, const double* taps_dev, int K,
+                    double* out_dev, void* stream);
+
+/*
+ * Row-wise inf-norm normalisation out = x / (max|x| + 1e-12) (inf_norm,
+ * pybold/utils.py:112-138): V rows of n elements (n of any size; a 1-D or 3-D array of the
+ * reference is one row of all its elements).  NaN propagates like np.max.
+ */
+int pb_inf_norm(const double* x_dev, int64_t ldx, double* out_dev, int64_t ldo, int V, int64_t n,
+                void* stream);
+
+/*
+ * Theta-step of the blind solver without per-candidate passes over the data.
+ * hrf_fit_err(theta) = 0.5||y - h(theta) * z||^2 (pybold/bold_signal.py:217-222) is the
+ * quadratic form 0.5 yy - h^T b + 0.5 h^T G h in the K taps with
+ *   G[m][m'] = sum_i z[i-m] z[i-m'],  b[m] = sum_i z[i-m] y[i],  yy = sum_i y[i]^2.
+ *
+ * pb_hrf_normal_eq   one pass over (z, y): a set = G row-major [K][K], b [K], yy
+ *                    (pb_hrf_normal_eq_len(K) = K*K+K+1 float64).
+ *                    per_voxel = 0: out_dev [len] = sum over the V voxels (shared-HRF
+ *                      variant, BASELINE config 4; an empty shard V = 0 writes zeros so the
+ *                      rank still contributes to the all-reduce); work_dev = scratch of
+ *                      work_len float64 (>= len; more, up to 1024*len, = more workgroups);
+ *                      the sum order is fixed: results are reproducible.
+ *                    per_voxel = 1: out_dev [V][len], one set per voxel; work_dev unused.
+ * pb_theta_fit       argmin over theta in [lo, hi] of the quadratic form for M sets
+ *                    (ne_dev [M][ldne]) with h(theta) the un-normalised two-gamma SPM HRF
+ *                    at the K sample times t_dev (parameters as pb_spm_hrf): section search
+ *                    with 64 candidates per refinement (bracket / 31.5 each) closed by a
+ *                    parabola vertex; replaces the reference's fmin_l_bfgs_b call
+ *                    (:329-333).  theta_dev [M], cost_dev [M] = F(theta*), taps_dev
+ *                    [M][ldt] = h(theta*) (may be NULL).  Entirely on the device: the
+ *                    next z-step can read taps_dev through pb_fista_solve_pp (ldt = 0).
+ */
+int64_t pb_hrf_normal_eq_len(int K);
+int pb_hrf_normal_eq(const double* z_dev, int64_t ldz, const float* y_dev, int64_t ldy,
+                     int V, int N, int K, int per_voxel, double* work_dev, int64_t work_len,
+                     double* out_dev, void* stream);
+int pb_hrf_normal_eq_d(const double* z_dev, int64_t ldz, const double* y_dev, int64_t ldy,
+                       int V, int N, int K, int per_voxel, double* work_dev, int64_t work_len,
+                       double* out_dev, void* stream);
+int pb_theta_fit(const double* ne_dev, int64_t ldne, int M, int K, const double* t_dev,
+                 double a_peak, double loc_peak, double a_under, double loc_under, double ratio,
+                 double lo, double hi, int n_refine, double* theta_dev, double* cost_dev,
+                 double* taps_dev, int64_t ldt, void* stream);
 
 #ifdef __cplusplus
 }

@@ -371,7 +371,7 @@ def bd(y, t_r, lbda=1.0, theta_0=None, z_0=None, hrf_dur=20.0, bounds=None,
     r_0 = np.sum(np.square(x - y))
     g_0 = np.sum(np.abs(w))
     j_0 = r_0 + lbda * g_0
-    d = {'r': [1.0], 'g': [g_0], 'J': [1.0], 'l_alpha': []}
+    d = {'r': [1.0], 'g': [g_0], 'J': [1.0], 'l_alpha': [], 'theta': []}
     for idx in range(nb_iter):
         H = toeplitz_from_kernel(h, n, n)
         w = loops_deconv(y, w, H, lbda, nb_iter, early_stopping, wind, tol)
@@ -379,6 +379,7 @@ def bd(y, t_r, lbda=1.0, theta_0=None, z_0=None, hrf_dur=20.0, bounds=None,
         theta, _, _ = fmin_l_bfgs_b(
             func=hrf_fit_err, x0=theta, args=(z, y, t_r, hrf_dur),
             bounds=bounds, approx_grad=True, maxiter=999, pgtol=1.0e-12)
+        d['theta'].append(float(np.ravel(theta)[0]))     # not returned by the reference; for tests
         h, _ = spm_hrf(float(np.ravel(theta)[0]), t_r, hrf_dur, False)
         x = causal_conv(h, z)
         r = np.sum(np.square(x - y))
@@ -502,3 +503,122 @@ def deconv_auto_lbda(y, hrf, sigma, lipschitz, early_stopping=True, tol=1.0e-6, 
     z = np.cumsum(w)
     x = causal_conv(hrf, z)
     return x, z, w, J, R, G
+
+
+# --------------------------------------------------------------------------
+# Helpers around the path: regularisation path top, inf-norm, shared-HRF step
+# --------------------------------------------------------------------------
+def lambda_max(Y, hrf):
+    """``|| H^T y ||_inf`` per row, ``H = toeplitz(hrf) . cumsum`` (pybold/linear.py:95-113):
+    for ``lbda >= lambda_max`` the minimiser of ``0.5||H w - y||^2 + lbda ||w||_1`` is 0."""
+    Y = np.atleast_2d(np.asarray(Y, dtype=np.float64))
+    return np.array([np.max(np.abs(integ_adj(causal_corr(hrf, y)))) for y in Y])
+
+
+def inf_norm(arrays, axis=1):
+    """pybold/utils.py:112-138: ``x / (max|x| + 1e-12)``; 2-D arrays along ``axis``, 1-D and
+    3-D arrays as a whole, lists element-wise."""
+    def one(x):
+        return x / (np.max(np.abs(x)) + 1.0e-12)
+
+    def arr(a):
+        a = np.asarray(a, dtype=np.float64)
+        if a.ndim == 2:
+            return np.vstack(np.apply_along_axis(one, axis, a))
+        if a.ndim in (1, 3):
+            return one(a)
+        raise ValueError("inf-norm normalization only handle 1D, 2D or 3D arrays")
+    if isinstance(arrays, list):
+        return [arr(a) for a in arrays]
+    return arr(arrays)
+
+
+def hrf_normal_eq(Z, Y, K):
+    """Normal equations of ``hrf_fit_err`` in the K taps, summed over the rows of
+    ``(Z, Y)``: with the ``(N, K)`` Toeplitz matrix ``T_z[i, m] = z[i - m]`` (so that
+    ``h * z = T_z h``, pybold/convolution.py:105-132 with the roles of signal and kernel
+    swapped, as pybold/tests/test_convolution.py:169-176 does): ``G = sum T_z^T T_z``,
+    ``b = sum T_z^T y``, ``yy = sum ||y||^2``."""
+    Z = np.atleast_2d(np.asarray(Z, dtype=np.float64))
+    Y = np.atleast_2d(np.asarray(Y, dtype=np.float64))
+    n = Z.shape[1]
+    G, b, yy = np.zeros((K, K)), np.zeros(K), 0.0
+    for z, y in zip(Z, Y):
+        T = toeplitz_from_kernel(z, K, n)          # (n, K): T[i, m] = z[i - m]
+        G += T.T.dot(T)
+        b += T.T.dot(y)
+        yy += float(np.dot(y, y))
+    return G, b, yy
+
+
+def shared_hrf_cost(theta, Z, Y, t_r, hrf_dur):
+    """``sum_v 0.5 || y_v - h(theta) * z_v ||^2``: the shared-HRF objective of BASELINE
+    config 4; for one voxel it is exactly :func:`hrf_fit_err`."""
+    h, _ = spm_hrf(float(np.ravel(theta)[0]), t_r, hrf_dur, False)
+    Z, Y = np.atleast_2d(Z), np.atleast_2d(Y)
+    return float(sum(0.5 * np.sum(np.square(y - causal_conv(h, z))) for z, y in zip(Z, Y)))
+
+
+def shared_theta_argmin(Z, Y, t_r, hrf_dur, bounds=(MIN_DELTA + 0.1, MAX_DELTA - 0.1), n_grid=64,
+                        n_refine=6):
+    """Global minimiser of :func:`shared_hrf_cost` over ``bounds`` by plain section search
+    on the DIRECT cost (no normal equations): the checker of the device theta-step."""
+    a, b = bounds
+    best = a
+    for _ in range(n_refine):
+        grid = np.linspace(a, b, n_grid)
+        f = [shared_hrf_cost(t, Z, Y, t_r, hrf_dur) for t in grid]
+        m = int(np.argmin(f))
+        best = grid[m]
+        a, b = grid[max(m - 1, 0)], grid[min(m + 1, n_grid - 1)]
+    return best, shared_hrf_cost(best, Z, Y, t_r, hrf_dur)
+
+
+def gen_regular_bloc_bold(dur=10, tr=1.0, dur_bloc=30.0, hrf=None, snr=1.0, noise=None):
+    """Regular block design of pybold/data.py:10-41: innovation +1/-1 alternating every
+    ``int(dur_bloc / tr)`` samples starting at 0 (:14-16), block signal = its cumsum, both
+    centred (:20-22), BOLD = ``hrf * blocks`` (:34); ``noise`` (a unit-variance draw) is
+    rescaled to the exact SNR in dB as ``add_gaussian_noise`` does (:436-444).
+    Returns ``(noisy, clean, ai_s, i_s, scaled noise)``."""
+    n = int(dur * 60 / tr)
+    i_s = np.zeros(n)
+    marks = np.arange(0, n, int(dur_bloc / tr))
+    i_s[marks] = -1.0
+    i_s[marks[::2]] = 1.0
+    ai_s = np.cumsum(i_s)
+    ai_s = ai_s - ai_s.mean()
+    i_s = i_s - i_s.mean()
+    clean = causal_conv(np.asarray(hrf, dtype=np.float64), ai_s)
+    if noise is None:
+        return clean, clean, ai_s, i_s, np.zeros(n)
+    noise = np.asarray(noise, dtype=np.float64)
+    ratio = np.linalg.norm(clean) / (np.linalg.norm(noise) + np.finfo(np.float64).eps)
+    noise = (1.0 / np.sqrt(10 ** (snr / 10.0))) * ratio * noise
+    return clean + noise, clean, ai_s, i_s, noise
+
+
+def theta_fit_normal_eq(G, b, yy, t_r, hrf_dur, bounds, n_refine=3, n_grid=64):
+    """The device theta-step restated on the CPU: minimise the quadratic form
+    ``0.5 yy - h^T b + 0.5 h^T G h`` (= :func:`shared_hrf_cost` written with the normal
+    equations of :func:`hrf_normal_eq`) over ``bounds`` by section search -- ``n_grid``
+    equispaced candidates, bracket = the two cells around the best one -- closed by the
+    vertex of the parabola through the best candidate and its neighbours.
+    Returns ``(theta, F(theta), h(theta))``."""
+    def price(th):
+        h = spm_hrf(th, t_r, hrf_dur, False)[0]
+        return 0.5 * yy - h.dot(b) + 0.5 * h.dot(G.dot(h))
+    a, c = bounds
+    best = a
+    for r in range(n_refine):
+        grid = a + (c - a) * (np.arange(n_grid) / float(n_grid - 1))
+        f = np.array([price(t) for t in grid])
+        m = int(np.argmin(f))
+        il, ir = max(m - 1, 0), min(m + 1, n_grid - 1)
+        best = grid[m]
+        if r == n_refine - 1 and 0 < m < n_grid - 1:
+            den = f[il] - 2.0 * f[m] + f[ir]
+            if den > 0.0:
+                tv = grid[m] + 0.5 * (grid[m] - grid[il]) * (f[il] - f[ir]) / den
+                best = min(max(tv, grid[il]), grid[ir])
+        a, c = grid[il], grid[ir]
+    return best, price(best), spm_hrf(best, t_r, hrf_dur, False)[0]

@@ -68,6 +68,32 @@ SIGNATURES = {
                                      _ptr, _c_i64, _ptr, _c_i64, _ptr]),
     "pb_spm_hrf": (_c_int, [_ptr, _c_int, _ptr, _c_int, _c_dbl, _c_dbl, _c_dbl, _c_dbl, _c_dbl,
                             _ptr, _ptr]),
+    # float64-y forms
+    "pb_fista_solve_d": (_c_int, [
+        _ptr, _c_i64, _c_int,            # y_dev (float64), ldy, y_rep
+        _ptr, _c_i64, _c_int, _c_int,    # w_dev, ldw, P, N
+        _ptr, _c_int,                    # taps_dev, K
+        _c_dbl, _c_dbl, _ptr,            # step, lbda, lbda_dev
+        _ptr, _c_int,                    # betas_dev, n_iter
+        _ptr, _c_i64,                    # J_dev (float64), ldj
+        _c_int, _c_dbl, _c_int, _ptr,    # stop_mode, tol, wind, n_done_dev
+        _ptr]),                          # stream
+    "pb_fista_stats_d": (_c_int, [_ptr, _c_i64, _ptr, _c_i64, _c_int, _c_int, _c_int, _ptr,
+                                  _c_int, _ptr, _ptr, _ptr]),
+    "pb_hrf_cost_d": (_c_int, [_ptr, _c_i64, _ptr, _c_i64, _c_int, _c_int, _ptr,
+                               _c_int, _c_int, _ptr, _ptr]),
+    "pb_hrf_cost_pv_d": (_c_int, [_ptr, _c_i64, _ptr, _c_i64, _c_int, _c_int, _ptr,
+                                  _c_int, _c_int, _ptr, _ptr]),
+    "pb_lambda_max": (_c_int, [_ptr, _c_i64, _c_int, _c_int, _ptr, _c_int, _ptr, _ptr]),
+    "pb_lambda_max_d": (_c_int, [_ptr, _c_i64, _c_int, _c_int, _ptr, _c_int, _ptr, _ptr]),
+    "pb_inf_norm": (_c_int, [_ptr, _c_i64, _ptr, _c_i64, _c_int, _c_i64, _ptr]),
+    "pb_hrf_normal_eq_len": (_c_i64, [_c_int]),
+    "pb_hrf_normal_eq": (_c_int, [_ptr, _c_i64, _ptr, _c_i64, _c_int, _c_int, _c_int, _c_int,
+                                  _ptr, _c_i64, _ptr, _ptr]),
+    "pb_hrf_normal_eq_d": (_c_int, [_ptr, _c_i64, _ptr, _c_i64, _c_int, _c_int, _c_int, _c_int,
+                                    _ptr, _c_i64, _ptr, _ptr]),
+    "pb_theta_fit": (_c_int, [_ptr, _c_i64, _c_int, _c_int, _ptr, _c_dbl, _c_dbl, _c_dbl, _c_dbl,
+                              _c_dbl, _c_dbl, _c_dbl, _c_int, _ptr, _ptr, _ptr, _c_i64, _ptr]),
 }
 
 _lib = None

@@ -65,10 +65,18 @@ def bd_batch(Y, t_r, lbda=1.0, theta_0=None, z_0=None, hrf_dur=20.0, bounds=None
     V, n = Y.shape
     if bounds is None:
         bounds = [(MIN_DELTA + 1.0e-1, MAX_DELTA - 1.0e-1)]
-    theta = torch.full((V,), MAX_DELTA if theta_0 is None else float(theta_0),
-                       dtype=torch.float64, device=dev)
-    if theta_0 is not None and np.ndim(theta_0) > 0:
-        theta = torch.as_tensor(theta_0, dtype=torch.float64).to(dev)
+    if theta_0 is not None and (torch.is_tensor(theta_0) or np.ndim(theta_0) > 0):
+        theta = torch.as_tensor(theta_0, dtype=torch.float64).to(dev).reshape(-1).clone()
+        if theta.numel() != V:
+            raise ValueError("theta_0 must be a scalar or hold one dilation per voxel "
+                             "(%d), got %d" % (V, theta.numel()))
+        if V and (float(theta.min()) < MIN_DELTA or float(theta.max()) > MAX_DELTA):
+            raise ValueError("theta_0 must lie in [%g, %g]" % (MIN_DELTA, MAX_DELTA))   # hrf_model.py:17-21
+    else:
+        t0 = MAX_DELTA if theta_0 is None else float(theta_0)
+        if t0 < MIN_DELTA or t0 > MAX_DELTA:
+            raise ValueError("theta_0 must lie in [%g, %g]" % (MIN_DELTA, MAX_DELTA))
+        theta = torch.full((V,), t0, dtype=torch.float64, device=dev)
     taps = solver.spm_hrf_batch(theta, t_r, hrf_dur)                    # (V, K)
     if z_0 is None:
         W = torch.zeros((V, n), dtype=torch.float64, device=dev)

@@ -9,8 +9,9 @@ CUDA tensor in gives CUDA tensors out (x, z, diff_z stay in HBM).
 Deviations from the reference, all deliberate:
   * the fixed-lambda ``deconv`` does not print one line per iteration
     (pybold/bold_signal.py:79-80 does, unconditionally);
-  * ``y`` is stored in float32 in HBM (the iterate and its update stay float64
-    on chip); outputs are float64 like the reference's;
+  * a 2-D batch ``y`` is stored in float32 in HBM (the iterate and its update stay
+    float64 on chip); a 1-D ``y`` is computed in float64 end to end; outputs are
+    float64 like the reference's;
   * ``_loops_deconv`` does not overwrite the caller's ``diff_z`` (the reference
     does at :261; every caller rebinds the returned array);
   * ``deconv(lbda=None)`` (noise-driven lambda search, :99-214) estimates the
@@ -41,15 +42,21 @@ class _Shape:
 
 
 def _y_to_device(y):
-    """-> (float32 CUDA (V, N), _Shape)"""
+    """-> (CUDA (V, N), _Shape).  A 2-D batch is stored as float32 (the layout of the
+    register-resident kernels).  A 1-D series -- the reference's own call pattern -- stays
+    float64 and runs on the all-float64 kernels (``pb_fista_solve_d`` & co.): same
+    arithmetic as the reference end to end, which also keeps the finite-difference
+    L-BFGS-B of the theta-step on the reference's trajectory."""
     if torch.is_tensor(y):
         one_d = y.dim() == 1
         on_device = y.is_cuda
-        t = y.to(device=solver.device(y.device if y.is_cuda else None), dtype=torch.float32)
+        t = y.to(device=solver.device(y.device if y.is_cuda else None),
+                 dtype=torch.float64 if one_d else torch.float32)
     else:
         a = np.asarray(y)
         one_d, on_device = a.ndim == 1, False
-        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(solver.device())
+        t = torch.from_numpy(np.ascontiguousarray(
+            a, dtype=np.float64 if one_d else np.float32)).to(solver.device())
     return (t.reshape(1, -1) if one_d else t), _Shape(one_d, on_device)
 
 
@@ -217,7 +224,7 @@ class _BlindTrace:
         self.r0 = float(np.sum(np.square(x - y)))
         g0 = float(np.sum(np.abs(w)))
         self.j0 = self.r0 + lbda * g0
-        self.J, self.r, self.g = [1.0], [1.0], [g0]
+        self.J, self.r, self.g, self.theta = [1.0], [1.0], [g0], []
 
     def record(self, x, w, eps):
         r = float(np.sum(np.square(x - self.y)))
@@ -233,7 +240,7 @@ class _BlindTrace:
 
     def as_dict(self):
         return {'J': np.array(self.J), 'r': np.array(self.r), 'g': np.array(self.g),
-                'l_alpha': []}
+                'l_alpha': [], 'theta': np.array(self.theta)}     # 'theta': extra key (per outer iteration)
 
 
 def _loops_deconv(y, diff_z, H, lbda, nb_iter, early_stopping, wind, tol):
@@ -305,6 +312,7 @@ def bd(y, t_r, lbda=1.0, theta_0=None, z_0=None, hrf_dur=20.0,  # noqa
         z = DiscretInteg().op(diff_z)                 # block signal of this iterate (:326)
         theta, _, _ = fmin_l_bfgs_b(func=hrf_fit_err, x0=theta, args=(z, y, t_r, hrf_dur),
                                     bounds=bounds, approx_grad=True, maxiter=999, pgtol=1.0e-12)
+        trace.theta.append(float(np.ravel(theta)[0]))
         h, _ = spm_hrf(float(np.ravel(theta)[0]), t_r, hrf_dur, False)
         x, z = outputs(diff_z, h)
         trace.record(x, diff_z, eps=1.0e-30)

@@ -1,0 +1,231 @@
+// HRF-fit (theta-step) kernels of the blind solver, float64.
+//
+// The reference prices one candidate HRF at a time: hrf_fit_err(theta) =
+// 0.5 || y - h(theta) * z ||^2 (pybold/bold_signal.py:217-222), called ~10-20 times per
+// outer iteration by L-BFGS-B with a finite-difference gradient (:329-333), each call a
+// full pass over the voxel's data.  The cost is a quadratic form in the K taps,
+//
+//   F(theta) = 0.5 yy - h^T b + 0.5 h^T G h,      h = h(theta)
+//   G[m][m'] = sum_i z[i-m] z[i-m']   b[m] = sum_i z[i-m] y[i]   yy = sum_i y[i]^2
+//
+// so ONE pass over the data (normal_eq_kernel) gives (G, b, yy) -- summed over the voxels
+// of the rank for the shared-HRF variant, then over ranks by one all-reduce of K^2+K+1
+// float64 -- and the whole 1-D search over theta runs on those few numbers in a single
+// wave (theta_fit_kernel), with no further pass over the data and no host round trip.
+//
+// G is Toeplitz up to the truncation at the end of the series:
+//   G[m][m'] = R_d(N-1-max(m,m')),  d = |m-m'|,  R_d(T) = sum_{j<=T} z[j] z[j+d]
+// so a lane owns one lag d, walks j once and records the running sum at the K-d
+// truncation points: K lanes x N steps per voxel instead of K^2 x N.
+#pragma once
+#include "common.h"
+#include "generic.h"
+
+namespace pb {
+
+constexpr int NE_THREADS = 256;
+
+__host__ __device__ inline int ne_len(int K) { return K * K + K + 1; }
+
+// Layout of one normal-equation set: G row-major [K][K], then b [K], then yy.
+// Shared mode (PER_VOXEL = false): block B sums its voxels into part[B][ne_len]; a second
+// kernel adds the blocks in a fixed order (deterministic).  PER_VOXEL: out[v][ne_len].
+// Each workgroup handles SLOTS = 256 / (2K+1) voxels at a time; thread role r of a slot:
+//   r <  K   autocorrelation lag r        (G diagonals)
+//   r < 2K   cross-correlation lag r-K    (b)
+//   r = 2K   yy
+// LDS per slot: z[N] y[N] (float64), acc[ne_len] (shared mode only).
+template <typename TY, bool PER_VOXEL>
+__global__ __launch_bounds__(NE_THREADS) void normal_eq_kernel(const double* z, int64_t ldz,
+                                                               const TY* y, int64_t ldy, int V,
+                                                               int N, int K, double* out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int roles = 2 * K + 1;
+  const int slots = NE_THREADS / roles;
+  const int ne = ne_len(K);
+  const int slot = threadIdx.x / roles;
+  const int role = threadIdx.x - slot * roles;
+  const bool worker = slot < slots;
+  double* lz = reinterpret_cast<double*>(smem) + (size_t)(worker ? slot : 0) * 2 * N;
+  double* ly = lz + N;
+  double* acc = reinterpret_cast<double*>(smem) + (size_t)slots * 2 * N + (size_t)(worker ? slot : 0) * ne;
+  if constexpr (!PER_VOXEL) {
+    for (int e = threadIdx.x; e < slots * ne; e += NE_THREADS)
+      (reinterpret_cast<double*>(smem) + (size_t)slots * 2 * N)[e] = 0.0;
+  }
+  __syncthreads();
+  const int groups = (V + slots - 1) / slots;
+  for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+    // stage the rows of this group's voxels (all threads help; slot s <- voxel grp*slots+s)
+    for (int s = 0; s < slots; ++s) {
+      const int v = grp * slots + s;
+      double* dz = reinterpret_cast<double*>(smem) + (size_t)s * 2 * N;
+      double* dy = dz + N;
+      if (v < V) {
+        const double* zr = z + (int64_t)v * ldz;
+        const TY* yr = y + (int64_t)v * ldy;
+        for (int i = threadIdx.x; i < N; i += NE_THREADS) {
+          dz[i] = zr[i];
+          dy[i] = (double)yr[i];
+        }
+      }
+    }
+    __syncthreads();
+    const int v = grp * slots + slot;
+    if (worker && v < V) {
+      double* dst = PER_VOXEL ? out + (int64_t)v * ne : acc;
+      if (role < K) {
+        const int d = role;
+        double r = 0.0;
+        // T = j ; record at T = N-1-m' for m' = K-1 .. d  (j = N-K .. N-1-d)
+        const int j_rec = N - K;
+        for (int j = 0; j < N - d; ++j) {
+          r = fma(lz[j], lz[j + d], r);
+          if (j >= j_rec) {
+            const int mp = N - 1 - j;          // m' = max(m, m'), m = m' - d
+            if (mp < K) {
+              const int m = mp - d;
+              if constexpr (PER_VOXEL) {
+                dst[m * K + mp] = r;
+                dst[mp * K + m] = r;
+              } else {
+                dst[m * K + mp] += r;
+                if (d) dst[mp * K + m] += r;
+              }
+            }
+          }
+        }
+        // series shorter than the HRF: entries whose truncation point lies before j = 0
+        if constexpr (PER_VOXEL) {
+          for (int mp = (N - d > 0 ? N : d) ; mp < K; ++mp) {   // N-1-mp < 0
+            const int m = mp - d;
+            dst[m * K + mp] = 0.0;
+            dst[mp * K + m] = 0.0;
+          }
+        }
+      } else if (role < 2 * K) {
+        const int m = role - K;
+        double s = 0.0;
+        for (int j = 0; j < N - m; ++j) s = fma(lz[j], ly[j + m], s);
+        if constexpr (PER_VOXEL) dst[K * K + m] = s; else dst[K * K + m] += s;
+      } else {
+        double s = 0.0;
+        for (int i = 0; i < N; ++i) s = fma(ly[i], ly[i], s);
+        if constexpr (PER_VOXEL) dst[K * K + K] = s; else dst[K * K + K] += s;
+      }
+    }
+    __syncthreads();
+  }
+  if constexpr (!PER_VOXEL) {
+    // fold the slots of this block (fixed order) and publish the block's partial sums
+    const double* a0 = reinterpret_cast<double*>(smem) + (size_t)slots * 2 * N;
+    double* part = out + (int64_t)blockIdx.x * ne;
+    for (int e = threadIdx.x; e < ne; e += NE_THREADS) {
+      double s = 0.0;
+      for (int q = 0; q < slots; ++q) s += a0[(size_t)q * ne + e];
+      part[e] = s;
+    }
+  }
+}
+
+// out[e] = sum_b part[b][e], b in fixed order (nblocks may be 0: an empty shard gives zeros)
+__global__ __launch_bounds__(NE_THREADS) void normal_eq_reduce_kernel(const double* part, int nblocks,
+                                                                      int ne, double* out) {
+  const int e = blockIdx.x * NE_THREADS + threadIdx.x;
+  if (e >= ne) return;
+  double s = 0.0;
+  for (int b = 0; b < nblocks; ++b) s += part[(int64_t)b * ne + e];
+  out[e] = s;
+}
+
+struct HrfModel {        // two-gamma SPM HRF, un-normalised (pybold/hrf_model.py:25-31)
+  double a1, loc1, lg1, a2, loc2, lg2, ratio;
+};
+
+__device__ __forceinline__ double spm_hrf_value(const HrfModel& hm, double x) {
+  auto pdf = [](double v, double a, double lg) {
+    return v > 0.0 ? exp((a - 1.0) * log(v) - v - lg) : 0.0;
+  };
+  return pdf(x - hm.loc1, hm.a1, hm.lg1) - hm.ratio * pdf(x - hm.loc2, hm.a2, hm.lg2);
+}
+
+// argmin_theta F(theta) over [lo, hi] for M independent normal-equation sets, one wave
+// (= 64 candidate dilations per refinement) per set: section search, the bracket shrinks to
+// the two grid cells around the best candidate (x31.5 per refinement); the last refinement
+// ends with the vertex of the parabola through the best candidate and its neighbours.
+// LDS: set [ne] then h [K][64] (lane-major columns, conflict-free).
+// theta[s], cost[s] = F(theta*), taps[s][K] = h(theta*).
+__global__ __launch_bounds__(64) void theta_fit_kernel(const double* ne_sets, int64_t ldne, int M,
+                                                       int K, const double* t, HrfModel hm,
+                                                       double lo, double hi, int n_refine,
+                                                       double* theta, double* cost, double* taps,
+                                                       int64_t ldt) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int s = blockIdx.x;
+  if (s >= M) return;
+  const int lane = threadIdx.x;
+  const int ne = ne_len(K);
+  double* G = reinterpret_cast<double*>(smem);
+  double* b = G + K * K;
+  double* hl = G + ne + lane;                 // h[k] of this lane at hl[k * 64]
+  const double* src = ne_sets + (int64_t)s * ldne;
+  for (int e = lane; e < ne; e += 64) G[e] = src[e];
+  __syncthreads();
+  const double yy = b[K];
+
+  auto price = [&](double th) -> double {
+    for (int k = 0; k < K; ++k) hl[k * 64] = spm_hrf_value(hm, th * t[k]);
+    double quad = 0.0, lin = 0.0;
+    for (int m = 0; m < K; ++m) {
+      double row = 0.0;
+      for (int mp = 0; mp < K; ++mp) row = fma(G[m * K + mp], hl[mp * 64], row);
+      quad = fma(hl[m * 64], row, quad);
+      lin = fma(hl[m * 64], b[m], lin);
+    }
+    return 0.5 * yy - lin + 0.5 * quad;
+  };
+
+  double a = lo, c = hi, best_t = lo, best_f = 0.0;
+  for (int r = 0; r < n_refine; ++r) {
+    const double th = a + (c - a) * ((double)lane / 63.0);
+    const double f = price(th);
+    // argmin over the wave (first minimum wins: deterministic)
+    double fm = f;
+    int im = lane;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const double fo = __shfl_xor(fm, o, 64);
+      const int io = __shfl_xor(im, o, 64);
+      if (fo < fm || (fo == fm && io < im)) { fm = fo; im = io; }
+    }
+    const int il = im > 0 ? im - 1 : 0, ir = im < 63 ? im + 1 : 63;
+    const double tl = __shfl(th, il, 64), tm = __shfl(th, im, 64), tr = __shfl(th, ir, 64);
+    const double fl = __shfl(f, il, 64), fr = __shfl(f, ir, 64);
+    best_t = tm;
+    best_f = fm;
+    if (r == n_refine - 1 && im > 0 && im < 63) {
+      // vertex of the parabola through (tl, fl), (tm, fm), (tr, fr); equal spacing
+      const double den = fl - 2.0 * fm + fr;
+      if (den > 0.0) {
+        const double hstep = tm - tl;
+        double tv = tm + 0.5 * hstep * (fl - fr) / den;
+        tv = fmin(fmax(tv, tl), tr);
+        best_t = tv;
+      }
+    }
+    a = tl;
+    c = tr;
+  }
+  // cost and taps at the returned dilation (every lane prices it; lane 0 publishes)
+  best_f = price(best_t);
+  if (lane == 0) {
+    theta[s] = best_t;
+    cost[s] = best_f;
+  }
+  if (taps) {
+    double* trow = taps + (int64_t)s * ldt;
+    for (int k = lane; k < K; k += 64) trow[k] = spm_hrf_value(hm, best_t * t[k]);
+  }
+}
+
+}  // namespace pb

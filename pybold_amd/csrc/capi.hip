@@ -11,6 +11,7 @@
 #include "generic.h"
 #include "launch_fast.h"
 #include "fista_pair.h"
+#include "blind.h"
 
 namespace {
 
@@ -138,19 +139,116 @@ bool pair_is_faster(int P) {
 template <int KIND>
 int launch_op(const double* x, int64_t ldx, double* out, int64_t ldo, int V, int n_src, int n_dst,
               const double* taps, int K, void* stream, const char* name) {
-  if (V < 0 || n_src < 1 || n_dst < 1 || K < 0 || !x || !out || (K > 0 && !taps))
-    return fail(PB_ERR_INVALID, "%s: bad argument", name);
+  // sizes first; an empty batch is a no-op whatever the pointers are (torch hands out
+  // data_ptr() == 0 for zero-element tensors)
+  if (V < 0 || n_src < 1 || n_dst < 1 || K < 0)
+    return fail(PB_ERR_INVALID, "%s: bad size (V=%d n_src=%d n_dst=%d K=%d)", name, V, n_src, n_dst, K);
   if (ldx < n_src || ldo < n_dst) return fail(PB_ERR_INVALID, "%s: leading dimension too small", name);
   const int nmax = n_src > n_dst ? n_src : n_dst;
   if (2 * (int64_t)nmax + K + 8 > LDS_DOUBLES_MAX)
     return fail(PB_ERR_INVALID, "%s: row of %d with %d taps exceeds LDS", name, nmax, K);
   if (V == 0) return PB_OK;
+  if (!x || !out || (K > 0 && !taps)) return fail(PB_ERR_INVALID, "%s: NULL pointer", name);
   const size_t lds = (size_t)(2 * nmax + K + 8) * sizeof(double);
   hipLaunchKernelGGL((pb::op_kernel<KIND>), dim3(V), dim3(pb::GEN_THREADS), lds, (hipStream_t)stream,
                      x, ldx, out, ldo, n_src, n_dst, taps, K);
   return check_launch(name);
 }
 
+}  // namespace
+
+namespace {
+template <typename TY>
+int stats_impl(const double* w_dev, int64_t ldw, const TY* y_dev, int64_t ldy, int y_rep, int P,
+               int N, const double* taps_dev, int K, double* r2_dev, double* l1_dev, void* stream,
+               const char* name) {
+  if (P < 0 || N < 1 || K < 1 || y_rep < 1 || ldw < N || ldy < N)
+    return fail(PB_ERR_INVALID, "%s: bad size", name);
+  if (2 * (int64_t)N + K + 8 > LDS_DOUBLES_MAX)
+    return fail(PB_ERR_INVALID, "%s: N=%d K=%d exceeds LDS", name, N, K);
+  if (P == 0) return PB_OK;
+  if (!w_dev || !y_dev || !taps_dev || !r2_dev || !l1_dev)
+    return fail(PB_ERR_INVALID, "%s: NULL pointer", name);
+  const size_t lds = (size_t)(2 * N + K + 8) * sizeof(double);
+  hipLaunchKernelGGL((pb::stats_kernel<TY>), dim3(P), dim3(pb::GEN_THREADS), lds,
+                     (hipStream_t)stream, w_dev, ldw, y_dev, ldy, y_rep, N, taps_dev, K, r2_dev,
+                     l1_dev);
+  return check_launch(name);
+}
+
+template <typename TY>
+int hrf_cost_impl(const double* z_dev, int64_t ldz, const TY* y_dev, int64_t ldy, int V, int N,
+                  const double* taps_dev, int K, int n_hrf, double* cost_dev, int per_voxel,
+                  void* stream, const char* name) {
+  if (V < 0 || N < 1 || K < 1 || n_hrf < 1 || ldz < N || ldy < N)
+    return fail(PB_ERR_INVALID, "%s: bad size", name);
+  if (n_hrf > 65535) return fail(PB_ERR_INVALID, "%s: more than 65535 candidate HRFs", name);
+  if ((int64_t)N + K + 8 > LDS_DOUBLES_MAX) return fail(PB_ERR_INVALID, "%s: exceeds LDS", name);
+  if (V == 0) return PB_OK;
+  if (!z_dev || !y_dev || !taps_dev || !cost_dev) return fail(PB_ERR_INVALID, "%s: NULL pointer", name);
+  const size_t lds = (size_t)(N + K + 8) * sizeof(double);
+  hipLaunchKernelGGL((pb::hrf_cost_kernel<TY>), dim3(V, n_hrf), dim3(pb::GEN_THREADS), lds,
+                     (hipStream_t)stream, z_dev, ldz, y_dev, ldy, V, N, taps_dev, K, cost_dev,
+                     per_voxel);
+  return check_launch(name);
+}
+}  // namespace
+
+namespace {
+template <typename TY>
+int lambda_max_impl(const TY* y_dev, int64_t ldy, int V, int N, const double* taps_dev, int K,
+                    double* out_dev, void* stream, const char* name) {
+  if (V < 0 || N < 1 || K < 1 || ldy < N) return fail(PB_ERR_INVALID, "%s: bad size", name);
+  if (2 * (int64_t)N + K + 8 > LDS_DOUBLES_MAX)
+    return fail(PB_ERR_INVALID, "%s: N=%d K=%d exceeds LDS", name, N, K);
+  if (V == 0) return PB_OK;
+  if (!y_dev || !taps_dev || !out_dev) return fail(PB_ERR_INVALID, "%s: NULL pointer", name);
+  const size_t lds = (size_t)(2 * N + K + 8) * sizeof(double);
+  hipLaunchKernelGGL((pb::lambda_max_kernel<TY>), dim3(V), dim3(pb::GEN_THREADS), lds,
+                     (hipStream_t)stream, y_dev, ldy, N, taps_dev, K, out_dev);
+  return check_launch(name);
+}
+
+constexpr int NE_MAX_BLOCKS = 1024;
+
+template <typename TY>
+int normal_eq_impl(const double* z_dev, int64_t ldz, const TY* y_dev, int64_t ldy, int V, int N,
+                   int K, int per_voxel, double* work_dev, int64_t work_len, double* out_dev,
+                   void* stream, const char* name) {
+  if (V < 0 || N < 1 || K < 1 || K > 127 || ldz < N || ldy < N)
+    return fail(PB_ERR_INVALID, "%s: bad size (V=%d N=%d K=%d)", name, V, N, K);
+  const int ne = pb::ne_len(K);
+  const int slots = pb::NE_THREADS / (2 * K + 1);
+  const int64_t nd = (int64_t)slots * 2 * N + (per_voxel ? 0 : (int64_t)slots * ne);
+  if (nd > LDS_DOUBLES_MAX) return fail(PB_ERR_INVALID, "%s: N=%d K=%d exceeds LDS", name, N, K);
+  if (!out_dev) return fail(PB_ERR_INVALID, "%s: NULL output", name);
+  const int groups = (V + slots - 1) / slots;
+  const size_t lds = (size_t)nd * sizeof(double);
+  if (per_voxel) {
+    if (V == 0) return PB_OK;
+    if (!z_dev || !y_dev) return fail(PB_ERR_INVALID, "%s: NULL pointer", name);
+    hipLaunchKernelGGL((pb::normal_eq_kernel<TY, true>), dim3(groups < 65535 * 16 ? groups : 65535 * 16),
+                       dim3(pb::NE_THREADS), lds, (hipStream_t)stream, z_dev, ldz, y_dev, ldy, V, N, K,
+                       out_dev);
+    return check_launch(name);
+  }
+  // shared mode: block partials in work_dev, then a fixed-order sum (an empty shard yields
+  // zeros, so that the rank still contributes to the all-reduce)
+  int blocks = groups < NE_MAX_BLOCKS ? groups : NE_MAX_BLOCKS;
+  if (work_len / ne < blocks) blocks = (int)(work_len / ne);
+  if (V > 0) {
+    if (blocks < 1 || !work_dev)
+      return fail(PB_ERR_INVALID, "%s: work buffer must hold at least %d doubles", name, ne);
+    if (!z_dev || !y_dev) return fail(PB_ERR_INVALID, "%s: NULL pointer", name);
+    hipLaunchKernelGGL((pb::normal_eq_kernel<TY, false>), dim3(blocks), dim3(pb::NE_THREADS), lds,
+                       (hipStream_t)stream, z_dev, ldz, y_dev, ldy, V, N, K, work_dev);
+  } else {
+    blocks = 0;
+  }
+  hipLaunchKernelGGL(pb::normal_eq_reduce_kernel, dim3((ne + pb::NE_THREADS - 1) / pb::NE_THREADS),
+                     dim3(pb::NE_THREADS), 0, (hipStream_t)stream, work_dev, blocks, ne, out_dev);
+  return check_launch(name);
+}
 }  // namespace
 
 extern "C" {
@@ -188,7 +286,7 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
                 N, K, n_iter, y_rep);
   if (P > 0 && (!y_dev || !w_dev || !taps_host || (n_iter > 0 && !betas_dev)))
     return fail(PB_ERR_INVALID, "pb_fista_solve: NULL pointer");
-  if (P > (1 << 27)) return fail(PB_ERR_INVALID, "pb_fista_solve: more than 2^27 problems per launch");
+  if (P > (1 << 25)) return fail(PB_ERR_INVALID, "pb_fista_solve: more than 2^25 problems per launch");
   if (ldy < N || ldw < N) return fail(PB_ERR_INVALID, "pb_fista_solve: leading dimension < N");
   if (J_dev && ldj < n_iter) return fail(PB_ERR_INVALID, "pb_fista_solve: ldj < n_iter");
   if (!(step > 0.0)) return fail(PB_ERR_INVALID, "pb_fista_solve: step must be positive");
@@ -199,10 +297,11 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
   if (P == 0) return PB_OK;
 
   pb::FistaArgs a;
-  a.y = y_dev; a.ldy = ldy; a.w = w_dev; a.ldw = ldw; a.lbda_vec = lbda_dev; a.betas = betas_dev;
-  a.J = J_dev; a.ldj = ldj; a.n_done = n_done_dev; a.step = step; a.lbda = lbda; a.tol = tol;
+  a.y = y_dev; a.y64 = nullptr; a.ldy = ldy; a.w = w_dev; a.ldw = ldw; a.lbda_vec = lbda_dev;
+  a.betas = betas_dev; a.J = J_dev; a.J64 = nullptr; a.ldj = ldj; a.n_done = n_done_dev;
+  a.step = step; a.lbda = lbda; a.tol = tol;
   a.y_rep = y_rep; a.P = P; a.N = N; a.n_iter = n_iter; a.stop_mode = stop_mode;
-  a.taps_pp = nullptr; a.ldt = 0; a.step_vec = nullptr; a.K = K;
+  a.taps_pp = nullptr; a.ldt = 0; a.step_vec = nullptr; a.step_shared = 0; a.K = K;
 
   const FastEntry* fe = (flags & PB_FLAG_FORCE_GENERIC) ? nullptr : pick_fast(N, K);
   // the register-resident window rule keeps wind-1 = 5 iterates in VGPRs: wind = 6
@@ -214,10 +313,12 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
     // kernel (measured 21.5 vs 21.7 ms), so it is used for it only on request.
     if (fe->fn_pair && stop_mode == PB_STOP_NONE && P >= 2 && !(flags & PB_FLAG_NO_PAIR) &&
         ((flags & PB_FLAG_FORCE_PAIR) || (!J_dev && pair_is_faster(P)))) {
-      fe->fn_pair(a, taps_host, K, J_dev != nullptr, (hipStream_t)stream);
+      if (fe->fn_pair(a, taps_host, K, J_dev != nullptr, (hipStream_t)stream) != 0)
+        return fail(PB_ERR_INVALID, "pb_fista_solve: pair kernel rejected the launch");
       return check_launch("fista_pair_kernel");
     }
-    fe->fn(a, taps_host, K, J_dev != nullptr, stop_mode, (hipStream_t)stream);
+    if (fe->fn(a, taps_host, K, J_dev != nullptr, stop_mode, (hipStream_t)stream) != 0)
+      return fail(PB_ERR_INVALID, "pb_fista_solve: no register-resident form for this stop rule");
     return check_launch("fista_fast_kernel");
   }
   // long series: one problem per wave (window rule: wind = 6 and S <= 20, as above)
@@ -225,7 +326,8 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
     const WideEntry* we = pick_wide(N, K);
     if (we && stop_mode == PB_STOP_WINDOW && (wind != 6 || we->S > 20)) we = nullptr;
     if (we) {
-      we->fn(a, taps_host, K, J_dev != nullptr, stop_mode, (hipStream_t)stream);
+      if (we->fn(a, taps_host, K, J_dev != nullptr, stop_mode, (hipStream_t)stream) != 0)
+        return fail(PB_ERR_INVALID, "pb_fista_solve: no one-problem-per-wave form for this stop rule");
       return check_launch("fista_fast_kernel(wide)");
     }
   }
@@ -249,15 +351,52 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
   return check_launch("fista_generic_kernel");
 }
 
+int pb_fista_solve_d(const double* y_dev, int64_t ldy, int y_rep, double* w_dev, int64_t ldw,
+                     int P, int N, const double* taps_dev, int K, double step, double lbda,
+                     const double* lbda_dev, const double* betas_dev, int n_iter, double* J_dev,
+                     int64_t ldj, int stop_mode, double tol, int wind, int32_t* n_done_dev,
+                     void* stream) {
+  if (P < 0 || N < 1 || K < 1 || n_iter < 0 || y_rep < 1)
+    return fail(PB_ERR_INVALID, "pb_fista_solve_d: bad size (P=%d N=%d K=%d n_iter=%d y_rep=%d)", P,
+                N, K, n_iter, y_rep);
+  if (ldy < N || ldw < N) return fail(PB_ERR_INVALID, "pb_fista_solve_d: leading dimension < N");
+  if (J_dev && ldj < n_iter) return fail(PB_ERR_INVALID, "pb_fista_solve_d: ldj < n_iter");
+  if (!(step > 0.0)) return fail(PB_ERR_INVALID, "pb_fista_solve_d: step must be positive");
+  if (stop_mode < PB_STOP_NONE || stop_mode > PB_STOP_WINDOW)
+    return fail(PB_ERR_INVALID, "pb_fista_solve_d: unknown stop_mode %d", stop_mode);
+  if (stop_mode == PB_STOP_WINDOW && wind < 2)
+    return fail(PB_ERR_INVALID, "pb_fista_solve_d: wind must be >= 2");
+  const int64_t nd = 3 * (int64_t)N + K + 2 * pb::GEN_WAVES +
+                     (stop_mode == PB_STOP_WINDOW ? (int64_t)wind * N : 0);
+  if (nd > LDS_DOUBLES_MAX)
+    return fail(PB_ERR_INVALID, "pb_fista_solve_d: N=%d K=%d wind=%d exceeds LDS", N, K, wind);
+  if (P == 0) return PB_OK;
+  if (!y_dev || !w_dev || !taps_dev || (n_iter > 0 && !betas_dev))
+    return fail(PB_ERR_INVALID, "pb_fista_solve_d: NULL pointer");
+  pb::FistaArgs a;
+  a.y = nullptr; a.y64 = y_dev; a.ldy = ldy; a.w = w_dev; a.ldw = ldw; a.lbda_vec = lbda_dev;
+  a.betas = betas_dev; a.J = nullptr; a.J64 = J_dev; a.ldj = ldj; a.n_done = n_done_dev;
+  a.step = step; a.lbda = lbda; a.tol = tol;
+  a.y_rep = y_rep; a.P = P; a.N = N; a.n_iter = n_iter; a.stop_mode = stop_mode;
+  a.taps_pp = nullptr; a.ldt = 0; a.step_vec = nullptr; a.step_shared = 0; a.K = K;
+  const size_t lds = (size_t)nd * sizeof(double);
+  if (J_dev)
+    hipLaunchKernelGGL((pb::fista_generic_kernel<true, true>), dim3(P), dim3(pb::GEN_THREADS), lds,
+                       (hipStream_t)stream, a, taps_dev, K, wind);
+  else
+    hipLaunchKernelGGL((pb::fista_generic_kernel<false, true>), dim3(P), dim3(pb::GEN_THREADS), lds,
+                       (hipStream_t)stream, a, taps_dev, K, wind);
+  return check_launch("fista_generic_kernel(f64)");
+}
+
 int pb_fista_outputs(const double* w_dev, int64_t ldw, int P, int N, const double* taps_dev, int K,
                      double* z_dev, int64_t ldz, double* x_dev, int64_t ldx, void* stream) {
-  if (P == 0 && N >= 1 && K >= 1) return PB_OK;
-  if (!w_dev || !taps_dev || P < 0 || N < 1 || K < 1 || ldw < N || (z_dev && ldz < N) ||
-      (x_dev && ldx < N))
-    return fail(PB_ERR_INVALID, "pb_fista_outputs: bad argument");
+  if (P < 0 || N < 1 || K < 1 || ldw < N || (z_dev && ldz < N) || (x_dev && ldx < N))
+    return fail(PB_ERR_INVALID, "pb_fista_outputs: bad size");
   if (2 * (int64_t)N + K + 8 > LDS_DOUBLES_MAX)
     return fail(PB_ERR_INVALID, "pb_fista_outputs: N=%d K=%d exceeds LDS", N, K);
   if (P == 0 || (!z_dev && !x_dev)) return PB_OK;
+  if (!w_dev || !taps_dev) return fail(PB_ERR_INVALID, "pb_fista_outputs: NULL pointer");
   const size_t lds = (size_t)(2 * N + K + 8) * sizeof(double);
   hipLaunchKernelGGL(pb::outputs_kernel, dim3(P), dim3(pb::GEN_THREADS), lds, (hipStream_t)stream,
                      w_dev, ldw, N, taps_dev, (int64_t)0, K, z_dev, ldz, x_dev, ldx);
@@ -267,13 +406,12 @@ int pb_fista_outputs(const double* w_dev, int64_t ldw, int P, int N, const doubl
 int pb_fista_outputs_pp(const double* w_dev, int64_t ldw, int P, int N, const double* taps_dev,
                         int64_t ldt, int K, double* z_dev, int64_t ldz, double* x_dev, int64_t ldx,
                         void* stream) {
-  if (P == 0 && N >= 1 && K >= 1) return PB_OK;
-  if (!w_dev || !taps_dev || P < 0 || N < 1 || K < 1 || ldw < N || ldt < K ||
-      (z_dev && ldz < N) || (x_dev && ldx < N))
-    return fail(PB_ERR_INVALID, "pb_fista_outputs_pp: bad argument");
+  if (P < 0 || N < 1 || K < 1 || ldw < N || ldt < K || (z_dev && ldz < N) || (x_dev && ldx < N))
+    return fail(PB_ERR_INVALID, "pb_fista_outputs_pp: bad size");
   if (2 * (int64_t)N + K + 8 > LDS_DOUBLES_MAX)
     return fail(PB_ERR_INVALID, "pb_fista_outputs_pp: N=%d K=%d exceeds LDS", N, K);
-  if (!z_dev && !x_dev) return PB_OK;
+  if (P == 0 || (!z_dev && !x_dev)) return PB_OK;
+  if (!w_dev || !taps_dev) return fail(PB_ERR_INVALID, "pb_fista_outputs_pp: NULL pointer");
   const size_t lds = (size_t)(2 * N + K + 8) * sizeof(double);
   hipLaunchKernelGGL(pb::outputs_kernel, dim3(P), dim3(pb::GEN_THREADS), lds, (hipStream_t)stream,
                      w_dev, ldw, N, taps_dev, ldt, K, z_dev, ldz, x_dev, ldx);
@@ -283,9 +421,10 @@ int pb_fista_outputs_pp(const double* w_dev, int64_t ldw, int P, int N, const do
 int pb_spm_hrf(const double* deltas_dev, int M, const double* t_dev, int K, double a_peak,
                double loc_peak, double a_under, double loc_under, double ratio, double* out_dev,
                void* stream) {
-  if (!deltas_dev || !t_dev || !out_dev || M < 0 || K < 1 || !(a_peak > 0.0) || !(a_under > 0.0))
+  if (M < 0 || K < 1 || !(a_peak > 0.0) || !(a_under > 0.0))
     return fail(PB_ERR_INVALID, "pb_spm_hrf: bad argument");
   if (M == 0) return PB_OK;
+  if (!deltas_dev || !t_dev || !out_dev) return fail(PB_ERR_INVALID, "pb_spm_hrf: NULL pointer");
   const int64_t total = (int64_t)M * K;
   const unsigned blocks = (unsigned)((total + pb::GEN_THREADS - 1) / pb::GEN_THREADS);
   hipLaunchKernelGGL(pb::spm_hrf_kernel, dim3(blocks), dim3(pb::GEN_THREADS), 0, (hipStream_t)stream,
@@ -294,25 +433,24 @@ int pb_spm_hrf(const double* deltas_dev, int M, const double* t_dev, int K, doub
   return check_launch("spm_hrf_kernel");
 }
 
+
 int pb_fista_stats(const double* w_dev, int64_t ldw, const float* y_dev, int64_t ldy, int y_rep,
                    int P, int N, const double* taps_dev, int K, double* r2_dev, double* l1_dev,
                    void* stream) {
-  if (!w_dev || !y_dev || !taps_dev || !r2_dev || !l1_dev || P < 0 || N < 1 || K < 1 ||
-      y_rep < 1 || ldw < N || ldy < N)
-    return fail(PB_ERR_INVALID, "pb_fista_stats: bad argument");
-  if (2 * (int64_t)N + K + 8 > LDS_DOUBLES_MAX)
-    return fail(PB_ERR_INVALID, "pb_fista_stats: N=%d K=%d exceeds LDS", N, K);
-  if (P == 0) return PB_OK;
-  const size_t lds = (size_t)(2 * N + K + 8) * sizeof(double);
-  hipLaunchKernelGGL(pb::stats_kernel, dim3(P), dim3(pb::GEN_THREADS), lds, (hipStream_t)stream,
-                     w_dev, ldw, y_dev, ldy, y_rep, N, taps_dev, K, r2_dev, l1_dev);
-  return check_launch("stats_kernel");
+  return stats_impl<float>(w_dev, ldw, y_dev, ldy, y_rep, P, N, taps_dev, K, r2_dev, l1_dev, stream,
+                           "pb_fista_stats");
+}
+int pb_fista_stats_d(const double* w_dev, int64_t ldw, const double* y_dev, int64_t ldy, int y_rep,
+                     int P, int N, const double* taps_dev, int K, double* r2_dev, double* l1_dev,
+                     void* stream) {
+  return stats_impl<double>(w_dev, ldw, y_dev, ldy, y_rep, P, N, taps_dev, K, r2_dev, l1_dev, stream,
+                            "pb_fista_stats_d");
 }
 
 int pb_spectral_radius(const double* x0_dev, int N, const double* taps_dev, int K, int nb_iter,
                        double tol, double* out_dev, void* stream) {
-  if (!x0_dev || !taps_dev || !out_dev || N < 1 || K < 1 || nb_iter < 0)
-    return fail(PB_ERR_INVALID, "pb_spectral_radius: bad argument");
+  if (N < 1 || K < 1 || nb_iter < 0) return fail(PB_ERR_INVALID, "pb_spectral_radius: bad size");
+  if (!x0_dev || !taps_dev || !out_dev) return fail(PB_ERR_INVALID, "pb_spectral_radius: NULL pointer");
   if (3 * (int64_t)N + K + 8 > LDS_DOUBLES_MAX)
     return fail(PB_ERR_INVALID, "pb_spectral_radius: N=%d K=%d exceeds LDS", N, K);
   const size_t lds = (size_t)(3 * N + K + 8) * sizeof(double);
@@ -347,41 +485,93 @@ int pb_op_adjoint(const double* r, int64_t ldr, double* out, int64_t ldo, int V,
 
 int pb_hrf_cost(const double* z_dev, int64_t ldz, const float* y_dev, int64_t ldy, int V, int N,
                 const double* taps_dev, int K, int n_hrf, double* cost_dev, void* stream) {
-  if (!z_dev || !y_dev || !taps_dev || !cost_dev || V < 0 || N < 1 || K < 1 || n_hrf < 1 ||
-      ldz < N || ldy < N)
-    return fail(PB_ERR_INVALID, "pb_hrf_cost: bad argument");
-  if ((int64_t)N + K + 8 > LDS_DOUBLES_MAX) return fail(PB_ERR_INVALID, "pb_hrf_cost: exceeds LDS");
-  if (V == 0) return PB_OK;
-  const size_t lds = (size_t)(N + K + 8) * sizeof(double);
-  hipLaunchKernelGGL(pb::hrf_cost_kernel, dim3(V, n_hrf), dim3(pb::GEN_THREADS), lds,
-                     (hipStream_t)stream, z_dev, ldz, y_dev, ldy, V, N, taps_dev, K, cost_dev, 0);
-  return check_launch("hrf_cost_kernel");
+  return hrf_cost_impl<float>(z_dev, ldz, y_dev, ldy, V, N, taps_dev, K, n_hrf, cost_dev, 0, stream,
+                              "pb_hrf_cost");
 }
-
+int pb_hrf_cost_d(const double* z_dev, int64_t ldz, const double* y_dev, int64_t ldy, int V, int N,
+                  const double* taps_dev, int K, int n_hrf, double* cost_dev, void* stream) {
+  return hrf_cost_impl<double>(z_dev, ldz, y_dev, ldy, V, N, taps_dev, K, n_hrf, cost_dev, 0, stream,
+                               "pb_hrf_cost_d");
+}
 int pb_hrf_cost_pv(const double* z_dev, int64_t ldz, const float* y_dev, int64_t ldy, int V, int N,
                    const double* taps_dev, int K, int n_hrf, double* cost_dev, void* stream) {
-  if (!z_dev || !y_dev || !taps_dev || !cost_dev || V < 0 || N < 1 || K < 1 || n_hrf < 1 ||
-      ldz < N || ldy < N)
-    return fail(PB_ERR_INVALID, "pb_hrf_cost_pv: bad argument");
-  if ((int64_t)N + K + 8 > LDS_DOUBLES_MAX) return fail(PB_ERR_INVALID, "pb_hrf_cost_pv: exceeds LDS");
-  if (V == 0) return PB_OK;
-  const size_t lds = (size_t)(N + K + 8) * sizeof(double);
-  hipLaunchKernelGGL(pb::hrf_cost_kernel, dim3(V, n_hrf), dim3(pb::GEN_THREADS), lds,
-                     (hipStream_t)stream, z_dev, ldz, y_dev, ldy, V, N, taps_dev, K, cost_dev, 1);
-  return check_launch("hrf_cost_kernel");
+  return hrf_cost_impl<float>(z_dev, ldz, y_dev, ldy, V, N, taps_dev, K, n_hrf, cost_dev, 1, stream,
+                              "pb_hrf_cost_pv");
+}
+int pb_hrf_cost_pv_d(const double* z_dev, int64_t ldz, const double* y_dev, int64_t ldy, int V,
+                     int N, const double* taps_dev, int K, int n_hrf, double* cost_dev,
+                     void* stream) {
+  return hrf_cost_impl<double>(z_dev, ldz, y_dev, ldy, V, N, taps_dev, K, n_hrf, cost_dev, 1, stream,
+                               "pb_hrf_cost_pv_d");
 }
 
 int pb_gram_frobenius(const double* taps_dev, int64_t ldt, int P, int K, int N, double* out_dev,
                       void* stream) {
-  if (!taps_dev || !out_dev || P < 0 || K < 1 || N < 1 || ldt < K)
-    return fail(PB_ERR_INVALID, "pb_gram_frobenius: bad argument");
+  if (P < 0 || K < 1 || N < 1 || (P > 1 && ldt < K))
+    return fail(PB_ERR_INVALID, "pb_gram_frobenius: bad size");
   if ((int64_t)N + 8 > LDS_DOUBLES_MAX) return fail(PB_ERR_INVALID, "pb_gram_frobenius: exceeds LDS");
   if (P == 0) return PB_OK;
+  if (!taps_dev || !out_dev) return fail(PB_ERR_INVALID, "pb_gram_frobenius: NULL pointer");
   const size_t lds = (size_t)(N + 8) * sizeof(double);
   hipLaunchKernelGGL(pb::gram_frobenius_kernel, dim3(P), dim3(pb::GEN_THREADS), lds,
                      (hipStream_t)stream, taps_dev, ldt, K < N ? K : N, N, out_dev);
   return check_launch("gram_frobenius_kernel");
 }
+
+int pb_lambda_max(const float* y_dev, int64_t ldy, int V, int N, const double* taps_dev, int K,
+                  double* out_dev, void* stream) {
+  return lambda_max_impl<float>(y_dev, ldy, V, N, taps_dev, K, out_dev, stream, "pb_lambda_max");
+}
+int pb_lambda_max_d(const double* y_dev, int64_t ldy, int V, int N, const double* taps_dev, int K,
+                    double* out_dev, void* stream) {
+  return lambda_max_impl<double>(y_dev, ldy, V, N, taps_dev, K, out_dev, stream, "pb_lambda_max_d");
+}
+
+int pb_inf_norm(const double* x_dev, int64_t ldx, double* out_dev, int64_t ldo, int V, int64_t n,
+                void* stream) {
+  if (V < 0 || n < 1 || (V > 1 && (ldx < n || ldo < n)))
+    return fail(PB_ERR_INVALID, "pb_inf_norm: bad size");
+  if (V == 0) return PB_OK;
+  if (!x_dev || !out_dev) return fail(PB_ERR_INVALID, "pb_inf_norm: NULL pointer");
+  hipLaunchKernelGGL(pb::inf_norm_kernel, dim3(V), dim3(pb::GEN_THREADS), 0, (hipStream_t)stream,
+                     x_dev, ldx, out_dev, ldo, n);
+  return check_launch("pb_inf_norm");
+}
+
+int64_t pb_hrf_normal_eq_len(int K) { return K >= 1 ? (int64_t)pb::ne_len(K) : 0; }
+
+int pb_hrf_normal_eq(const double* z_dev, int64_t ldz, const float* y_dev, int64_t ldy, int V,
+                     int N, int K, int per_voxel, double* work_dev, int64_t work_len,
+                     double* out_dev, void* stream) {
+  return normal_eq_impl<float>(z_dev, ldz, y_dev, ldy, V, N, K, per_voxel, work_dev, work_len,
+                               out_dev, stream, "pb_hrf_normal_eq");
+}
+int pb_hrf_normal_eq_d(const double* z_dev, int64_t ldz, const double* y_dev, int64_t ldy, int V,
+                       int N, int K, int per_voxel, double* work_dev, int64_t work_len,
+                       double* out_dev, void* stream) {
+  return normal_eq_impl<double>(z_dev, ldz, y_dev, ldy, V, N, K, per_voxel, work_dev, work_len,
+                                out_dev, stream, "pb_hrf_normal_eq_d");
+}
+
+int pb_theta_fit(const double* ne_dev, int64_t ldne, int M, int K, const double* t_dev,
+                 double a_peak, double loc_peak, double a_under, double loc_under, double ratio,
+                 double lo, double hi, int n_refine, double* theta_dev, double* cost_dev,
+                 double* taps_dev, int64_t ldt, void* stream) {
+  if (M < 0 || K < 1 || K > 127 || n_refine < 1 || !(a_peak > 0.0) || !(a_under > 0.0) ||
+      !(lo <= hi) || (M > 1 && ldne < pb::ne_len(K)) || (taps_dev && M > 1 && ldt < K))
+    return fail(PB_ERR_INVALID, "pb_theta_fit: bad argument");
+  const int64_t nd = (int64_t)pb::ne_len(K) + 64 * (int64_t)K;
+  if (nd > LDS_DOUBLES_MAX) return fail(PB_ERR_INVALID, "pb_theta_fit: K=%d exceeds LDS", K);
+  if (M == 0) return PB_OK;
+  if (!ne_dev || !t_dev || !theta_dev || !cost_dev)
+    return fail(PB_ERR_INVALID, "pb_theta_fit: NULL pointer");
+  pb::HrfModel hm{a_peak, loc_peak, lgamma(a_peak), a_under, loc_under, lgamma(a_under), ratio};
+  hipLaunchKernelGGL(pb::theta_fit_kernel, dim3(M), dim3(64), (size_t)nd * sizeof(double),
+                     (hipStream_t)stream, ne_dev, ldne, M, K, t_dev, hm, lo, hi, n_refine, theta_dev,
+                     cost_dev, taps_dev, ldt);
+  return check_launch("pb_theta_fit");
+}
+
 
 int pb_fista_solve_pp(const float* y_dev, int64_t ldy, double* w_dev, int64_t ldw, int P, int N,
                       const double* taps_dev, int64_t ldt, int K, const double* step_dev,
@@ -389,28 +579,32 @@ int pb_fista_solve_pp(const float* y_dev, int64_t ldy, double* w_dev, int64_t ld
                       int stop_mode, double tol, int32_t* n_done_dev, unsigned flags, void* stream) {
   if (P < 0 || N < 1 || K < 1 || n_iter < 0)
     return fail(PB_ERR_INVALID, "pb_fista_solve_pp: bad size (P=%d N=%d K=%d n_iter=%d)", P, N, K, n_iter);
-  if (P > (1 << 27)) return fail(PB_ERR_INVALID, "pb_fista_solve_pp: more than 2^27 problems per launch");
+  if (P > (1 << 25)) return fail(PB_ERR_INVALID, "pb_fista_solve_pp: more than 2^25 problems per launch");
+  if (ldy < N || ldw < N || (ldt != 0 && ldt < K))
+    return fail(PB_ERR_INVALID, "pb_fista_solve_pp: leading dimension too small");
   if (P == 0) return PB_OK;
   if (!y_dev || !w_dev || !taps_dev || !step_dev || (n_iter > 0 && !betas_dev))
     return fail(PB_ERR_INVALID, "pb_fista_solve_pp: NULL pointer");
-  if (ldy < N || ldw < N || ldt < K) return fail(PB_ERR_INVALID, "pb_fista_solve_pp: leading dimension too small");
   if (stop_mode != PB_STOP_NONE && stop_mode != PB_STOP_LOOPS)
     return fail(PB_ERR_INVALID, "pb_fista_solve_pp: stop_mode must be PB_STOP_NONE or PB_STOP_LOOPS");
 
   pb::FistaArgs a;
-  a.y = y_dev; a.ldy = ldy; a.w = w_dev; a.ldw = ldw; a.lbda_vec = lbda_dev; a.betas = betas_dev;
-  a.J = nullptr; a.ldj = 0; a.n_done = n_done_dev; a.step = 0.0; a.lbda = lbda; a.tol = tol;
+  a.y = y_dev; a.y64 = nullptr; a.ldy = ldy; a.w = w_dev; a.ldw = ldw; a.lbda_vec = lbda_dev;
+  a.betas = betas_dev; a.J = nullptr; a.J64 = nullptr; a.ldj = 0; a.n_done = n_done_dev;
+  a.step = 0.0; a.lbda = lbda; a.tol = tol;
   a.y_rep = 1; a.P = P; a.N = N; a.n_iter = n_iter; a.stop_mode = stop_mode;
-  a.taps_pp = taps_dev; a.ldt = ldt; a.step_vec = step_dev; a.K = K;
+  a.taps_pp = taps_dev; a.ldt = ldt; a.step_vec = step_dev; a.step_shared = (ldt == 0); a.K = K;
 
   const FastEntry* fe = (flags & PB_FLAG_FORCE_GENERIC) ? nullptr : pick_fast(N, K);
   if (fe) {
-    fe->fn_pp(a, stop_mode, (hipStream_t)stream);
+    if (fe->fn_pp(a, stop_mode, (hipStream_t)stream) != 0)
+      return fail(PB_ERR_INVALID, "pb_fista_solve_pp: launch rejected");
     return check_launch("fista_fast_kernel(pp)");
   }
   if (!(flags & PB_FLAG_FORCE_GENERIC)) {
     if (const WideEntry* we = pick_wide(N, K)) {
-      we->fn_pp(a, stop_mode, (hipStream_t)stream);
+      if (we->fn_pp(a, stop_mode, (hipStream_t)stream) != 0)
+        return fail(PB_ERR_INVALID, "pb_fista_solve_pp: launch rejected");
       return check_launch("fista_fast_kernel(wide, pp)");
     }
   }

@@ -36,17 +36,20 @@ namespace pb {
 
 struct FistaArgs {
   const float* y;         // [ceil(P/y_rep)][ldy]
+  const double* y64;      // the same in float64 (all-float64 LDS kernel only) or nullptr
   int64_t ldy;
   double* w;              // [P][ldw] in: warm start, out: final iterate
   int64_t ldw;
   const double* lbda_vec; // [P] or nullptr
   const double* betas;    // [n_iter]
   float* J;               // [P][ldj] or nullptr
+  double* J64;            // float64 cost trace (all-float64 LDS kernel only) or nullptr
   int64_t ldj;
   int32_t* n_done;        // [P] or nullptr
   const double* taps_pp;  // [P][ldt] per-problem HRF taps (K of them) or nullptr
   int64_t ldt;
   const double* step_vec; // [P] per-problem step (goes with taps_pp) or nullptr
+  int step_shared;        // 1: taps_pp / step_vec hold ONE HRF / step used by every problem
   double step;
   double lbda;
   double tol;
@@ -103,9 +106,9 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
   static_assert(D <= 15, "halo spans more than one DPP row");
   using TP = TapPairs<KT>;
 
-  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int sub = threadIdx.x & (LPV - 1);  // lane within the problem's segment
-  const int prob = gid / LPV;
+  const int prob = (int)(gid / LPV);
   const bool live = prob < a.P;
   const int p = live ? prob : a.P - 1;
   const int base = sub * S;
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
     asm volatile("" : "+v"(mk[j]));
   }
   const double lb = a.lbda_vec ? a.lbda_vec[p] : a.lbda;
-  const double stp = PP ? a.step_vec[p] : a.step;
+  const double stp = PP ? a.step_vec[a.step_shared ? 0 : p] : a.step;
   const double th = lb * stp;
   const double nstep = -stp;
   const float lbf = (float)lb;
@@ -173,6 +176,10 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
     ring = reinterpret_cast<float*>(fast_smem) + ((threadIdx.x / LPV) * 4 * S * LPV + sub);
 #pragma unroll
     for (int j = 0; j < S; ++j) uprev[j] = 0.0;
+    // slots 1..3 are read (as delta_{k-1..k-3}) before iterations 1..3 have written them;
+    // each lane owns its slots, so it zeroes them itself and no barrier is needed
+#pragma unroll
+    for (int q = 0; q < 4 * S; ++q) ring[q * LPV] = 0.0f;
   }
 
   bool active = live;                       // per-problem (row-uniform) early-stop state; idle rows never hold a wave
@@ -356,7 +363,8 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
       den = seg_allsum_f64<LPV>(den);
       if (active) {
         done = it + 1;
-        const int first_test = (STOP == 1) ? 3 : WIND + 1;
+        constexpr int first_test = (STOP == 1) ? 3 : WIND + 1;
+        static_assert(STOP != 2 || first_test >= 4, "the increment ring holds 4 valid slots from it = 3 on");
         if (it >= first_test && sqrt(num) / (sqrt(den) + floor_eps) < a.tol) active = false;
       }
       if (__builtin_amdgcn_ballot_w64(active) == 0) n_stop = it + 1;

@@ -202,8 +202,9 @@ __global__ __launch_bounds__(GEN_THREADS) void gram_frobenius_kernel(const doubl
 // cost[c][v] = 0.5 || y_v - taps * z_v ||^2 ; grid = (V, n_hrf).  taps index:
 // shared candidates taps[c][K] (per_voxel = 0) or one HRF per (candidate, voxel)
 // taps[c][v][K] (per_voxel = 1).
+template <typename TY>
 __global__ __launch_bounds__(GEN_THREADS) void hrf_cost_kernel(const double* z, int64_t ldz,
-                                                               const float* y, int64_t ldy, int V,
+                                                               const TY* y, int64_t ldy, int V,
                                                                int N, const double* taps, int K,
                                                                double* cost, int per_voxel) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(GEN_THREADS) void hrf_cost_kernel(const double* z, 
   double* red = k + K;
   const int v = blockIdx.x, c = blockIdx.y;
   const double* zr = z + (int64_t)v * ldz;
-  const float* yr = y + (int64_t)v * ldy;
+  const TY* yr = y + (int64_t)v * ldy;
   const double* tc = taps + (per_voxel ? ((int64_t)c * V + v) * K : (int64_t)c * K);
   for (int i = threadIdx.x; i < N; i += GEN_THREADS) a[i] = zr[i];
   for (int i = threadIdx.x; i < K; i += GEN_THREADS) k[i] = tc[i];
@@ -273,8 +274,9 @@ __global__ __launch_bounds__(GEN_THREADS) void power_iter_kernel(const double* x
 
 // r2[p] = || taps * cumsum(w_p) - y_p ||^2 , l1[p] = || w_p ||_1
 // (the quantities R, G the lambda search tracks, pybold/bold_signal.py:141-157)
+template <typename TY>
 __global__ __launch_bounds__(GEN_THREADS) void stats_kernel(const double* w, int64_t ldw,
-                                                            const float* y, int64_t ldy, int y_rep,
+                                                            const TY* y, int64_t ldy, int y_rep,
                                                             int N, const double* taps, int K,
                                                             double* r2, double* l1) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(GEN_THREADS) void stats_kernel(const double* w, int
   double* red = k + K;
   const int p = blockIdx.x;
   const double* wr = w + (int64_t)p * ldw;
-  const float* yr = y + (int64_t)(p / y_rep) * ldy;
+  const TY* yr = y + (int64_t)(p / y_rep) * ldy;
   double part_l1 = 0.0;
   for (int i = threadIdx.x; i < N; i += GEN_THREADS) {
     a[i] = wr[i];
@@ -307,11 +309,72 @@ __global__ __launch_bounds__(GEN_THREADS) void stats_kernel(const double* w, int
   }
 }
 
+// max of one double per thread, result in every thread; red = 2*GEN_WAVES doubles of LDS
+__device__ __forceinline__ double block_max(double v, double* red) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  const int wid = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[wid] = v;
+  __syncthreads();
+  double s = red[0];
+#pragma unroll
+  for (int i = 1; i < GEN_WAVES; ++i) s = fmax(s, red[i]);
+  return s;
+}
+
+// out[v] = || H^T y_v ||_inf, H = toeplitz(taps) . cumsum: the smallest lambda for which
+// the solution of min 0.5||H w - y||^2 + lambda ||w||_1 is w = 0, i.e. the top of a
+// regularisation path (the reference hard-codes its lambda lists,
+// examples/icassp_2019/simulation.py:113-114).  LDS: a[N] b[N] k[K] red[8].
+template <typename TY>
+__global__ __launch_bounds__(GEN_THREADS) void lambda_max_kernel(const TY* y, int64_t ldy, int N,
+                                                                 const double* taps, int K,
+                                                                 double* out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* a = reinterpret_cast<double*>(smem);
+  double* b = a + N;
+  double* k = b + N;
+  double* red = k + K;
+  const TY* yr = y + (int64_t)blockIdx.x * ldy;
+  for (int i = threadIdx.x; i < N; i += GEN_THREADS) a[i] = (double)yr[i];
+  for (int i = threadIdx.x; i < K; i += GEN_THREADS) k[i] = taps[i];
+  __syncthreads();
+  block_corr(a, N, b, N, k, K);
+  block_cumsum<true>(b, b, N, red);
+  double m = 0.0;
+  for (int i = threadIdx.x; i < N; i += GEN_THREADS) m = fmax(m, fabs(b[i]));
+  m = block_max(m, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = m;
+}
+
+// out = x / (max|x| + 1e-12) per row (inf_norm, pybold/utils.py:112-138); rows of any length
+// (two passes over global memory, nothing staged)
+__global__ __launch_bounds__(GEN_THREADS) void inf_norm_kernel(const double* x, int64_t ldx,
+                                                               double* out, int64_t ldo, int64_t n) {
+  __shared__ double red[2 * GEN_WAVES];
+  const double* xr = x + (int64_t)blockIdx.x * ldx;
+  double* orow = out + (int64_t)blockIdx.x * ldo;
+  double m = 0.0, has_nan = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += GEN_THREADS) {
+    const double v = fabs(xr[i]);
+    m = fmax(m, v);
+    if (v != v) has_nan = 1.0;                 // np.max propagates NaN, fmax drops it
+  }
+  m = block_max(m, red);
+  has_nan = block_max(has_nan, red);
+  const double d = (has_nan > 0.0 ? __builtin_nan("") : m) + 1.0e-12;
+  for (int64_t i = threadIdx.x; i < n; i += GEN_THREADS) orow[i] = xr[i] / d;
+}
+
 // ---- generic FISTA: one workgroup per problem, float64 state in LDS ---------
 // LDS: w[N] a[N] b[N] k[K] red[8] hist[wind*N] (window rule only)
-template <bool WITH_J>
+// F64IO: y and the cost trace are float64 (a_.y64 / a_.J64): the reference's arithmetic
+// end to end, used for single-voxel / small-batch calls (pb_fista_solve_d).
+template <bool WITH_J, bool F64IO = false>
 __global__ __launch_bounds__(GEN_THREADS) void fista_generic_kernel(FistaArgs a_, const double* taps,
                                                                     int K, int wind) {
+  using TY = std::conditional_t<F64IO, double, float>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int N = a_.N;
   double* w = reinterpret_cast<double*>(smem);
@@ -321,17 +384,25 @@ __global__ __launch_bounds__(GEN_THREADS) void fista_generic_kernel(FistaArgs a_
   double* red = k + K;
   double* hist = red + 2 * GEN_WAVES;
   const int p = blockIdx.x;
-  const float* yr = a_.y + (int64_t)(p / a_.y_rep) * a_.ldy;
+  const TY* yr = [&] {
+    if constexpr (F64IO) return a_.y64 + (int64_t)(p / a_.y_rep) * a_.ldy;
+    else return a_.y + (int64_t)(p / a_.y_rep) * a_.ldy;
+  }();
   double* wrow = a_.w + (int64_t)p * a_.ldw;
   const double* tp = a_.taps_pp ? a_.taps_pp + (int64_t)p * a_.ldt : taps;
-  const double stp = a_.step_vec ? a_.step_vec[p] : a_.step;
+  const double stp = a_.step_vec ? a_.step_vec[a_.step_shared ? 0 : p] : a_.step;
   for (int i = threadIdx.x; i < N; i += GEN_THREADS) w[i] = wrow[i];
   for (int i = threadIdx.x; i < K; i += GEN_THREADS) k[i] = tp[i];
   __syncthreads();
   const double lb = a_.lbda_vec ? a_.lbda_vec[p] : a_.lbda;
   const double th = lb * stp;
   const int stop = a_.stop_mode;
-  float* Jrow = WITH_J ? a_.J + (int64_t)p * a_.ldj : nullptr;
+  using TJ = std::conditional_t<F64IO, double, float>;
+  TJ* Jrow = nullptr;
+  if constexpr (WITH_J) {
+    if constexpr (F64IO) Jrow = a_.J64 + (int64_t)p * a_.ldj;
+    else Jrow = a_.J + (int64_t)p * a_.ldj;
+  }
 
   int n_stop = a_.n_iter;   // iterations to execute (shrinks when the stop rule fires)
   int it = 0;
@@ -348,7 +419,7 @@ __global__ __launch_bounds__(GEN_THREADS) void fista_generic_kernel(FistaArgs a_
         for (int i = threadIdx.x; i < N; i += GEN_THREADS)
           part += 0.5 * b[i] * b[i] + lb * fabs(w[i]);
         const double cost = block_sum(part, red);
-        if (threadIdx.x == 0) Jrow[it - 1] = (float)cost;
+        if (threadIdx.x == 0) Jrow[it - 1] = (TJ)cost;
       }
       if (it >= n_stop) break;
     }

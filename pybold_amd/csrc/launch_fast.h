@@ -43,6 +43,8 @@ int launch_wide(const FistaArgs& a, const double* taps, int K, bool with_j, int 
       const size_t lds = (size_t)4 * 4 * S * 64 * sizeof(float);
       if (with_j) hipLaunchKernelGGL((fista_fast_kernel<S, KT, true, 2, false, 64>), grid, block, lds, st, a, tp);
       else hipLaunchKernelGGL((fista_fast_kernel<S, KT, false, 2, false, 64>), grid, block, lds, st, a, tp);
+    } else {
+      return 1;   // no increment ring for S > 20: the caller must not come here
     }
   }
   return 0;

@@ -3,15 +3,24 @@
 Voxels (and (voxel, lambda) problems) are independent, so the fixed-HRF solves
 need NO collective: each rank runs :func:`solver.fista_solve` on
 its shard.  The only exchange step of the path is the shared-HRF variant of the
-blind step: one all-reduce (SUM) of two float64 values per evaluation of
+blind step, which minimises
 
     F(theta) = sum_ranks sum_v 0.5 || y_v - h(theta) * z_v ||^2
 
 (the reference fits one theta per voxel with ``hrf_fit_err``,
 pybold/bold_signal.py:217-222, :329-333; for a single voxel on a single rank
-the functions below reduce to exactly that).  ``torch.distributed`` carries it:
-backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.  The
-message is 16 bytes, i.e. latency-bound; link bandwidth is irrelevant.
+the functions below reduce to exactly that).  ``F`` is a quadratic form in the K
+taps, so each rank makes ONE pass over its shard for the normal equations
+``(G, b, yy)`` (``pb_hrf_normal_eq``), ONE all-reduce (SUM) of ``K*K + K + 2``
+float64 (~6 kB, latency-bound: xGMI link bandwidth is irrelevant) makes them
+global, and every rank runs the identical 1-D search on those numbers
+(``pb_theta_fit``, one wave) -- no per-candidate pass, no host round trip: theta,
+the new taps and the step constant stay in HBM and feed the next z-step
+(``pb_fista_solve_pp`` with shared taps).  ``torch.distributed`` carries the
+all-reduce: backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
+``theta_solver="lbfgsb"`` keeps the reference's optimiser (SciPy L-BFGS-B with a
+finite-difference gradient, one all-reduce of two float64 per evaluation) for
+the single-voxel equivalence tests.
 """
 import numpy as np
 import torch
@@ -51,6 +60,19 @@ class Comm:
     def rank(self):
         return self.dist.get_rank(self.group) if self.dist else 0
 
+    def allreduce_(self, t):
+        """In-place SUM over ranks of a float64 tensor living on the compute device; no
+        host synchronisation on the RCCL path (gloo reduces a host copy)."""
+        if self.dist is None:
+            return t
+        if t.device.type == self.device.type:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        else:
+            c = t.to(self.device)
+            self.dist.all_reduce(c, op=self.dist.ReduceOp.SUM, group=self.group)
+            t.copy_(c)
+        return t
+
     def allreduce_sum(self, values):
         """SUM of a small float64 vector over ranks; returns a NumPy array."""
         v = np.atleast_1d(np.asarray(values, dtype=np.float64))
@@ -86,17 +108,95 @@ def shared_theta_fit(local_cost, theta0, bounds, comm, maxiter=999, pgtol=1.0e-1
     return float(theta[0]), float(f), n_evals[0]
 
 
+class HipOps:
+    """The compute steps of :func:`bd_shared`, each one (or two) launches of the HIP
+    library on the current stream; nothing returns to the host.  (The gloo test of the
+    multi-rank logic substitutes the CPU oracle for this class.)"""
+
+    def __init__(self, t_r, hrf_dur, n):
+        from . import solver
+        self.s, self.t_r, self.hrf_dur, self.n = solver, t_r, hrf_dur, n
+        self.work = None
+
+    def hrf(self, theta):                       # (1,) -> (K,)
+        return self.s.spm_hrf_batch(theta, self.t_r, self.hrf_dur)[0]
+
+    def z_step(self, Y, taps, lbda, nb_inner, W):
+        step = 1.0 / self.s.gram_frobenius_batch(taps.reshape(1, -1), self.n)    # (1,)
+        W, _ = self.s.fista_solve_pp(Y, taps, step, lbda, nb_inner, W0=W, inplace=True)
+        return W
+
+    def normal_eq(self, W, Y, K):
+        Z = self.s.integ_op(W)
+        if self.work is None:
+            self.work = torch.empty((512 * (K * K + K + 1),), dtype=torch.float64, device=Y.device)
+        return self.s.hrf_normal_eq(Z, Y, K, work=self.work)
+
+    def theta_fit(self, ne, bounds):            # -> theta (1,), F(theta) (1,), taps (K,)
+        theta, f, taps = self.s.theta_fit(ne, self.t_r, self.hrf_dur, bounds)
+        return theta, f, taps[0]
+
+
 def bd_shared(Y, t_r, lbda=1.0, theta_0=None, hrf_dur=20.0, bounds=None, nb_iter=20,
-              nb_inner=100, comm=None, verbose=0):
+              nb_inner=100, comm=None, verbose=0, theta_solver="device", ops=None):
     """Semi-blind deconvolution with ONE HRF dilation shared by all voxels of
     all ranks (BASELINE config 4).  ``Y`` is this rank's shard, float32 CUDA
-    ``(V_local, N)``.  Structure of ``bd`` (pybold/bold_signal.py:281-382): outer
-    loop of z-step (``nb_inner`` iterations of the ``_loops_deconv`` recurrence,
-    step ``1/||A^T A||_F``, warm-started) and theta-step (:func:`shared_theta_fit`).
+    ``(V_local, N)`` (may be empty).  Structure of ``bd``
+    (pybold/bold_signal.py:281-382): outer loop of z-step (``nb_inner`` iterations
+    of the ``_loops_deconv`` recurrence, step ``1/||A^T A||_F``, warm-started) and
+    theta-step (see the module docstring), then a last z-step (:365-369).
 
     Returns ``(W float64 CUDA (V_local, N), h, d)`` with ``d['theta']``,
-    ``d['J']`` (global normalised cost per outer iteration) and ``d['evals']``.
+    ``d['J']`` (global normalised cost per outer iteration) and ``d['evals']``
+    (cost evaluations per theta-step: passes over the data for "lbfgsb", 1 for
+    "device").  With ``theta_solver="device"`` nothing is copied to the host before
+    the loop ends.
     """
+    if theta_solver == "lbfgsb":
+        return _bd_shared_lbfgsb(Y, t_r, lbda, theta_0, hrf_dur, bounds, nb_iter, nb_inner, comm,
+                                 verbose)
+    if theta_solver != "device":
+        raise ValueError("theta_solver must be 'device' or 'lbfgsb'")
+    comm = comm or Comm()
+    dev = Y.device
+    V, n = Y.shape
+    ops = ops or HipOps(t_r, hrf_dur, n)
+    theta0 = MAX_DELTA if theta_0 is None else float(theta_0)
+    if theta0 < MIN_DELTA or theta0 > MAX_DELTA:
+        raise ValueError("theta_0 must lie in [%g, %g]" % (MIN_DELTA, MAX_DELTA))
+    if bounds is None:
+        bounds = [(MIN_DELTA + 1.0e-1, MAX_DELTA - 1.0e-1)]
+    theta = torch.full((1,), theta0, dtype=torch.float64, device=dev)
+    taps = ops.hrf(theta)                                        # (K,), stays on the device
+    K = taps.numel()
+    ne_len = K * K + K + 1
+    W = torch.zeros((V, n), dtype=torch.float64, device=dev)
+    msg = torch.empty((ne_len + 1,), dtype=torch.float64, device=dev)
+    thetas, costs = [theta], []
+    for it in range(nb_iter + 1):
+        W = ops.z_step(Y, taps, lbda, nb_inner, W)
+        msg[:ne_len] = ops.normal_eq(W, Y, K)
+        msg[ne_len] = W.abs().sum()
+        comm.allreduce_(msg)                     # the ONE collective of the outer iteration
+        ne = msg[:ne_len]
+        if it < nb_iter:
+            theta, f, taps = ops.theta_fit(ne, bounds[0])
+            thetas.append(theta)
+        else:                                    # last z-step: price the current HRF
+            G, b = ne[:K * K].reshape(K, K), ne[K * K:K * K + K]
+            f = (0.5 * ne[ne_len - 1] - taps.dot(b) + 0.5 * taps.dot(G.mv(taps))).reshape(1)
+        costs.append((2.0 * f + lbda * msg[ne_len]) / ne[ne_len - 1])
+        if verbose > 0 and comm.rank == 0:
+            print("bd_shared outer %d: theta=%.6f J=%.6f" % (it, float(theta), float(costs[-1])))
+    d = {"theta": torch.cat(thetas).cpu().numpy(),
+         "J": np.concatenate([[1.0], torch.cat(costs).cpu().numpy()]),
+         "evals": [1] * nb_iter}
+    return W, taps.cpu().numpy(), d
+
+
+def _bd_shared_lbfgsb(Y, t_r, lbda, theta_0, hrf_dur, bounds, nb_iter, nb_inner, comm, verbose):
+    """``bd_shared`` with the reference's optimiser in the loop: SciPy L-BFGS-B on the host,
+    every cost evaluation a pass over the data (``pb_hrf_cost``) + a 16-byte all-reduce."""
     from . import solver
     from .utils import gram_frobenius
     comm = comm or Comm()

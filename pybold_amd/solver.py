@@ -75,6 +75,14 @@ def _rows(t, dtype, name):
     return t
 
 
+def _y_rows(Y, fn_f32, fn_f64):
+    """Observed series are float32 (batch layout) or float64 (reference arithmetic):
+    returns the checked tensor and the matching entry point."""
+    if torch.is_tensor(Y) and Y.dtype == torch.float64:
+        return _rows(Y, torch.float64, "Y"), fn_f64
+    return _rows(Y, torch.float32, "Y"), fn_f32
+
+
 def _ld(t):
     """Leading dimension in elements (a single-row view may report stride 0)."""
     return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
@@ -100,7 +108,9 @@ def fista_solve(Y, hrf, lbda, step, n_iter, W0=None, want_J=False, stop=None,
     """Run ``n_iter`` iterations of the reference recurrence
     (pybold/bold_signal.py:62-72, :259-276) for every row of ``Y`` in one launch.
 
-    Y     float32 CUDA ``(V, N)``
+    Y     float32 CUDA ``(V, N)`` (the batch layout; register-resident kernels), or
+          float64 CUDA ``(V, N)``: all-float64 LDS kernel (``pb_fista_solve_d``), the
+          reference's arithmetic end to end -- what the 1-D calls of the API use
     hrf   1-D array of K taps (host)
     lbda  scalar, or array/tensor of ``V * y_rep`` per-problem values
     step  ``1 / L``
@@ -109,7 +119,8 @@ def fista_solve(Y, hrf, lbda, step, n_iter, W0=None, want_J=False, stop=None,
     Returns ``(W float64 (P, N), J float32 (P, n_iter) or None, n_done int32 (P,))``.
     """
     lib = _lib.load()
-    Y = _rows(Y, torch.float32, "Y")
+    f64 = torch.is_tensor(Y) and Y.dtype == torch.float64
+    Y = _rows(Y, torch.float64 if f64 else torch.float32, "Y")
     dev = Y.device
     V, N = Y.shape
     P = V * int(y_rep)
@@ -130,10 +141,24 @@ def fista_solve(Y, hrf, lbda, step, n_iter, W0=None, want_J=False, stop=None,
         if lbda_dev.numel() != P:
             raise ValueError("per-problem lbda must have %d entries" % P)
     betas = _betas_on(dev, n_iter)
-    J = torch.empty((P, max(n_iter, 1)), dtype=torch.float32, device=dev) if want_J else None
+    J = torch.empty((P, max(n_iter, 1)), dtype=torch.float64 if f64 else torch.float32,
+                    device=dev) if want_J else None
     if J is not None:
         J.fill_(float("nan"))
     n_done = torch.empty((P,), dtype=torch.int32, device=dev)
+    if f64:
+        if force not in (None, "generic"):
+            raise ValueError("float64 y runs on the all-float64 LDS kernel only")
+        with torch.cuda.device(dev):
+            rc = lib.pb_fista_solve_d(
+                Y.data_ptr(), _ld(Y), int(y_rep), W.data_ptr(), _ld(W), P, N,
+                taps_dev.data_ptr(), taps.size, float(step), lbda_scalar,
+                lbda_dev.data_ptr() if lbda_dev is not None else None,
+                betas.data_ptr(), int(n_iter),
+                J.data_ptr() if J is not None else None, _ld(J) if J is not None else 0,
+                _STOP[stop], float(tol), int(wind), n_done.data_ptr(), _stream_ptr(dev))
+        _lib.check(rc, "pb_fista_solve_d")
+        return W, J, n_done
     with torch.cuda.device(dev):
         rc = lib.pb_fista_solve(
             Y.data_ptr(), _ld(Y), int(y_rep), W.data_ptr(), _ld(W), P, N,
@@ -213,14 +238,14 @@ def fista_stats(W, Y, hrf, y_rep=1):
     each): the R / G terms of pybold/bold_signal.py:141-157."""
     lib = _lib.load()
     W = _rows(W, torch.float64, "W")
-    Y = _rows(Y, torch.float32, "Y")
+    Y, fn = _y_rows(Y, lib.pb_fista_stats, lib.pb_fista_stats_d)
     dev = W.device
     P, N = W.shape
     taps_dev = torch.from_numpy(_as_taps(hrf)).to(dev)
     r2 = torch.empty((P,), dtype=torch.float64, device=dev)
     l1 = torch.empty((P,), dtype=torch.float64, device=dev)
     with torch.cuda.device(dev):
-        rc = lib.pb_fista_stats(W.data_ptr(), _ld(W), Y.data_ptr(), _ld(Y), int(y_rep), P, N,
+        rc = fn(W.data_ptr(), _ld(W), Y.data_ptr(), _ld(Y), int(y_rep), P, N,
                                 taps_dev.data_ptr(), taps_dev.numel(), r2.data_ptr(),
                                 l1.data_ptr(), _stream_ptr(dev))
     _lib.check(rc, "pb_fista_stats")
@@ -303,36 +328,56 @@ def hrf_cost(Z, Y, taps):
     ``(C, K)``; returns float64 ``(C, V)``."""
     lib = _lib.load()
     Z = _rows(Z, torch.float64, "Z")
-    Y = _rows(Y, torch.float32, "Y")
+    Y, fn = _y_rows(Y, lib.pb_hrf_cost, lib.pb_hrf_cost_d)
     dev = Z.device
     V, N = Z.shape
-    t = np.atleast_2d(np.asarray(taps, dtype=np.float64))
-    C, K = t.shape
-    t_dev = torch.from_numpy(np.ascontiguousarray(t)).to(dev)
+    if torch.is_tensor(taps):
+        t_dev = taps.to(device=dev, dtype=torch.float64).reshape(-1, taps.shape[-1]).contiguous()
+        C, K = t_dev.shape
+    else:
+        t = np.atleast_2d(np.asarray(taps, dtype=np.float64))
+        C, K = t.shape
+        t_dev = torch.from_numpy(np.ascontiguousarray(t)).to(dev)
     cost = torch.empty((C, V), dtype=torch.float64, device=dev)
     with torch.cuda.device(dev):
-        rc = lib.pb_hrf_cost(Z.data_ptr(), _ld(Z), Y.data_ptr(), _ld(Y), V, N,
+        rc = fn(Z.data_ptr(), _ld(Z), Y.data_ptr(), _ld(Y), V, N,
                              t_dev.data_ptr(), K, C, cost.data_ptr(), _stream_ptr(dev))
     _lib.check(rc, "pb_hrf_cost")
     return cost
 
 
 # ---- per-voxel HRFs (batched blind deconvolution) ---------------------------
-def fista_solve_pp(Y, taps, steps, lbda, n_iter, W0=None, stop=None, tol=0.0, force=None):
+def fista_solve_pp(Y, taps, steps, lbda, n_iter, W0=None, stop=None, tol=0.0, force=None,
+                   inplace=False):
     """:func:`fista_solve` with one HRF and one step per problem: ``taps`` float64
-    CUDA ``(V, K)``, ``steps`` float64 CUDA ``(V,)``.  Returns ``(W, n_done)``."""
+    CUDA ``(V, K)``, ``steps`` float64 CUDA ``(V,)`` -- or ONE HRF ``(K,)`` and ONE
+    step ``(1,)`` living in device memory and shared by every problem (the shared-HRF
+    blind step: taps come straight from :func:`theta_fit`).  ``inplace=True`` iterates
+    in ``W0`` itself instead of a copy.  Returns ``(W, n_done)``."""
     lib = _lib.load()
     Y = _rows(Y, torch.float32, "Y")
-    taps = _rows(taps, torch.float64, "taps")
     dev = Y.device
     V, N = Y.shape
-    if taps.shape[0] != V:
-        raise ValueError("taps must have one row per voxel")
+    shared = taps.dim() == 1          # ONE HRF / step in device memory for every problem
+    if shared:
+        if taps.dtype != torch.float64 or not taps.is_cuda:
+            raise TypeError("taps must be a float64 CUDA tensor")
+        taps = taps.contiguous().reshape(1, -1)
+    else:
+        taps = _rows(taps, torch.float64, "taps")
+        if taps.shape[0] != V:
+            raise ValueError("taps must have one row per voxel")
     steps = steps.to(device=dev, dtype=torch.float64).contiguous().ravel()
-    if steps.numel() != V:
-        raise ValueError("steps must have one entry per voxel")
-    W = torch.zeros((V, N), dtype=torch.float64, device=dev) if W0 is None else \
-        _rows(W0, torch.float64, "W0").clone()
+    if steps.numel() != (1 if shared else V):
+        raise ValueError("steps must have one entry per voxel (one in all for a shared HRF)")
+    if W0 is None:
+        W = torch.zeros((V, N), dtype=torch.float64, device=dev)
+    else:
+        W = _rows(W0, torch.float64, "W0")
+        if not inplace or W.data_ptr() != W0.data_ptr():
+            W = W.clone()
+        if W.shape != (V, N):
+            raise ValueError("W0 must be %s, got %s" % ((V, N), tuple(W.shape)))
     lbda_dev, lbda_scalar = None, 0.0
     if np.ndim(lbda) == 0 and not torch.is_tensor(lbda):
         lbda_scalar = float(lbda)
@@ -342,8 +387,8 @@ def fista_solve_pp(Y, taps, steps, lbda, n_iter, W0=None, stop=None, tol=0.0, fo
     n_done = torch.empty((V,), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         rc = lib.pb_fista_solve_pp(
-            Y.data_ptr(), _ld(Y), W.data_ptr(), _ld(W), V, N, taps.data_ptr(), _ld(taps),
-            taps.shape[1], steps.data_ptr(), lbda_scalar,
+            Y.data_ptr(), _ld(Y), W.data_ptr(), _ld(W), V, N, taps.data_ptr(),
+            0 if shared else _ld(taps), taps.shape[1], steps.data_ptr(), lbda_scalar,
             lbda_dev.data_ptr() if lbda_dev is not None else None, betas.data_ptr(), int(n_iter),
             _STOP[stop], float(tol), n_done.data_ptr(), _FORCE[force], _stream_ptr(dev))
     _lib.check(rc, "pb_fista_solve_pp")
@@ -372,7 +417,7 @@ def hrf_cost_pv(Z, Y, taps):
     float64 ``(C, V)``."""
     lib = _lib.load()
     Z = _rows(Z, torch.float64, "Z")
-    Y = _rows(Y, torch.float32, "Y")
+    Y, fn = _y_rows(Y, lib.pb_hrf_cost_pv, lib.pb_hrf_cost_pv_d)
     dev = Z.device
     V, N = Z.shape
     if taps.dim() != 3 or taps.shape[1] != V or taps.dtype != torch.float64:
@@ -381,7 +426,7 @@ def hrf_cost_pv(Z, Y, taps):
     C, _, K = taps.shape
     cost = torch.empty((C, V), dtype=torch.float64, device=dev)
     with torch.cuda.device(dev):
-        rc = lib.pb_hrf_cost_pv(Z.data_ptr(), _ld(Z), Y.data_ptr(), _ld(Y), V, N, taps.data_ptr(),
+        rc = fn(Z.data_ptr(), _ld(Z), Y.data_ptr(), _ld(Y), V, N, taps.data_ptr(),
                                 K, C, cost.data_ptr(), _stream_ptr(dev))
     _lib.check(rc, "pb_hrf_cost_pv")
     return cost
@@ -421,3 +466,99 @@ def spm_hrf_batch(deltas, t_r, dur, dt=0.001, p_delay=6, undershoot=16.0, p_disp
                             _stream_ptr(dev))
     _lib.check(rc, "pb_spm_hrf")
     return out.reshape(tuple(deltas.shape) + (K,))
+
+
+# ---- regularisation path, post-processing, theta-step on the device ------------
+def lambda_max(Y, hrf):
+    """``|| H^T y_v ||_inf`` per voxel (float64 ``(V,)``), ``H = toeplitz(hrf) . cumsum``:
+    the smallest ``lbda`` whose ``deconv`` solution is ``diff_z = 0``; a
+    regularisation path is ``lbda = c * lambda_max`` with ``c`` in ``(0, 1]``."""
+    lib = _lib.load()
+    Y, fn = _y_rows(Y, lib.pb_lambda_max, lib.pb_lambda_max_d)
+    dev = Y.device
+    V, N = Y.shape
+    taps_dev = torch.from_numpy(_as_taps(hrf)).to(dev)
+    out = torch.empty((V,), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = fn(Y.data_ptr(), _ld(Y), V, N, taps_dev.data_ptr(), taps_dev.numel(), out.data_ptr(),
+                _stream_ptr(dev))
+    _lib.check(rc, "pb_lambda_max")
+    return out
+
+
+def inf_norm_rows(X):
+    """``x / (max|x| + 1e-12)`` for every row of a float64 CUDA ``(V, n)`` tensor
+    (pybold/utils.py:112-115 applied row-wise)."""
+    lib = _lib.load()
+    X = _rows(X, torch.float64, "x")
+    dev = X.device
+    V, n = X.shape
+    out = torch.empty_like(X)
+    if n == 0:
+        return out
+    with torch.cuda.device(dev):
+        rc = lib.pb_inf_norm(X.data_ptr(), _ld(X), out.data_ptr(), _ld(out), V, n, _stream_ptr(dev))
+    _lib.check(rc, "pb_inf_norm")
+    return out
+
+
+def hrf_normal_eq(Z, Y, n_taps, per_voxel=False, work=None):
+    """One pass over ``(Z, Y)`` -> the normal equations of ``hrf_fit_err``
+    (pybold/bold_signal.py:217-222) in the ``K`` taps: ``G (K, K)``, ``b (K,)``, ``yy``
+    packed as ``K*K + K + 1`` float64 -- summed over voxels (``per_voxel=False``, shape
+    ``(len,)``; zeros for an empty shard) or one set per voxel (``(V, len)``)."""
+    lib = _lib.load()
+    Z = _rows(Z, torch.float64, "Z")
+    Y, fn = _y_rows(Y, lib.pb_hrf_normal_eq, lib.pb_hrf_normal_eq_d)
+    dev = Z.device
+    V, N = Z.shape
+    K = int(n_taps)
+    ne = int(lib.pb_hrf_normal_eq_len(K))
+    if per_voxel:
+        out = torch.empty((V, ne), dtype=torch.float64, device=dev)
+        work_ptr, work_len = None, 0
+    else:
+        out = torch.empty((ne,), dtype=torch.float64, device=dev)
+        if work is None or work.numel() < ne:
+            work = torch.empty((512 * ne,), dtype=torch.float64, device=dev)
+        work_ptr, work_len = work.data_ptr(), work.numel()
+    with torch.cuda.device(dev):
+        rc = fn(Z.data_ptr(), _ld(Z) if V else N, Y.data_ptr(), _ld(Y) if V else N, V, N, K,
+                int(bool(per_voxel)), work_ptr, work_len, out.data_ptr(), _stream_ptr(dev))
+    _lib.check(rc, "pb_hrf_normal_eq")
+    return out
+
+
+def hrf_sample_times(t_r, dur, dt=0.001):
+    """Sample times of ``spm_hrf(., t_r, dur)`` (pybold/hrf_model.py:25: the fine
+    ``linspace`` grid includes its end point, then decimation by ``int(t_r / dt)``)."""
+    return np.ascontiguousarray(np.linspace(0, dur, int(float(dur) / dt))[::int(t_r / dt)])
+
+
+def theta_fit(ne, t_r, dur, bounds, n_refine=3, dt=0.001, p_delay=6, undershoot=16.0, p_disp=1.0,
+              u_disp=1.0, p_u_ratio=0.167):
+    """``argmin_theta 0.5 ||y - h(theta) * z||^2`` over ``bounds = (lo, hi)`` from normal
+    equations (:func:`hrf_normal_eq`), entirely on the device: ``ne`` is ``(len,)`` (one
+    shared set) or ``(M, len)``.  Returns ``(theta (M,), cost (M,), taps (M, K))`` float64
+    CUDA tensors; nothing is copied to the host."""
+    lib = _lib.load()
+    one = ne.dim() == 1
+    ne2 = _rows(ne.reshape(1, -1) if one else ne, torch.float64, "ne")
+    dev = ne2.device
+    t = hrf_sample_times(t_r, dur, dt)
+    K = len(t)
+    if ne2.shape[1] != int(lib.pb_hrf_normal_eq_len(K)):
+        raise ValueError("normal equations do not match an HRF of %d taps" % K)
+    M = ne2.shape[0]
+    t_dev = torch.from_numpy(t).to(dev)
+    theta = torch.empty((M,), dtype=torch.float64, device=dev)
+    cost = torch.empty((M,), dtype=torch.float64, device=dev)
+    taps = torch.empty((M, K), dtype=torch.float64, device=dev)
+    lo, hi = float(bounds[0]), float(bounds[1])
+    with torch.cuda.device(dev):
+        rc = lib.pb_theta_fit(ne2.data_ptr(), _ld(ne2), M, K, t_dev.data_ptr(), p_delay / p_disp,
+                              dt / p_disp, undershoot / u_disp, dt / u_disp, p_u_ratio, lo, hi,
+                              int(n_refine), theta.data_ptr(), cost.data_ptr(), taps.data_ptr(),
+                              _ld(taps), _stream_ptr(dev))
+    _lib.check(rc, "pb_theta_fit")
+    return theta, cost, taps

@@ -61,10 +61,36 @@ def gram_frobenius(hrf, n):
     return np.sqrt(np.sum(weight * r * r))
 
 
-def inf_norm(x):
-    """``x / (max|x| + 1e-12)`` (pybold/utils.py:112-115), 1-D helper."""
-    x = np.asarray(x, dtype=np.float64)
-    return x / (np.max(np.abs(x)) + 1.0e-12)
+def _inf_norm(arr, axis=1):
+    """One array of :func:`inf_norm` (pybold/utils.py:118-130) on the GPU: 2-D arrays are
+    normalised along ``axis``, 1-D and 3-D arrays as a whole."""
+    import torch
+    from . import solver
+    on_device = torch.is_tensor(arr) and arr.is_cuda
+    t = arr if torch.is_tensor(arr) else torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64))
+    t = t.to(device=solver.device(t.device if on_device else None), dtype=torch.float64)
+    if t.dim() == 2:
+        if axis in (1, -1):
+            out = solver.inf_norm_rows(t)
+        elif axis in (0, -2):
+            out = solver.inf_norm_rows(t.t().contiguous()).t()
+        else:
+            raise ValueError("axis out of range for a 2-D array")
+    elif t.dim() in (1, 3):
+        out = solver.inf_norm_rows(t.reshape(1, -1)).reshape(t.shape)
+    else:
+        raise ValueError("inf-norm normalization only handle 1D, 2D or 3D arrays")
+    return out if on_device else out.cpu().numpy()
+
+
+def inf_norm(arrays, axis=1):
+    """Inf-norm normalisation ``x / (max|x| + 1e-12)`` of an array or of each array of a
+    list (pybold/utils.py:112-138), computed on the GPU (``pb_inf_norm``): NumPy in ->
+    NumPy float64 out, CUDA tensors in -> CUDA tensors out (no host round trip, e.g. on
+    the ``(V, N)`` outputs of a batched ``bd``)."""
+    if isinstance(arrays, list):
+        return [_inf_norm(a, axis=axis) for a in arrays]
+    return _inf_norm(arrays, axis=axis)
 
 
 # db3 decomposition high-pass filter (PyWavelets' Wavelet('db3').dec_hi)

@@ -1,0 +1,281 @@
+"""GPU tests of the round-2 additions, all through the C ABI: empty batches in every entry
+point, the all-float64 forms (1-D calls of the reference API), lambda_max, inf_norm and the
+theta-step on normal equations (pb_hrf_normal_eq + pb_theta_fit)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pybold_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+T_R, HRF_DUR = 0.75, 20.0
+
+
+def rel_rows(a, b):
+    a, b = np.atleast_2d(a), np.atleast_2d(b)
+    return (np.linalg.norm(a - b, axis=1) / (np.linalg.norm(b, axis=1) + 1e-300)).max()
+
+
+def dev32(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def dev64(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+
+
+@pytest.fixture(scope="module")
+def solver():
+    from pybold_amd import solver
+    assert torch.cuda.is_available()
+    return solver
+
+
+def blind_problem(n_vox=8, n=300, seed=0, theta=0.8, noise=0.05):
+    rng = np.random.RandomState(seed)
+    h = orc.spm_hrf(theta, T_R, HRF_DUR, False)[0]
+    Z = np.zeros((n_vox, n))
+    for v in range(n_vox):
+        for _ in range(5):
+            o = rng.randint(0, n - 30)
+            Z[v, o:o + rng.randint(8, 20)] += 1.0
+    Y = orc.causal_conv(h, Z) + noise * rng.randn(n_vox, n)
+    return Z, Y, h
+
+
+def test_empty_batch_in_every_wrapper(solver, golden):
+    """V = 0 / P = 0 / M = 0 is a no-op in every entry point (torch hands out NULL data
+    pointers for empty tensors); a shard may be empty (distributed.shard_bounds)."""
+    hrf = golden("case1")["hrf"]
+    N, K = 300, len(hrf)
+    Y0, Y0d = dev32(np.zeros((0, N))), dev64(np.zeros((0, N)))
+    W0 = dev64(np.zeros((0, N)))
+    for Y in (Y0, Y0d):
+        W, J, nd = solver.fista_solve(Y, hrf, 1.0, 1e-6, 5, want_J=True, stop="window", tol=1e-3)
+        assert W.shape == (0, N) and J.shape == (0, 5) and nd.shape == (0,)
+        r2, l1 = solver.fista_stats(W0, Y, hrf)
+        assert r2.shape == (0,) and l1.shape == (0,)
+        assert solver.hrf_cost(W0, Y, np.stack([hrf, hrf])).shape == (2, 0)
+        assert solver.hrf_cost_pv(W0, Y, dev64(np.zeros((3, 0, K)))).shape == (3, 0)
+        assert solver.lambda_max(Y, hrf).shape == (0,)
+        ne = solver.hrf_normal_eq(W0, Y, K)
+        assert ne.shape == (K * K + K + 1,) and float(ne.abs().max()) == 0.0     # zeros, not garbage
+        assert solver.hrf_normal_eq(W0, Y, K, per_voxel=True).shape == (0, K * K + K + 1)
+    for fn in (solver.integ_op, solver.integ_adj):
+        assert fn(W0).shape == (0, N)
+    for fn in (solver.conv, solver.corr, solver.op_forward, solver.op_adjoint):
+        assert fn(W0, hrf).shape == (0, N)
+    X, Z = solver.fista_outputs(W0, hrf)
+    assert X.shape == (0, N) and Z.shape == (0, N)
+    X, Z = solver.fista_outputs_pp(W0, dev64(np.zeros((0, K))))
+    assert X.shape == (0, N)
+    W, nd = solver.fista_solve_pp(Y0, dev64(np.zeros((0, K))), dev64(np.zeros(0)), 1.0, 5)
+    assert W.shape == (0, N)
+    W, nd = solver.fista_solve_pp(Y0, dev64(hrf), dev64([1e-6]), 1.0, 5)      # shared taps, no voxel
+    assert W.shape == (0, N)
+    assert solver.gram_frobenius_batch(dev64(np.zeros((0, K))), N).shape == (0,)
+    assert solver.spm_hrf_batch(dev64(np.zeros(0)), T_R, HRF_DUR).shape[0] == 0
+    assert solver.inf_norm_rows(W0).shape == (0, N)
+    th, c, t = solver.theta_fit(dev64(np.zeros((0, 27 * 27 + 27 + 1))), T_R, HRF_DUR, (0.6, 1.9))
+    assert th.shape == (0,) and t.shape == (0, 27)
+    # the batched blind solver and the auto-lambda branch on an empty batch
+    from pybold_amd import blind
+    X, Z, W, taps, d = blind.bd_batch(Y0, T_R, nb_iter=2)
+    assert X.shape == (0, N) and taps.shape[0] == 0
+
+
+def test_float64_solver_is_the_reference_arithmetic(solver, golden):
+    """pb_fista_solve_d: float64 end to end, golden grid at 1e-10 (the float32-FIR
+    kernels are held to 1e-5), cost trace at 1e-12, stop rules exact."""
+    g = golden("grid")
+    Y = np.stack([g["y_s%d" % s] for s in range(4)])
+    hrf, lip = g["hrf"], float(g["lip_s0"])
+    for lbda in (0.1, 1.0, 10.0):
+        for nit in (1, 2, 3, 10, 500):
+            W, J, nd = solver.fista_solve(dev64(Y), hrf, lbda, 1.0 / lip, nit, want_J=True)
+            ref = np.stack([g["dz_s%d_l%g_n%d" % (s, lbda, nit)] for s in range(4)])
+            assert rel_rows(W.cpu().numpy(), ref) < 1e-10, (lbda, nit)
+            assert J.dtype == torch.float64
+            if nit == 10 and lbda == 1.0:
+                for s in range(4):
+                    Js = J[s].cpu().numpy()
+                    np.testing.assert_allclose(Js / Js[0], g["J_s%d_l1_n10" % s], rtol=1e-11)
+    g1 = golden("case1")
+    W = dev64(g1["diff_z"][None])
+    r2, l1 = solver.fista_stats(W, dev64(g1["y"][None]), g1["hrf"])
+    assert float(r2[0]) == pytest.approx(np.sum(np.square(g1["x"] - g1["y"])), rel=1e-12)
+    with pytest.raises(ValueError):
+        solver.fista_solve(dev64(Y), hrf, 1.0, 1.0 / lip, 5, force="fast")
+
+
+def test_one_d_api_calls_match_goldens_tightly(golden):
+    """1-D calls of the reference API run float64 end to end: deconv / _loops_deconv /
+    hrf_fit_err reproduce the goldens at 1e-9 (batches: 1e-5)."""
+    import pybold_amd
+    g = golden("case1")
+    np.random.seed(0)
+    x, z, dz, J, _, _ = pybold_amd.deconv(g["y"], 1.0, g["hrf"], lbda=1.0, nb_iter=500,
+                                          early_stopping=False)
+    errs = (rel_rows(dz, g["diff_z"]), rel_rows(z, g["z"]), rel_rows(x, g["x"]))
+    print("1-D deconv vs golden (diff_z, z, x):", errs)
+    assert max(errs) < 1e-9
+    np.testing.assert_allclose(J, g["J"], rtol=1e-10)
+    gl = golden("loops_deconv")
+    H = pybold_amd.toeplitz_from_kernel(gl["h"], len(gl["y"]), len(gl["y"]))
+    w = pybold_amd._loops_deconv(gl["y"], np.zeros_like(gl["y"]), H, 1.7, 100, False, 4, 1e-12)
+    assert rel_rows(w, gl["w_n100_es0_tol1e-12"]) < 1e-9
+    gh = golden("hrf_estim")
+    for theta, err in zip(gh["thetas"], gh["errs"]):
+        got = pybold_amd.hrf_fit_err(theta, gh["z"], gh["y"], float(gh["t_r"]), float(gh["hrf_dur"]))
+        assert got == pytest.approx(err, rel=1e-12)
+
+
+def test_lambda_max(solver, golden):
+    g = golden("grid")
+    Y = np.stack([g["y_s%d" % s] for s in range(4)])
+    hrf, lip = g["hrf"], float(g["lip_s0"])
+    ref = orc.lambda_max(Y, hrf)
+    np.testing.assert_allclose(solver.lambda_max(dev64(Y), hrf).cpu().numpy(), ref, rtol=1e-12)
+    lm = solver.lambda_max(dev32(Y), hrf)
+    np.testing.assert_allclose(lm.cpu().numpy(), orc.lambda_max(Y.astype(np.float32), hrf), rtol=1e-12)
+    # at lambda_max the first prox step thresholds everything; just below it something survives
+    W, _, _ = solver.fista_solve(dev32(Y), hrf, lm * (1 + 1e-9), 1.0 / lip, 1)
+    assert float(W.abs().max()) == 0.0
+    W, _, _ = solver.fista_solve(dev32(Y), hrf, lm * 0.99, 1.0 / lip, 1)
+    assert (W.abs().amax(dim=1) > 0).all()
+
+
+def test_inf_norm_like_reference():
+    """pybold/utils.py:112-138 (and pybold/tests/test_utils.py:8-15: max |inf_norm(x)| == 1):
+    1-D, 2-D along both axes, 3-D, lists; NumPy in -> NumPy out, CUDA in -> CUDA out."""
+    from pybold_amd.utils import inf_norm
+    rng = np.random.RandomState(3)
+    a1, a2, a3 = rng.randn(1000) * 7, rng.randn(37, 300) * 3, rng.randn(4, 5, 60)
+    np.testing.assert_allclose(inf_norm(a1), orc.inf_norm(a1), rtol=1e-15)
+    assert np.max(np.abs(inf_norm(a1))) == pytest.approx(1.0, abs=1e-7)
+    np.testing.assert_allclose(inf_norm(a2), orc.inf_norm(a2), rtol=1e-15)
+    np.testing.assert_allclose(inf_norm(a2, axis=0), orc.inf_norm(a2, axis=0), rtol=1e-15)
+    np.testing.assert_allclose(inf_norm(a3), orc.inf_norm(a3), rtol=1e-15)
+    out = inf_norm([a1, a2, a3])
+    ref = orc.inf_norm([a1, a2, a3])
+    assert isinstance(out, list) and all(np.allclose(o, r, rtol=1e-15) for o, r in zip(out, ref))
+    t = inf_norm(dev64(a2))
+    assert torch.is_tensor(t) and t.is_cuda
+    np.testing.assert_allclose(t.cpu().numpy(), orc.inf_norm(a2), rtol=1e-15)
+    z = inf_norm(np.zeros(10))
+    assert np.all(z == 0.0)
+    bad = a1.copy()
+    bad[5] = np.nan
+    assert np.isnan(inf_norm(bad)).all()            # np.max propagates NaN
+    with pytest.raises(ValueError):
+        inf_norm(np.zeros((2, 2, 2, 2)))
+
+
+@pytest.mark.parametrize("n,K_dur", [(300, 20.0), (240, 20.0), (100, 15.0), (20, 20.0)])
+def test_normal_equations_match_dense_oracle(solver, n, K_dur):
+    t_hrf = solver.hrf_sample_times(T_R, K_dur)
+    K = len(t_hrf)
+    rng = np.random.RandomState(n)
+    Z = np.cumsum((rng.rand(11, n) < 0.06) * rng.randn(11, n), axis=1)
+    Y = rng.randn(11, n)
+    G, b, yy = orc.hrf_normal_eq(Z, Y, K)
+    ref = np.concatenate([G.ravel(), b, [yy]])
+    ne = solver.hrf_normal_eq(dev64(Z), dev64(Y), K).cpu().numpy()
+    np.testing.assert_allclose(ne, ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
+    ne32 = solver.hrf_normal_eq(dev64(Z), dev32(Y), K).cpu().numpy()
+    np.testing.assert_allclose(ne32, ref, rtol=1e-5, atol=1e-6 * np.abs(ref).max())
+    pv = solver.hrf_normal_eq(dev64(Z), dev64(Y), K, per_voxel=True).cpu().numpy()
+    for v in range(11):
+        Gv, bv, yyv = orc.hrf_normal_eq(Z[v], Y[v], K)
+        refv = np.concatenate([Gv.ravel(), bv, [yyv]])
+        np.testing.assert_allclose(pv[v], refv, rtol=1e-12, atol=1e-12 * np.abs(refv).max())
+    np.testing.assert_allclose(pv.sum(axis=0), ref, rtol=1e-11, atol=1e-11 * np.abs(ref).max())
+    # a tiny work buffer (one block) gives the same sums
+    one = solver.hrf_normal_eq(dev64(Z), dev64(Y), K,
+                               work=torch.empty(K * K + K + 1, dtype=torch.float64, device="cuda"))
+    np.testing.assert_allclose(one.cpu().numpy(), ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
+
+
+def test_theta_fit_matches_direct_minimiser_and_lbfgsb(solver):
+    from scipy.optimize import fmin_l_bfgs_b
+    Z, Y, h_true = blind_problem()
+    K = len(h_true)
+    ne = solver.hrf_normal_eq(dev64(Z), dev64(Y), K)
+    theta, cost, taps = solver.theta_fit(ne, T_R, HRF_DUR, (0.6, 1.9))
+    th_ref, f_ref = orc.shared_theta_argmin(Z, Y, T_R, HRF_DUR, (0.6, 1.9))
+    print("shared theta: device %.10f direct-cost oracle %.10f" % (float(theta[0]), th_ref))
+    assert float(theta[0]) == pytest.approx(th_ref, abs=2e-7)
+    assert float(cost[0]) == pytest.approx(f_ref, rel=1e-8)
+    np.testing.assert_allclose(taps[0].cpu().numpy(), orc.spm_hrf(float(theta[0]), T_R, HRF_DUR, False)[0],
+                               rtol=1e-10, atol=1e-14)
+    G, b, yy = orc.hrf_normal_eq(Z, Y, K)
+    th_o, f_o, _ = orc.theta_fit_normal_eq(G, b, yy, T_R, HRF_DUR, (0.6, 1.9))
+    assert float(theta[0]) == pytest.approx(th_o, abs=1e-9)       # the restated algorithm itself
+    # one set per voxel = the reference's per-voxel theta-step (bold_signal.py:329-333)
+    pv = solver.hrf_normal_eq(dev64(Z), dev64(Y), K, per_voxel=True)
+    thetas, costs, _ = solver.theta_fit(pv, T_R, HRF_DUR, (0.6, 1.9))
+    for v in range(len(Z)):
+        t_ref, f_l, _ = fmin_l_bfgs_b(func=orc.hrf_fit_err, x0=1.9, args=(Z[v], Y[v], T_R, HRF_DUR),
+                                      bounds=[(0.6, 1.9)], approx_grad=True, maxiter=999, pgtol=1e-12)
+        assert float(thetas[v]) == pytest.approx(float(t_ref[0]), abs=5e-5)   # L-BFGS-B's own accuracy
+        assert float(costs[v]) <= float(f_l) * (1 + 1e-9)
+        assert float(costs[v]) == pytest.approx(orc.hrf_fit_err(float(thetas[v]), Z[v], Y[v], T_R, HRF_DUR),
+                                                rel=1e-8)
+    # minimiser on a bound
+    th_b, _, _ = solver.theta_fit(ne, T_R, HRF_DUR, (1.2, 1.9))
+    assert float(th_b[0]) == pytest.approx(1.2, abs=1e-12)
+
+
+def test_shared_taps_solver_equals_host_taps_solver(solver, golden):
+    """pb_fista_solve_pp with ldt = 0 (taps and step read from device memory, shared by all
+    problems) is bitwise the per-problem-taps kernel with equal rows and 1e-5 from the oracle."""
+    g = golden("loops_deconv")
+    rng = np.random.RandomState(0)
+    Y = g["y"][None] * (0.5 + rng.rand(37, 1))
+    h = g["h"]
+    from pybold_amd.utils import gram_frobenius
+    step = 1.0 / gram_frobenius(h, Y.shape[1])
+    Ws, _ = solver.fista_solve_pp(dev32(Y), dev64(h), dev64([step]), 1.7, 50)
+    Wp, _ = solver.fista_solve_pp(dev32(Y), dev64(np.tile(h, (37, 1))), dev64(np.full(37, step)), 1.7, 50)
+    assert torch.equal(Ws, Wp)
+    ref = orc.fista_batch(Y.astype(np.float32).astype(np.float64), h, 1.7, step, 50)
+    assert rel_rows(Ws.cpu().numpy(), ref) < 1e-5
+    Wg, _ = solver.fista_solve_pp(dev32(Y), dev64(h), dev64([step]), 1.7, 50, force="generic")
+    assert rel_rows(Wg.cpu().numpy(), ref) < 1e-6
+    # inplace=True iterates in the caller's buffer
+    W0 = torch.zeros((37, Y.shape[1]), dtype=torch.float64, device="cuda")
+    Wi, _ = solver.fista_solve_pp(dev32(Y), dev64(h), dev64([step]), 1.7, 50, W0=W0, inplace=True)
+    assert Wi.data_ptr() == W0.data_ptr() and torch.equal(Wi, Ws)
+
+
+def test_bd_shared_device_theta_step(solver):
+    """Config-4 structure on a small batch: device theta-step vs the L-BFGS-B variant and
+    vs the oracle run of the same loop; V = 1 equals the reference-style per-voxel fit."""
+    from pybold_amd import distributed
+    Z, Y, h_true = blind_problem(n_vox=64, noise=0.1)
+    Yd = dev32(Y)
+    kw = dict(lbda=0.5, hrf_dur=HRF_DUR, nb_iter=6, nb_inner=60)
+    W, h, d = distributed.bd_shared(Yd, T_R, **kw)
+    W2, h2, d2 = distributed.bd_shared(Yd, T_R, theta_solver="lbfgsb", **kw)
+    print("bd_shared theta device:", d["theta"], "\n          theta lbfgsb:", d2["theta"])
+    assert (np.diff(d["J"]) < 0).all()
+    np.testing.assert_allclose(d["theta"], d2["theta"], atol=2e-4)     # L-BFGS-B stops early (factr 1e7)
+    np.testing.assert_allclose(d["J"], d2["J"], rtol=1e-5)
+    assert rel_rows(h, h2) < 1e-3
+    assert d["J"][-1] <= d2["J"][-1] * (1 + 1e-7)                      # never a worse minimiser
+    assert d["theta"][-1] == pytest.approx(0.8, abs=0.1)
+
+
+def test_vector_theta0_in_bd_batch(solver):
+    from pybold_amd import blind
+    Z, Y, _ = blind_problem(n_vox=6)
+    t0 = np.linspace(0.9, 1.8, 6)
+    X, Zd, W, taps, d = blind.bd_batch(dev32(Y), T_R, lbda=0.5, theta_0=t0, hrf_dur=HRF_DUR, nb_iter=2)
+    X1, _, W1, _, d1 = blind.bd_batch(dev32(Y[2:3]), T_R, lbda=0.5, theta_0=float(t0[2]),
+                                      hrf_dur=HRF_DUR, nb_iter=2)
+    assert torch.equal(W[2:3], W1)                       # voxel 2 is independent of its neighbours
+    with pytest.raises(ValueError):
+        blind.bd_batch(dev32(Y), T_R, theta_0=np.ones(5), nb_iter=1)
+    with pytest.raises(ValueError):
+        blind.bd_batch(dev32(Y), T_R, theta_0=np.full(6, 2.5), nb_iter=1)

@@ -183,3 +183,67 @@ def test_c_oracle_matches_goldens(golden):
     W, _, _ = c_oracle.fista_batch(g5["y"][None], g5["h"], 1.7,
                                    1.0 / orc.gram_lipschitz(g5["h"], len(g5["y"])), 5, W0=g5["w0"][None])
     assert rel(W[0], g5["w_warm_n5"]) < 1e-9
+
+
+# ---- round-2 fixtures (tests/golden/make_golden_r2.py) ------------------------------------
+def test_bd_theta_trajectory_and_warm_start(golden):
+    """theta after every outer iteration of the reference's bd (recorded around its
+    fmin_l_bfgs_b call, bold_signal.py:330-333) and the z_0 / theta_0 warm start (:291-301)."""
+    g, b = golden("round2"), golden("bd")
+    x, z, w, h, d = orc.bd(b["y"], float(b["t_r"]), lbda=float(b["lbda"]),
+                           hrf_dur=float(b["hrf_dur"]), nb_iter=int(b["nb_iter"]))
+    np.testing.assert_allclose(d["theta"], g["bd_theta"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(d["J"], g["bd_J"], rtol=1e-6)
+    x, z, w, h, d = orc.bd(g["bdw_y"], 0.75, lbda=1.7, theta_0=1.0, z_0=g["bdw_z0"], hrf_dur=20.0,
+                           nb_iter=3)
+    np.testing.assert_allclose(d["theta"], g["bdw_theta"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(d["J"], g["bdw_J"], rtol=1e-6)
+    np.testing.assert_allclose(d["r"], g["bdw_r"], rtol=1e-6)
+    np.testing.assert_allclose(d["g"], g["bdw_g"], rtol=1e-5)
+    assert rel(h, g["bdw_h"]) < 1e-5 and rel(x, g["bdw_x"]) < 1e-5 and rel(w, g["bdw_diff_z"]) < 1e-4
+
+
+def test_regular_block_generator(golden):
+    g = golden("round2")
+    for tag in "ab":
+        dur, tr, dur_bloc, snr, _ = g["reg_%s_p" % tag]
+        # the reference's noise, rescaled back to a unit draw, must come out identically
+        noisy, clean, ai_s, i_s, noise = orc.gen_regular_bloc_bold(
+            dur=int(dur), tr=tr, dur_bloc=dur_bloc, hrf=g["reg_%s_hrf" % tag], snr=snr,
+            noise=g["reg_%s_noise" % tag] * 3.7)
+        np.testing.assert_allclose(ai_s, g["reg_%s_ai_s" % tag], rtol=0, atol=1e-13)
+        np.testing.assert_allclose(i_s, g["reg_%s_i_s" % tag], rtol=0, atol=1e-13)
+        np.testing.assert_allclose(clean, g["reg_%s_clean" % tag], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(noise, g["reg_%s_noise" % tag], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(noisy, g["reg_%s_noisy" % tag], rtol=1e-12, atol=1e-13)
+        got = 20 * np.log10(np.linalg.norm(clean) / np.linalg.norm(noise))
+        assert got == pytest.approx(snr, abs=1e-9)
+
+
+def test_inf_norm(golden):
+    g = golden("round2")
+    np.testing.assert_allclose(orc.inf_norm(g["inf_a1"]), g["inf_o1"], rtol=1e-15)
+    np.testing.assert_allclose(orc.inf_norm(g["inf_a2"]), g["inf_o2"], rtol=1e-15)
+    np.testing.assert_allclose(orc.inf_norm(g["inf_a2"], axis=0), g["inf_o2_axis0"], rtol=1e-15)
+    np.testing.assert_allclose(orc.inf_norm(g["inf_a3"]), g["inf_o3"], rtol=1e-15)
+    out = orc.inf_norm([g["inf_a1"], g["inf_a2"], g["inf_a3"]])
+    for o, k in zip(out, ("inf_l0", "inf_l1", "inf_l2")):
+        np.testing.assert_allclose(o, g[k], rtol=1e-15)
+
+
+def test_normal_equations_reproduce_hrf_fit_err(golden):
+    """The quadratic form 0.5 yy - h^T b + 0.5 h^T G h of the device theta-step equals the
+    reference's hrf_fit_err (FFT convolution and all) on a 131-point theta grid, and its
+    section-search minimiser is the minimiser hrf_estim's L-BFGS-B stops next to."""
+    g = golden("round2")
+    z, y = g["fit_z"], g["fit_y"]
+    K = len(g["fit_h_estim"])
+    G, b, yy = orc.hrf_normal_eq(z, y, K)
+    for th, err in zip(g["fit_theta"], g["fit_err"]):
+        h = orc.spm_hrf(th, 0.75, 20.0, False)[0]
+        assert 0.5 * yy - h.dot(b) + 0.5 * h.dot(G.dot(h)) == pytest.approx(err, rel=1e-10)
+    th, f, h = orc.theta_fit_normal_eq(G, b, yy, 0.75, 20.0, (0.6, 1.9))
+    assert f <= g["fit_err"].min()
+    assert abs(th - g["fit_theta"][np.argmin(g["fit_err"])]) <= 0.01      # within one grid cell
+    assert rel(h, g["fit_h_estim"]) < 2e-4                                 # L-BFGS-B's own accuracy
+    assert orc.lambda_max(y, h)[0] > 0

@@ -1,8 +1,9 @@
 """CPU-only, world_size 2, gloo backend: the multi-rank logic of
-pybold_amd.distributed (contiguous voxel shards, ONE 16-byte all-reduce per
-shared-HRF cost evaluation, identical scalar L-BFGS-B step on every rank).
-The per-rank cost here comes from the CPU oracle standing in for the HIP
-reduction kernel (pb_hrf_cost) so that the logic is exercised without a GPU."""
+pybold_amd.distributed (contiguous voxel shards; shared-HRF blind step = per-rank
+normal equations, ONE all-reduce per outer iteration, identical theta fit on every
+rank; and the L-BFGS-B variant with its 16-byte all-reduce per cost evaluation).
+The per-rank compute here comes from the CPU oracle standing in for the HIP
+kernels (distributed.HipOps) so that the logic is exercised without a GPU."""
 import os
 import socket
 
@@ -93,3 +94,105 @@ def test_single_voxel_shared_fit_equals_reference_style_fit():
                                                distributed.Comm())
     assert theta == pytest.approx(float(theta_ref[0]), rel=1e-5)
     assert f == pytest.approx(float(f_ref), rel=1e-6)
+
+
+# ---- shared-HRF blind loop with the device theta-step (normal equations) -------------
+class OracleOps:
+    """CPU stand-in for distributed.HipOps: same five steps, float64 NumPy oracle."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def hrf(self, theta):
+        return torch.from_numpy(orc.spm_hrf(float(theta[0]), T_R, HRF_DUR, False)[0].copy())
+
+    def z_step(self, Y, taps, lbda, nb_inner, W):
+        if Y.shape[0] == 0:
+            return W
+        h = taps.numpy()
+        step = 1.0 / orc.gram_lipschitz(h, self.n)
+        return torch.from_numpy(orc.fista_batch(Y.numpy().astype(np.float64), h, lbda, step,
+                                                nb_inner, W0=W.numpy()))
+
+    def normal_eq(self, W, Y, K):
+        G, b, yy = orc.hrf_normal_eq(np.cumsum(W.numpy(), axis=1), Y.numpy().astype(np.float64), K) \
+            if Y.shape[0] else (np.zeros((K, K)), np.zeros(K), 0.0)
+        return torch.from_numpy(np.concatenate([G.ravel(), b, [yy]]))
+
+    def theta_fit(self, ne, bounds):
+        K = int(round((-1 + np.sqrt(1 + 4 * (ne.numel() - 1))) / 2))
+        v = ne.numpy()
+        th, f, h = orc.theta_fit_normal_eq(v[:K * K].reshape(K, K), v[K * K:K * K + K], v[-1],
+                                           T_R, HRF_DUR, bounds)
+        return torch.tensor([th]), torch.tensor([f]), torch.from_numpy(h.copy())
+
+
+def _bd_worker(rank, world, port, n_vox, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _, Y = make_problem(n_vox=n_vox)
+        lo, hi = distributed.shard_bounds(len(Y), world, rank)
+        Yl = torch.from_numpy(Y[lo:hi].astype(np.float32))
+        W, h, d = distributed.bd_shared(Yl, T_R, lbda=0.05, hrf_dur=HRF_DUR, nb_iter=3, nb_inner=30,
+                                        comm=distributed.Comm(), ops=OracleOps(Y.shape[1]))
+        ret[rank] = (lo, hi, W.numpy(), h, d["theta"], d["J"])
+    finally:
+        dist.destroy_process_group()
+
+
+def _bd_single(n_vox):
+    _, Y = make_problem(n_vox=n_vox)
+    return distributed.bd_shared(torch.from_numpy(Y.astype(np.float32)), T_R, lbda=0.05,
+                                 hrf_dur=HRF_DUR, nb_iter=3, nb_inner=30,
+                                 comm=distributed.Comm(), ops=OracleOps(Y.shape[1]))
+
+
+@pytest.mark.parametrize("n_vox", [6, 1])
+def test_bd_shared_two_ranks_equal_one_process(n_vox):
+    """Voxel shards + one all-reduce of the normal equations per outer iteration give the
+    same theta trajectory, cost trace and iterates as one process; with n_vox = 1 < world
+    size the second rank owns NO voxel and must still join every all-reduce (no hang)."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_bd_worker, args=(world, free_port(), n_vox, ret), nprocs=world, join=True)
+    Ws, hs, ds = _bd_single(n_vox)
+    np.testing.assert_array_equal(ret[0][4], ret[1][4])          # identical theta on every rank
+    np.testing.assert_array_equal(ret[0][5], ret[1][5])
+    np.testing.assert_allclose(ret[0][4], ds["theta"], rtol=1e-9)
+    np.testing.assert_allclose(ret[0][5], ds["J"], rtol=1e-9)
+    assert len(ds["J"]) == 5 and ds["J"][0] == 1.0 and (np.diff(ds["J"]) < 0).all()
+    for r in range(world):
+        lo, hi, W = ret[r][0], ret[r][1], ret[r][2]
+        assert W.shape[0] == hi - lo
+        np.testing.assert_allclose(W, Ws.numpy()[lo:hi], rtol=1e-7, atol=1e-12)
+    if n_vox == 1:
+        assert ret[1][1] - ret[1][0] == 0                          # the empty rank
+    assert THETA_TRUE < ds["theta"][-1] < 1.9           # moving from theta_0 = 2.0 towards the truth
+
+
+def test_normal_equation_fit_equals_direct_cost_minimiser():
+    """The quadratic-form theta-step returns the minimiser of the DIRECT shared cost
+    sum_v 0.5||y_v - h(theta)*z_v||^2; for one voxel that is the reference's theta-step
+    objective (hrf_fit_err, bold_signal.py:217-222), whose L-BFGS-B solution it matches to
+    the optimiser's own accuracy."""
+    from scipy.optimize import fmin_l_bfgs_b
+    for n_vox in (1, 6):
+        Z, Y = make_problem(n_vox=n_vox)
+        K = len(orc.spm_hrf(1.0, T_R, HRF_DUR, False)[0])
+        G, b, yy = orc.hrf_normal_eq(Z, Y, K)
+        th, f, h = orc.theta_fit_normal_eq(G, b, yy, T_R, HRF_DUR, (0.6, 1.9))
+        th_direct, f_direct = orc.shared_theta_argmin(Z, Y, T_R, HRF_DUR, (0.6, 1.9))
+        assert th == pytest.approx(th_direct, abs=2e-7)
+        assert f == pytest.approx(f_direct, rel=1e-8)
+        assert f == pytest.approx(orc.shared_hrf_cost(th, Z, Y, T_R, HRF_DUR), rel=1e-9)
+    Z, Y = make_problem(n_vox=1)
+    theta_ref, f_ref, _ = fmin_l_bfgs_b(func=orc.hrf_fit_err, x0=1.9, args=(Z[0], Y[0], T_R, HRF_DUR),
+                                        bounds=[(0.6, 1.9)], approx_grad=True, maxiter=999,
+                                        pgtol=1.0e-12)
+    G, b, yy = orc.hrf_normal_eq(Z, Y, K)
+    th, f, _ = orc.theta_fit_normal_eq(G, b, yy, T_R, HRF_DUR, (0.6, 1.9))
+    assert th == pytest.approx(float(theta_ref[0]), abs=2e-5)     # L-BFGS-B stops at ~1e-5
+    assert f <= float(f_ref) * (1 + 1e-9)                         # and never finds a lower cost
