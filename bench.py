@@ -3,34 +3,46 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One *step* = one full solve of the per-GPU voxel batch: 500 iterations of the
-reference's FISTA-like recurrence (pybold/bold_signal.py:62-72) on V voxels x
-300 scans, L1/TV-regularised, fixed canonical HRF -- BASELINE.json config 3's
-problem (100k voxels x 300 scans x 500 iterations), which is the size the
-north_star target is quoted on and fits one GPU.  Voxels are independent, so
-with N > 1 every rank solves its own shard of V voxels (weak scaling, no
-data-path collective); the only collectives are the timing barrier and the
-MAX-reduction of the elapsed time.
+One *step* = one full solve of the voxel batch: 500 iterations of the reference's
+FISTA-like recurrence (pybold/bold_signal.py:62-72) on 300-scan series, L1/TV-regularised,
+fixed canonical HRF -- BASELINE.json config 3 (100k voxels x 300 scans x 500 iterations),
+the size the north_star target is quoted on; it fits one GPU.
 
-Prints ONE JSON line (rank 0): metric = voxel-iterations/s (whole job), plus
-`roofline` (dominant kernel against the HBM roofline, algorithmic bytes =
-12*N B per voxel-iteration) and `cpu_baseline` (the C/OpenMP
-float64 oracle timed on this box's host cores on a bounded sample).
+N > 1: one process per GPU.  Started WITHOUT a torch.distributed environment, this script
+launches its own ranks (python -m torch.distributed.run ... bench.py) as a child process
+before it touches the GPU; under torchrun (the driver's form) it is one of the ranks.
+Voxels are independent, so the ranks share the 100k voxels of config 3 in contiguous shards
+(`distributed.shard_bounds`, the reference's joblib axis,
+examples/icassp_2019/simulation.py:62-72) with NO data-path collective: strong scaling, the
+axis of the north_star's ">= 6x at 8 GPUs".  The only collectives are the timing barrier and
+the MAX-reduction of the elapsed time.  `--scaling weak` (or the `weak_scaling` key of the
+default line for N > 1) gives every rank its own 100k voxels instead.
+
+Prints ONE JSON line (rank 0): metric = voxel-iterations/s (whole job), plus `roofline`
+(dominant kernel against the fp32 vector-ALU peak that binds it; the HBM-algorithmic figure
+of SURVEY.md 8d and the measured HBM traffic as context) and `cpu_baseline` (the reference's
+dense-Toeplitz NumPy formulation fanned over the host cores, and the matrix-free C/OpenMP
+port, both from oracle/, on bounded samples of the same workload).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector), needs v_pk_fma_f32
 BYTES_PER_VOXEL_ITER_PER_SCAN = 12   # read w, read y, write w in fp32 (SURVEY 8d)
+
+
+def flops_per_voxel_iter(n, k):
+    """Algorithmic flops of one iteration: two K-tap FIRs 4NK, two scans 2N,
+    update/prox/momentum ~10N."""
+    return 4.0 * n * k + 12.0 * n
 
 
 def parse():
@@ -38,24 +50,65 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--voxels", type=int, default=100000, help="voxels per GPU")
+    ap.add_argument("--voxels", type=int, default=100000,
+                    help="voxels of the whole job (strong scaling) / per GPU (--scaling weak)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: shard --voxels over the ranks (strong, default) or give every "
+                         "rank --voxels of its own (weak)")
     ap.add_argument("--scans", type=int, default=300)
     ap.add_argument("--iters", type=int, default=500)
     ap.add_argument("--lbda", type=float, default=1.0)
     ap.add_argument("--extras", action="store_true",
-                    help="also time BASELINE config 2 (10k voxels) and the PCIe-inclusive solve "
-                         "(extra launches of the same kernel; off by default so that a rocprof "
-                         "summary of the default command holds only the timed launches)")
+                    help="also time BASELINE config 2 (10k voxels) and the 12 500-voxel shard of "
+                         "config 3 on 8 GPUs (extra launches; off by default so that a rocprof "
+                         "summary of the default command holds only the config-3 launches)")
     ap.add_argument("--kernel", choices=["auto", "fast1", "generic"], default="auto",
                     help="auto = library dispatch; fast1 = one problem per DPP row "
                          "(fista_fast_kernel) even where the pair kernel applies")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0,
-                    help="target CPU time of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0,
+                    help="target time of each cpu_baseline sample (0 = skip)")
+    ap.add_argument("--master-port", type=int, default=0, help="self-launched ranks only")
     return ap.parse_args()
+
+
+def job_layout(voxels, scaling, world, rank):
+    """Rows `[lo, hi)` of the job this rank solves and the job's total voxel count: strong =
+    contiguous shards of `voxels` (the reference's joblib axis), weak = `voxels` per rank."""
+    from pybold_amd.distributed import shard_bounds
+    if scaling == "strong":
+        lo, hi = shard_bounds(voxels, world, rank)
+        return lo, hi, voxels
+    return rank * voxels, (rank + 1) * voxels, voxels * world
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` from a bare shell: start the N ranks as ONE child process
+    (torch.distributed.run) and pass its exit code on.  Nothing here touches the GPU:
+    `torch.cuda.device_count()` does not initialise it."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.stderr.write("bench.py --gpus %d needs %d GPUs; this machine shows %d\n"
+                         % (args.gpus, args.gpus, have))
+        return 2
+    port = args.master_port
+    if not port:
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     # Everything but the final JSON line goes to stderr, including what native
     # libraries (RCCL's version banner) write to file descriptor 1.
     sys.stdout.flush()
@@ -76,11 +129,20 @@ def run(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run "
-                             "--nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    # CPU legs first (rank 0, one GPU): their worker processes are started before this
+    # process initialises the GPU
+    cpu_dense = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        cpu_dense = cpu_dense_baseline(args.scans, args.iters, args.lbda, args.cpu_seconds)
+
+    import numpy as np
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -90,57 +152,68 @@ def run(args):
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from pybold_amd import data, solver
+    from pybold_amd import data, distributed, solver
     from pybold_amd.hrf_model import spm_hrf
     from pybold_amd.linear import ConvAndLinear, DiscretInteg
     from pybold_amd.utils import spectral_radius_est
 
-    V, N, n_iter = args.voxels, args.scans, args.iters
+    N, n_iter = args.scans, args.iters
     tr = 1.0
     hrf = spm_hrf(1.0, t_r=tr, dur=30.0)[0]                    # canonical HRF, K = 30
-    Y, _, _ = data.gen_rnd_bloc_bold_batch(V, dur=N * tr / 60.0, tr=tr, hrf=hrf, nb_events=5,
-                                           avg_dur=12.0, std_dur=1.0, snr=1.0, seed=1000 + rank,
-                                           device=dev)
+    lo, hi, V_total = job_layout(args.voxels, args.scaling, world, rank)
+    V = hi - lo                                                 # this rank's voxels
+
+    def make_batch(n_vox, seed):
+        Y, _, _ = data.gen_rnd_bloc_bold_batch(n_vox, dur=N * tr / 60.0, tr=tr, hrf=hrf, nb_events=5,
+                                               avg_dur=12.0, std_dur=1.0, snr=1.0, seed=seed, device=dev)
+        return Y
+    Y = make_batch(V, 1000 + rank)
     np.random.seed(0)                                           # same constant on every rank
     H = ConvAndLinear(DiscretInteg(), hrf, dim_in=N, dim_out=N)
     lipschitz = 0.9 * spectral_radius_est(H, (N,))              # pybold/bold_signal.py:52
     step = 1.0 / lipschitz
-    plan = solver.FistaPlan(Y, hrf, args.lbda, step, n_iter,
-                            force=None if args.kernel == "auto" else args.kernel)
-    kernel_name = (solver.which_kernel(N, len(hrf), V) if args.kernel == "auto" else
+    force = None if args.kernel == "auto" else args.kernel
+    plan = solver.FistaPlan(Y, hrf, args.lbda, step, n_iter, force=force)
+    kernel_name = (solver.which_kernel(N, len(hrf), max(V, 1)) if args.kernel == "auto" else
                    {"fast1": solver.KERNEL_NAMES[1], "generic": solver.KERNEL_NAMES[0]}[args.kernel])
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        plan.run()
-    torch.cuda.synchronize(dev)
-    barrier()
+    def timed(p, steps, warmup):
+        """`warmup` untimed steps, then exactly `steps` steps between barrier +
+        synchronize on both sides; MAX over ranks.  Returns (elapsed s, mean kernel ms)."""
+        for _ in range(warmup):
+            p.run()
+        torch.cuda.synchronize(dev)
+        barrier()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(steps)]
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for k in range(steps):
+            p.W.zero_()
+            ev[k][0].record()          # same stream the kernel is launched on
+            p.launch()
+            ev[k][1].record()
+        torch.cuda.synchronize(dev)
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps)]
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        plan.W.zero_()
-        ev[k][0].record()          # same stream the kernel is launched on
-        plan.launch()
-        ev[k][1].record()
-    torch.cuda.synchronize(dev)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    elapsed, kern_ms = timed(plan, args.steps, args.warmup)
 
-    total_units = float(world) * V * n_iter * args.steps
-    value = total_units / elapsed
-    alg_bytes = BYTES_PER_VOXEL_ITER_PER_SCAN * N * float(V) * n_iter      # per launch
-    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    value = float(V_total) * n_iter * args.steps / elapsed
+    K = len(hrf)
+    flops_launch = flops_per_voxel_iter(N, K) * float(V) * n_iter          # this rank's launch
+    alg_bytes = BYTES_PER_VOXEL_ITER_PER_SCAN * N * float(V) * n_iter
+    valu_tflops = flops_launch / (kern_ms * 1e-3) / 1e12
+    hbm_alg_gbs = alg_bytes / (kern_ms * 1e-3) / 1e9
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tfile):
@@ -151,84 +224,167 @@ def run(args):
         except Exception:
             traffic = None
 
+    ms_step = elapsed / args.steps * 1e3
+    if world == 1:
+        workload = ("BASELINE config 3: %d voxels x %d scans, L1/TV block-signal deconv, fixed "
+                    "canonical HRF (K=%d), lambda=%g, %d FISTA iterations per step"
+                    % (V_total, N, K, args.lbda, n_iter))
+    else:
+        workload = ("BASELINE config 3 on %d GPUs (%s scaling): %d voxels in all, %s per GPU, x %d "
+                    "scans, L1/TV block-signal deconv, fixed canonical HRF (K=%d), lambda=%g, %d FISTA "
+                    "iterations per step" % (world, args.scaling, V_total,
+                                             "%d" % V if args.scaling == "weak" else "ceil(%d/%d)" % (V_total, world),
+                                             N, K, args.lbda, n_iter))
     out = {
         "metric": "voxel-iterations/sec", "value": value, "unit": "voxel-iterations/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
-        "wall_clock_to_eps_ms": elapsed / args.steps * 1e3,   # one full solve meeting eps <= 1e-5
+        "ms_per_step": ms_step,
+        "wall_clock_to_eps_ms": ms_step,       # one full solve meeting eps <= 1e-5, y resident in HBM
         "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
         "dtype_note": "FIR/scans/residual fp32 (packed), iterate and update fp64 on chip; "
                       "y fp32 in HBM; outputs fp64",
         "data": "synthetic",
-        "config": {"workload": "BASELINE config 3 per GPU: %d voxels x %d scans, L1/TV block-signal "
-                               "deconv, fixed canonical HRF (K=%d), lambda=%g, %d FISTA iterations "
-                               "per step" % (V, N, len(hrf), args.lbda, n_iter),
-                   "voxels_per_gpu": V, "scans": N, "taps": int(len(hrf)), "iters_per_step": n_iter,
-                   "kernel": kernel_name,
-                   "parallelism": "voxel-shard x%d, no data-path collective" % world},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel_ms": kern_ms,
+        "config": {"workload": workload,
+                   "voxels_total": V_total, "voxels_this_rank": V, "scans": N, "taps": int(K),
+                   "iters_per_step": n_iter, "kernel": kernel_name,
+                   "parallelism": "contiguous voxel shards x%d, no data-path collective" % world},
+        "roofline": {"bound": "valu_fp32", "achieved": valu_tflops, "peak": VALU_FP32_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": valu_tflops / VALU_FP32_PEAK_TFLOPS,
+                     "traffic": traffic, "kernel_ms": kern_ms,
+                     "flops_per_voxel_iteration": flops_per_voxel_iter(N, K),
+                     "algorithmic_flops_per_launch": flops_launch,
+                     "hbm_algorithmic_GBps": hbm_alg_gbs,
+                     "hbm_algorithmic_frac": hbm_alg_gbs / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_launch": alg_bytes,
-                     "note": "state-resident multi-iteration kernel: HBM is touched once per "
-                             "solve, so the algorithmic-byte rate may exceed the HBM peak; the "
-                             "kernel is VALU-issue bound (see DESIGN.md)"},
+                     "hbm_traffic_GBps": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else None,
+                     "note": "register-resident multi-iteration kernel, VALU-issue bound (PMC: "
+                             "profiles/): the binding roofline is the fp32 vector peak "
+                             "(v_pk_fma_f32). State never leaves the chip during a solve, so the "
+                             "SURVEY-8d algorithmic-byte rate (12*N B per voxel-iteration / kernel "
+                             "time) exceeds the HBM peak; measured HBM traffic = one read of y, w "
+                             "and one write of w per launch."},
     }
 
+    if world > 1 and args.scaling == "strong":
+        # secondary figure: weak scaling (every rank its own `--voxels` voxels)
+        Yw = make_batch(args.voxels, 2000 + rank)
+        planw = solver.FistaPlan(Yw, hrf, args.lbda, step, n_iter, force=force)
+        steps_w = max(3, min(args.steps, 5))
+        el_w, k_w = timed(planw, steps_w, 1)
+        out["weak_scaling"] = {"value": float(args.voxels) * world * n_iter * steps_w / el_w,
+                               "unit": "voxel-iterations/s", "voxels_per_gpu": args.voxels,
+                               "ms_per_step": el_w / steps_w * 1e3, "steps": steps_w}
+        del Yw, planw
+
+    if rank == 0 and world == 1:
+        out.update(pcie_inclusive(plan, Y, hrf, args.lbda, step, n_iter, solver, torch, dev))
+
     if rank == 0 and world == 1 and args.extras:
-        # BASELINE config 2 (10k voxels x 300 scans x 500 iterations) for reference
-        V2 = min(10000, V)
-        plan2 = solver.FistaPlan(Y[:V2].contiguous(), hrf, args.lbda, step, n_iter, force=None)
-        plan2.run()
-        torch.cuda.synchronize(dev)
-        t2 = time.perf_counter()
-        for _ in range(5):
-            plan2.run()
-        torch.cuda.synchronize(dev)
-        dt2 = (time.perf_counter() - t2) / 5
-        out["other_configs"] = {"config2_%d_voxels" % V2: {
-            "value": V2 * n_iter / dt2, "unit": "voxel-iterations/s", "ms_per_solve": dt2 * 1e3}}
-        # host-buffer variant of the boundary: y starts in pinned host memory and the
-        # iterate is copied back (never the headline value)
-        Yh = Y.cpu().pin_memory()
-        Wh = torch.empty(plan.W.shape, dtype=torch.float64).pin_memory()
-        Yd = torch.empty_like(Y)
-        planp = solver.FistaPlan(Yd, hrf, args.lbda, step, n_iter, force=None)
-        def pcie_step():
-            Yd.copy_(Yh, non_blocking=True)
-            planp.run()
-            Wh.copy_(planp.W, non_blocking=True)
-        pcie_step()
-        torch.cuda.synchronize(dev)
-        t3 = time.perf_counter()
-        for _ in range(3):
-            pcie_step()
-        torch.cuda.synchronize(dev)
-        dt3 = (time.perf_counter() - t3) / 3
-        out["pcie_inclusive"] = {"value": V * n_iter / dt3, "unit": "voxel-iterations/s",
-                                 "ms_per_solve": dt3 * 1e3,
-                                 "note": "H2D of y (fp32) + solve + D2H of diff_z (fp64), pinned host buffers"}
-        del Yh, Wh, Yd, planp
+        others = {}
+        for tag, V2 in (("config2_10000_voxels", 10000), ("config3_shard_of_8_12500_voxels", 12500)):
+            V2 = min(V2, V)
+            plan2 = solver.FistaPlan(Y[:V2].contiguous(), hrf, args.lbda, step, n_iter, force=None)
+            el2, k2 = timed(plan2, 5, 1)
+            others[tag] = {"value": V2 * n_iter * 5 / el2, "unit": "voxel-iterations/s",
+                           "ms_per_solve": el2 / 5 * 1e3, "kernel_ms": k2,
+                           "kernel": solver.which_kernel(N, K, V2)}
+        out["other_configs"] = others
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"], out["parity"] = cpu_baseline(Y, plan.W, hrf, args.lbda, step, n_iter,
-                                                          args.cpu_seconds)
+                                                          args.cpu_seconds, cpu_dense)
     if dist is not None:
         dist.destroy_process_group()
     return json.dumps(out) if rank == 0 else None
 
 
-def cpu_baseline(Y, W_gpu, hrf, lbda, step, n_iter, target_s):
-    """C/OpenMP float64 port of the reference loop (oracle/fista_oracle.c) on the
-    host cores of this box, on the first voxels of the same workload; also the
-    parity of the GPU result on that sample."""
-    from oracle import c_oracle
+def pcie_inclusive(plan, Y, hrf, lbda, step, n_iter, solver, torch, dev):
+    """Host-buffer variants of the boundary (never the headline value): y starts in pinned
+    host memory; (a) results stay in HBM, (b) diff_z also returns to the host as float32."""
+    Yh = Y.cpu().pin_memory()
+    Yd = torch.empty_like(Y)
+    planp = solver.FistaPlan(Yd, hrf, lbda, step, n_iter, force=None)
+    Wh = torch.empty(planp.W.shape, dtype=torch.float32).pin_memory()
+
+    def h2d_solve():
+        Yd.copy_(Yh, non_blocking=True)
+        planp.run()
+
+    def h2d_solve_d2h():
+        h2d_solve()
+        Wh.copy_(planp.W.float(), non_blocking=True)
+
+    res = {}
+    for key, fn in (("wall_clock_to_eps_ms_incl_h2d", h2d_solve),
+                    ("wall_clock_to_eps_ms_incl_h2d_d2h_f32", h2d_solve_d2h)):
+        fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(dev)
+        res[key] = (time.perf_counter() - t0) / 3 * 1e3
+    del Yh, Yd, Wh, planp
+    return res
+
+
+def cpu_topology():
+    info = {"cpu_count": os.cpu_count()}
     try:
-        cores = len(os.sched_getaffinity(0))
+        info["affinity"] = len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = min(cores, int(os.environ.get("PYBOLD_BENCH_CPU_THREADS", "16")))   # 1-GPU CPU share
+        info["affinity"] = info["cpu_count"]
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        info["cgroup_cpu_quota"] = None if quota == "max" else float(quota) / float(period)
+    except Exception:
+        info["cgroup_cpu_quota"] = None
+    usable = info["affinity"]
+    if info["cgroup_cpu_quota"]:
+        usable = max(1, min(usable, int(info["cgroup_cpu_quota"] + 0.5)))
+    info["usable_cores"] = usable
+    return info
+
+
+def cpu_dense_baseline(n_scans, n_iter, lbda, target_s):
+    """The reference's own formulation (dense N x N Toeplitz mat-vecs in float64 NumPy,
+    pybold/linear.py:73-113; no cost trace, no print) fanned out over the host cores like
+    the reference's joblib axis (examples/icassp_2019/simulation.py:62-72): one worker
+    process per usable core, BLAS threads pinned to 1 as examples/synth_data/deconv.py:11-14
+    does.  Runs before the GPU is initialised (oracle/dense_worker.py, plain NumPy)."""
+    topo = cpu_topology()
+    workers = int(os.environ.get("PYBOLD_BENCH_CPU_WORKERS", topo["usable_cores"]))
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1",
+               PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+
+    def fan(n_vox):
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([sys.executable, "-m", "oracle.dense_worker", str(n_vox),
+                                   str(n_scans), str(n_iter), str(lbda), str(w)],
+                                  env=env, cwd=ROOT, stdout=subprocess.PIPE) for w in range(workers)]
+        inner = [float(p.communicate()[0].decode().strip().split()[-1]) for p in procs]
+        if any(p.returncode != 0 for p in procs):
+            raise RuntimeError("oracle.dense_worker failed")
+        return time.perf_counter() - t0, max(inner)
+
+    _, t_cal = fan(2)                                     # calibrate: 2 voxels per worker
+    per_voxel = max(t_cal / 2.0, 1e-6)
+    n_vox = int(max(2, min(256, target_s / per_voxel)))
+    wall, inner = fan(n_vox)
+    return {"value": workers * n_vox * n_iter / inner, "workers": workers, "voxels_per_worker": n_vox,
+            "seconds": inner, "seconds_incl_process_start": wall, "topology": topo}
+
+
+def cpu_baseline(Y, W_gpu, hrf, lbda, step, n_iter, target_s, dense):
+    """`value`: the dense-Toeplitz NumPy formulation on all usable host cores (see
+    cpu_dense_baseline).  `port_value`: the matrix-free C/OpenMP float64 port
+    (oracle/fista_oracle.c) on the same cores, whose output is also the parity check of the
+    GPU result on that sample."""
+    import numpy as np
+    from oracle import c_oracle
+    topo = dense["topology"]
+    cores = int(os.environ.get("PYBOLD_BENCH_CPU_THREADS", topo["usable_cores"]))
     Yh = Y[:max(4 * cores, 64)].cpu().numpy().astype(np.float64)
     t0 = time.perf_counter()
     c_oracle.fista_batch(Yh[:2 * cores], hrf, lbda, step, n_iter, threads=cores)   # calibrate
@@ -240,16 +396,18 @@ def cpu_baseline(Y, W_gpu, hrf, lbda, step, n_iter, target_s):
     dt = time.perf_counter() - t0
     Wg = W_gpu[:n_sample].cpu().numpy()
     err = float((np.linalg.norm(Wg - Wc, axis=1) / (np.linalg.norm(Wc, axis=1) + 1e-300)).max())
-    # the reference's own formulation (dense Toeplitz mat-vecs, NumPy float64, as
-    # pybold/linear.py:73-113) on ONE core, for context next to the matrix-free C port
-    from oracle import pybold_oracle as orc
-    t1 = time.perf_counter()
-    orc.fista_batch(Yh[:4], hrf, lbda, step, n_iter, dense=True)
-    dense_rate = 4 * n_iter / (time.perf_counter() - t1)
-    base = {"value": n_sample * n_iter / dt, "unit": "voxel-iterations/s", "cores": int(used),
-            "kind": "port", "numpy_dense_toeplitz_1core": dense_rate,
-            "sample": "first %d voxels of the same batch x %d iterations, C/OpenMP float64 "
-                      "matrix-free port (oracle/fista_oracle.c), %.1f s" % (n_sample, n_iter, dt)}
+    base = {"value": dense["value"], "unit": "voxel-iterations/s", "cores": dense["workers"],
+            "kind": "port",
+            "sample": "%d worker processes x %d synthetic voxels x %d iterations of the reference's "
+                      "dense-Toeplitz float64 NumPy formulation (oracle.pybold_oracle.fista_batch, "
+                      "dense=True), BLAS threads = 1, %.1f s"
+                      % (dense["workers"], dense["voxels_per_worker"], n_iter, dense["seconds"]),
+            "cpu_count": topo["cpu_count"], "workers": dense["workers"],
+            "affinity": topo["affinity"], "cgroup_cpu_quota": topo["cgroup_cpu_quota"],
+            "port_value": n_sample * n_iter / dt, "port_threads": int(used),
+            "port_sample": "first %d voxels of the same batch x %d iterations, C/OpenMP float64 "
+                           "matrix-free port (oracle/fista_oracle.c), %d threads, %.1f s"
+                           % (n_sample, n_iter, int(used), dt)}
     parity = {"max_rel_l2_diff_z_vs_cpu_oracle": err, "voxels_checked": n_sample, "tolerance": 1e-5}
     return base, parity
 

@@ -264,7 +264,7 @@ int pb_inf_norm(const double* x_dev, int64_t ldx, double* out_dev, int64_t ldo, 
  *                    per_voxel = 0: out_dev [len] = sum over the V voxels (shared-HRF
  *                      variant, BASELINE config 4; an empty shard V = 0 writes zeros so the
  *                      rank still contributes to the all-reduce); work_dev = scratch of
- *                      work_len float64 (>= len; more, up to 1024*len, = more workgroups);
+ *                      work_len float64 (>= len; more, up to 2048*len, = more workgroups);
  *                      the sum order is fixed: results are reproducible.
  *                    per_voxel = 1: out_dev [V][len], one set per voxel; work_dev unused.
  * pb_theta_fit       argmin over theta in [lo, hi] of the quadratic form for M sets

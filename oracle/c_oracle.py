@@ -7,8 +7,17 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libfista_oracle.so")
 _lib = None
+
+
+def _so_path():
+    """AVX2+FMA build when the host CPU has both, else the plain x86-64 build."""
+    try:
+        flags = open("/proc/cpuinfo").read()
+        fast = " avx2" in flags and " fma" in flags
+    except OSError:
+        fast = False
+    return os.path.join(_HERE, "libfista_oracle.so" if fast else "libfista_oracle_generic.so")
 
 
 def build():
@@ -18,9 +27,10 @@ def build():
 def load():
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO):
+        so = _so_path()
+        if not os.path.exists(so):
             build()
-        lib = ctypes.CDLL(_SO)
+        lib = ctypes.CDLL(so)
         lib.oracle_fista_batch.restype = ctypes.c_int
         lib.oracle_fista_batch.argtypes = [
             ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,

@@ -30,74 +30,76 @@ __host__ __device__ inline int ne_len(int K) { return K * K + K + 1; }
 // Layout of one normal-equation set: G row-major [K][K], then b [K], then yy.
 // Shared mode (PER_VOXEL = false): block B sums its voxels into part[B][ne_len]; a second
 // kernel adds the blocks in a fixed order (deterministic).  PER_VOXEL: out[v][ne_len].
-// Each workgroup handles SLOTS = 256 / (2K+1) voxels at a time; thread role r of a slot:
-//   r <  K   autocorrelation lag r        (G diagonals)
-//   r < 2K   cross-correlation lag r-K    (b)
-//   r = 2K   yy
-// LDS per slot: z[N] y[N] (float64), acc[ne_len] (shared mode only).
+// One voxel at a time per workgroup; SUB adjacent lanes share one role (SUB = 4 for K <= 31):
+//   role r <  K   autocorrelation lag r        (G diagonals)
+//        r < 2K   cross-correlation lag r-K    (b)
+//        r = 2K   yy
+// The sums over j < N-K have no truncation point inside them, so the SUB lanes of a role
+// split them (stride SUB) and fold with two shuffles; lane 0 of the role then walks the last
+// K samples alone, recording the running sum at each truncation point.
+// LDS: z[N] y[N] (float64) and, in shared mode, acc[ne_len].
 template <typename TY, bool PER_VOXEL>
 __global__ __launch_bounds__(NE_THREADS) void normal_eq_kernel(const double* z, int64_t ldz,
                                                                const TY* y, int64_t ldy, int V,
-                                                               int N, int K, double* out) {
+                                                               int N, int K, int sub_log2,
+                                                               double* out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int roles = 2 * K + 1;
-  const int slots = NE_THREADS / roles;
+  const int SUB = 1 << sub_log2;
   const int ne = ne_len(K);
-  const int slot = threadIdx.x / roles;
-  const int role = threadIdx.x - slot * roles;
-  const bool worker = slot < slots;
-  double* lz = reinterpret_cast<double*>(smem) + (size_t)(worker ? slot : 0) * 2 * N;
+  const int role = threadIdx.x >> sub_log2;
+  const int sub = threadIdx.x & (SUB - 1);
+  const bool worker = role < 2 * K + 1;
+  double* lz = reinterpret_cast<double*>(smem);
   double* ly = lz + N;
-  double* acc = reinterpret_cast<double*>(smem) + (size_t)slots * 2 * N + (size_t)(worker ? slot : 0) * ne;
+  double* acc = ly + N;
   if constexpr (!PER_VOXEL) {
-    for (int e = threadIdx.x; e < slots * ne; e += NE_THREADS)
-      (reinterpret_cast<double*>(smem) + (size_t)slots * 2 * N)[e] = 0.0;
+    for (int e = threadIdx.x; e < ne; e += NE_THREADS) acc[e] = 0.0;
   }
-  __syncthreads();
-  const int groups = (V + slots - 1) / slots;
-  for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
-    // stage the rows of this group's voxels (all threads help; slot s <- voxel grp*slots+s)
-    for (int s = 0; s < slots; ++s) {
-      const int v = grp * slots + s;
-      double* dz = reinterpret_cast<double*>(smem) + (size_t)s * 2 * N;
-      double* dy = dz + N;
-      if (v < V) {
-        const double* zr = z + (int64_t)v * ldz;
-        const TY* yr = y + (int64_t)v * ldy;
-        for (int i = threadIdx.x; i < N; i += NE_THREADS) {
-          dz[i] = zr[i];
-          dy[i] = (double)yr[i];
-        }
+  const int jb = N > K ? N - K : 0;            // sums over j < jb are truncation-free
+  for (int v = blockIdx.x; v < V; v += gridDim.x) {
+    __syncthreads();                           // previous voxel fully consumed
+    {
+      const double* zr = z + (int64_t)v * ldz;
+      const TY* yr = y + (int64_t)v * ldy;
+      for (int i = threadIdx.x; i < N; i += NE_THREADS) {
+        lz[i] = zr[i];
+        ly[i] = (double)yr[i];
       }
     }
     __syncthreads();
-    const int v = grp * slots + slot;
-    if (worker && v < V) {
-      double* dst = PER_VOXEL ? out + (int64_t)v * ne : acc;
+    double* dst = PER_VOXEL ? out + (int64_t)v * ne : acc;
+    double r = 0.0;
+    if (worker) {
+      if (role < K) {                          // autocorrelation, bulk part
+        const int d = role;
+        for (int j = sub; j < jb; j += SUB) r = fma(lz[j], lz[j + d], r);
+      } else if (role < 2 * K) {               // cross-correlation lag m, all of it
+        const int m = role - K;
+        for (int j = sub; j < N - m; j += SUB) r = fma(lz[j], ly[j + m], r);
+      } else {
+        for (int i = sub; i < N; i += SUB) r = fma(ly[i], ly[i], r);
+      }
+    }
+    for (int o = SUB >> 1; o >= 1; o >>= 1) r += __shfl_xor(r, o, 64);   // fixed order
+    if (worker && sub == 0) {
       if (role < K) {
         const int d = role;
-        double r = 0.0;
-        // T = j ; record at T = N-1-m' for m' = K-1 .. d  (j = N-K .. N-1-d)
-        const int j_rec = N - K;
-        for (int j = 0; j < N - d; ++j) {
+        // T = j; record at T = N-1-m' for m' = K-1 .. d  (j = N-K .. N-1-d)
+        for (int j = jb; j < N - d; ++j) {
           r = fma(lz[j], lz[j + d], r);
-          if (j >= j_rec) {
-            const int mp = N - 1 - j;          // m' = max(m, m'), m = m' - d
-            if (mp < K) {
-              const int m = mp - d;
-              if constexpr (PER_VOXEL) {
-                dst[m * K + mp] = r;
-                dst[mp * K + m] = r;
-              } else {
-                dst[m * K + mp] += r;
-                if (d) dst[mp * K + m] += r;
-              }
-            }
+          const int mp = N - 1 - j;            // m' = max(m, m') < K here, m = m' - d
+          const int m = mp - d;
+          if constexpr (PER_VOXEL) {
+            dst[m * K + mp] = r;
+            dst[mp * K + m] = r;
+          } else {
+            dst[m * K + mp] += r;
+            if (d) dst[mp * K + m] += r;
           }
         }
-        // series shorter than the HRF: entries whose truncation point lies before j = 0
         if constexpr (PER_VOXEL) {
-          for (int mp = (N - d > 0 ? N : d) ; mp < K; ++mp) {   // N-1-mp < 0
+          // series shorter than the HRF: truncation point before j = 0 -> empty sums
+          for (int mp = (N > d ? N : d); mp < K; ++mp) {
             const int m = mp - d;
             dst[m * K + mp] = 0.0;
             dst[mp * K + m] = 0.0;
@@ -105,26 +107,16 @@ __global__ __launch_bounds__(NE_THREADS) void normal_eq_kernel(const double* z, 
         }
       } else if (role < 2 * K) {
         const int m = role - K;
-        double s = 0.0;
-        for (int j = 0; j < N - m; ++j) s = fma(lz[j], ly[j + m], s);
-        if constexpr (PER_VOXEL) dst[K * K + m] = s; else dst[K * K + m] += s;
+        if constexpr (PER_VOXEL) dst[K * K + m] = r; else dst[K * K + m] += r;
       } else {
-        double s = 0.0;
-        for (int i = 0; i < N; ++i) s = fma(ly[i], ly[i], s);
-        if constexpr (PER_VOXEL) dst[K * K + K] = s; else dst[K * K + K] += s;
+        if constexpr (PER_VOXEL) dst[K * K + K] = r; else dst[K * K + K] += r;
       }
     }
-    __syncthreads();
   }
   if constexpr (!PER_VOXEL) {
-    // fold the slots of this block (fixed order) and publish the block's partial sums
-    const double* a0 = reinterpret_cast<double*>(smem) + (size_t)slots * 2 * N;
+    __syncthreads();
     double* part = out + (int64_t)blockIdx.x * ne;
-    for (int e = threadIdx.x; e < ne; e += NE_THREADS) {
-      double s = 0.0;
-      for (int q = 0; q < slots; ++q) s += a0[(size_t)q * ne + e];
-      part[e] = s;
-    }
+    for (int e = threadIdx.x; e < ne; e += NE_THREADS) part[e] = acc[e];
   }
 }
 
@@ -149,43 +141,52 @@ __device__ __forceinline__ double spm_hrf_value(const HrfModel& hm, double x) {
   return pdf(x - hm.loc1, hm.a1, hm.lg1) - hm.ratio * pdf(x - hm.loc2, hm.a2, hm.lg2);
 }
 
-// argmin_theta F(theta) over [lo, hi] for M independent normal-equation sets, one wave
-// (= 64 candidate dilations per refinement) per set: section search, the bracket shrinks to
-// the two grid cells around the best candidate (x31.5 per refinement); the last refinement
-// ends with the vertex of the parabola through the best candidate and its neighbours.
-// LDS: set [ne] then h [K][64] (lane-major columns, conflict-free).
+// argmin_theta F(theta) over [lo, hi] for M independent normal-equation sets, one
+// 256-thread workgroup per set: 64 candidate dilations per refinement (lane = candidate),
+// the K taps of each candidate and the K rows of the quadratic form dealt over the 4 waves.
+// Section search, the bracket shrinks to the two grid cells around the best candidate (x31.5
+// per refinement); the last refinement ends with the vertex of the parabola through the best
+// candidate and its neighbours.  Every wave reduces the same 64 values in the same order, so
+// the four agree on the bracket without exchanging it.
+// LDS: set [ne], h [K][64] (lane-major columns, conflict-free), part [4][64].
 // theta[s], cost[s] = F(theta*), taps[s][K] = h(theta*).
-__global__ __launch_bounds__(64) void theta_fit_kernel(const double* ne_sets, int64_t ldne, int M,
-                                                       int K, const double* t, HrfModel hm,
-                                                       double lo, double hi, int n_refine,
-                                                       double* theta, double* cost, double* taps,
-                                                       int64_t ldt) {
+__global__ __launch_bounds__(256) void theta_fit_kernel(const double* ne_sets, int64_t ldne, int M,
+                                                        int K, const double* t, HrfModel hm,
+                                                        double lo, double hi, int n_refine,
+                                                        double* theta, double* cost, double* taps,
+                                                        int64_t ldt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int s = blockIdx.x;
   if (s >= M) return;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int ne = ne_len(K);
   double* G = reinterpret_cast<double*>(smem);
   double* b = G + K * K;
-  double* hl = G + ne + lane;                 // h[k] of this lane at hl[k * 64]
+  double* hl = G + ne + lane;                 // h[k] of candidate `lane` at hl[k * 64]
+  double* part = G + ne + 64 * K;             // [4][64]
   const double* src = ne_sets + (int64_t)s * ldne;
-  for (int e = lane; e < ne; e += 64) G[e] = src[e];
+  for (int e = threadIdx.x; e < ne; e += 256) G[e] = src[e];
   __syncthreads();
   const double yy = b[K];
 
   auto price = [&](double th) -> double {
-    for (int k = 0; k < K; ++k) hl[k * 64] = spm_hrf_value(hm, th * t[k]);
+    for (int k = wv; k < K; k += 4) hl[k * 64] = spm_hrf_value(hm, th * t[k]);
+    __syncthreads();
     double quad = 0.0, lin = 0.0;
-    for (int m = 0; m < K; ++m) {
+    for (int m = wv; m < K; m += 4) {
       double row = 0.0;
       for (int mp = 0; mp < K; ++mp) row = fma(G[m * K + mp], hl[mp * 64], row);
       quad = fma(hl[m * 64], row, quad);
       lin = fma(hl[m * 64], b[m], lin);
     }
-    return 0.5 * yy - lin + 0.5 * quad;
+    part[wv * 64 + lane] = 0.5 * quad - lin;
+    __syncthreads();
+    const double f = 0.5 * yy + ((part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]));
+    __syncthreads();                           // hl / part are rewritten by the next call
+    return f;
   };
 
-  double a = lo, c = hi, best_t = lo, best_f = 0.0;
+  double a = lo, c = hi, best_t = lo;
   for (int r = 0; r < n_refine; ++r) {
     const double th = a + (c - a) * ((double)lane / 63.0);
     const double f = price(th);
@@ -202,7 +203,6 @@ __global__ __launch_bounds__(64) void theta_fit_kernel(const double* ne_sets, in
     const double tl = __shfl(th, il, 64), tm = __shfl(th, im, 64), tr = __shfl(th, ir, 64);
     const double fl = __shfl(f, il, 64), fr = __shfl(f, ir, 64);
     best_t = tm;
-    best_f = fm;
     if (r == n_refine - 1 && im > 0 && im < 63) {
       // vertex of the parabola through (tl, fl), (tm, fm), (tr, fr); equal spacing
       const double den = fl - 2.0 * fm + fr;
@@ -216,15 +216,15 @@ __global__ __launch_bounds__(64) void theta_fit_kernel(const double* ne_sets, in
     a = tl;
     c = tr;
   }
-  // cost and taps at the returned dilation (every lane prices it; lane 0 publishes)
-  best_f = price(best_t);
-  if (lane == 0) {
+  // cost and taps at the returned dilation (every lane prices it; one thread publishes)
+  const double best_f = price(best_t);
+  if (threadIdx.x == 0) {
     theta[s] = best_t;
     cost[s] = best_f;
   }
   if (taps) {
     double* trow = taps + (int64_t)s * ldt;
-    for (int k = lane; k < K; k += 64) trow[k] = spm_hrf_value(hm, best_t * t[k]);
+    for (int k = threadIdx.x; k < K; k += 256) trow[k] = spm_hrf_value(hm, best_t * t[k]);
   }
 }
 

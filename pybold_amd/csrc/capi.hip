@@ -209,7 +209,7 @@ int lambda_max_impl(const TY* y_dev, int64_t ldy, int V, int N, const double* ta
   return check_launch(name);
 }
 
-constexpr int NE_MAX_BLOCKS = 1024;
+constexpr int NE_MAX_BLOCKS = 2048;
 
 template <typename TY>
 int normal_eq_impl(const double* z_dev, int64_t ldz, const TY* y_dev, int64_t ldy, int V, int N,
@@ -218,30 +218,30 @@ int normal_eq_impl(const double* z_dev, int64_t ldz, const TY* y_dev, int64_t ld
   if (V < 0 || N < 1 || K < 1 || K > 127 || ldz < N || ldy < N)
     return fail(PB_ERR_INVALID, "%s: bad size (V=%d N=%d K=%d)", name, V, N, K);
   const int ne = pb::ne_len(K);
-  const int slots = pb::NE_THREADS / (2 * K + 1);
-  const int64_t nd = (int64_t)slots * 2 * N + (per_voxel ? 0 : (int64_t)slots * ne);
+  int sub_log2 = 0;                            // lanes per role: 4 for K <= 31, 2 for K <= 63
+  while ((2 * K + 1) << (sub_log2 + 1) <= pb::NE_THREADS && sub_log2 < 2) ++sub_log2;
+  const int64_t nd = 2 * (int64_t)N + (per_voxel ? 0 : ne);
   if (nd > LDS_DOUBLES_MAX) return fail(PB_ERR_INVALID, "%s: N=%d K=%d exceeds LDS", name, N, K);
-  if (!out_dev) return fail(PB_ERR_INVALID, "%s: NULL output", name);
-  const int groups = (V + slots - 1) / slots;
   const size_t lds = (size_t)nd * sizeof(double);
   if (per_voxel) {
     if (V == 0) return PB_OK;
-    if (!z_dev || !y_dev) return fail(PB_ERR_INVALID, "%s: NULL pointer", name);
-    hipLaunchKernelGGL((pb::normal_eq_kernel<TY, true>), dim3(groups < 65535 * 16 ? groups : 65535 * 16),
+    if (!z_dev || !y_dev || !out_dev) return fail(PB_ERR_INVALID, "%s: NULL pointer", name);
+    hipLaunchKernelGGL((pb::normal_eq_kernel<TY, true>), dim3(V < 65536 ? V : 65536),
                        dim3(pb::NE_THREADS), lds, (hipStream_t)stream, z_dev, ldz, y_dev, ldy, V, N, K,
-                       out_dev);
+                       sub_log2, out_dev);
     return check_launch(name);
   }
   // shared mode: block partials in work_dev, then a fixed-order sum (an empty shard yields
   // zeros, so that the rank still contributes to the all-reduce)
-  int blocks = groups < NE_MAX_BLOCKS ? groups : NE_MAX_BLOCKS;
+  if (!out_dev) return fail(PB_ERR_INVALID, "%s: NULL output", name);
+  int blocks = V < NE_MAX_BLOCKS ? V : NE_MAX_BLOCKS;
   if (work_len / ne < blocks) blocks = (int)(work_len / ne);
   if (V > 0) {
     if (blocks < 1 || !work_dev)
       return fail(PB_ERR_INVALID, "%s: work buffer must hold at least %d doubles", name, ne);
     if (!z_dev || !y_dev) return fail(PB_ERR_INVALID, "%s: NULL pointer", name);
     hipLaunchKernelGGL((pb::normal_eq_kernel<TY, false>), dim3(blocks), dim3(pb::NE_THREADS), lds,
-                       (hipStream_t)stream, z_dev, ldz, y_dev, ldy, V, N, K, work_dev);
+                       (hipStream_t)stream, z_dev, ldz, y_dev, ldy, V, N, K, sub_log2, work_dev);
   } else {
     blocks = 0;
   }
@@ -270,8 +270,7 @@ int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mod
     if (we && stop_mode == PB_STOP_WINDOW && (wind != 6 || we->S > 20)) we = nullptr;
     return we ? 3 : 0;
   }
-  if (fe->fn_pair && !with_cost_trace && stop_mode == PB_STOP_NONE && P >= 2 && pair_is_faster(P))
-    return 2;
+  if (fe->fn_pair && stop_mode == PB_STOP_NONE && P >= 2 && pair_is_faster(P)) return 2;
   return 1;
 }
 
@@ -308,11 +307,9 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
   // (the reference default) on entries small enough to hold them; else LDS kernel
   if (fe && stop_mode == PB_STOP_WINDOW && (wind != 6 || fe->S > 20)) fe = nullptr;
   if (fe) {
-    // no stop rule: two problems per DPP row when that form finishes first.  With the
-    // cost trace the pair form spills a few registers and only ties the single-row
-    // kernel (measured 21.5 vs 21.7 ms), so it is used for it only on request.
+    // no stop rule (cost trace or not): two problems per DPP row when that form finishes first
     if (fe->fn_pair && stop_mode == PB_STOP_NONE && P >= 2 && !(flags & PB_FLAG_NO_PAIR) &&
-        ((flags & PB_FLAG_FORCE_PAIR) || (!J_dev && pair_is_faster(P)))) {
+        ((flags & PB_FLAG_FORCE_PAIR) || pair_is_faster(P))) {
       if (fe->fn_pair(a, taps_host, K, J_dev != nullptr, (hipStream_t)stream) != 0)
         return fail(PB_ERR_INVALID, "pb_fista_solve: pair kernel rejected the launch");
       return check_launch("fista_pair_kernel");
@@ -560,13 +557,13 @@ int pb_theta_fit(const double* ne_dev, int64_t ldne, int M, int K, const double*
   if (M < 0 || K < 1 || K > 127 || n_refine < 1 || !(a_peak > 0.0) || !(a_under > 0.0) ||
       !(lo <= hi) || (M > 1 && ldne < pb::ne_len(K)) || (taps_dev && M > 1 && ldt < K))
     return fail(PB_ERR_INVALID, "pb_theta_fit: bad argument");
-  const int64_t nd = (int64_t)pb::ne_len(K) + 64 * (int64_t)K;
+  const int64_t nd = (int64_t)pb::ne_len(K) + 64 * (int64_t)K + 256;
   if (nd > LDS_DOUBLES_MAX) return fail(PB_ERR_INVALID, "pb_theta_fit: K=%d exceeds LDS", K);
   if (M == 0) return PB_OK;
   if (!ne_dev || !t_dev || !theta_dev || !cost_dev)
     return fail(PB_ERR_INVALID, "pb_theta_fit: NULL pointer");
   pb::HrfModel hm{a_peak, loc_peak, lgamma(a_peak), a_under, loc_under, lgamma(a_under), ratio};
-  hipLaunchKernelGGL(pb::theta_fit_kernel, dim3(M), dim3(64), (size_t)nd * sizeof(double),
+  hipLaunchKernelGGL(pb::theta_fit_kernel, dim3(M), dim3(256), (size_t)nd * sizeof(double),
                      (hipStream_t)stream, ne_dev, ldne, M, K, t_dev, hm, lo, hi, n_refine, theta_dev,
                      cost_dev, taps_dev, ldt);
   return check_launch("pb_theta_fit");

@@ -312,8 +312,10 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
         w[j] = fma(nb1, d, u);
       }
     } else {
-      // One pass per sample: gradient step, prox+momentum, stop-rule partial sums.
-      // A stopped problem (row) keeps its iterate: the select is per lane.
+      // One pass per sample: gradient step, prox+momentum, stop-rule partial sums.  The
+      // iterate is updated unconditionally: a problem (row) that meets its rule is written
+      // out at that moment (rare, divergent store) and its lanes simply keep iterating,
+      // results discarded -- cheaper than a per-sample select in every iteration.
       double num = 0.0, den = 0.0;
       double floor_eps = 1.0e-10;
       if constexpr (STOP == 1) {
@@ -327,8 +329,10 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
           const double diff = wn - u;
           num = fma(diff, diff, num);
           den = fma(wn, wn, den);
-          w[j] = active ? wn : w[j];
+          w[j] = wn;
         }
+        num = seg_allsum_f64<LPV>(num);
+        den = seg_allsum_f64<LPV>(den);
       } else {
         // deconv window rule, wind = 6 (pybold/bold_signal.py:82-95): the stored iterates
         // are [u_{k-4} .. u_k, w_{k+1}] (each stored w was overwritten in place by the next
@@ -336,47 +340,60 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
         // three.  With delta_i = u_i - u_{i-1} and e = w_{k+1} - u_k:
         //   3 (new - old) = delta_{k-3} + 2 delta_{k-2} + 3 delta_{k-1} + 2 delta_k + e
         //   3 new         = 3 u_k - delta_k + e
-        // (sums left unscaled, so is the 1e-10 floor).
+        // (sums left unscaled, so is the 1e-10 floor).  delta_k and e are differences of
+        // float64 values rounded to float32 (relative accuracy 6e-8 each); the two norms are
+        // then accumulated as one packed float32 pair.  The criterion is accurate to ~1e-6
+        // relative, well inside what the float32 FIRs of the iterate itself leave of it.
         floor_eps = 3.0e-10;
         const float* r1 = ring + ((it + 3) & 3) * S * LPV;   // delta_{k-1}
         const float* r2 = ring + ((it + 2) & 3) * S * LPV;   // delta_{k-2}
         const float* r3 = ring + ((it + 1) & 3) * S * LPV;   // delta_{k-3}
         float* r0 = ring + (it & 3) * S * LPV;               // delta_k goes here
+        f2 nd = f2{0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < S; ++j) {
           const double u = fma(nstep, (double)g[j], w[j]);
           const double d = fmin(fmax(u, -th), th);
           const double wn = fma(nb1, d, u);
           const float dk = (float)(u - uprev[j]);
+          const float ef = (float)(wn - u);
+          const float uf = (float)u;
           const float dsum = fmaf(2.0f, dk, fmaf(3.0f, r1[j * LPV], fmaf(2.0f, r2[j * LPV], r3[j * LPV])));
-          const double e = wn - u;
-          const double diff = (double)dsum + e;
-          const double sn = fma(3.0, u, e - (double)dk);
-          num = fma(diff, diff, num);
-          den = fma(sn, sn, den);
+          const f2 v = f2{dsum + ef, fmaf(3.0f, uf, ef - dk)};
+          nd = __builtin_elementwise_fma(v, v, nd);
           r0[j * LPV] = dk;
           uprev[j] = u;
-          w[j] = active ? wn : w[j];
+          w[j] = wn;
         }
+        num = (double)seg_allsum<LPV>(nd.x);
+        den = (double)seg_allsum<LPV>(nd.y);
       }
-      num = seg_allsum_f64<LPV>(num);
-      den = seg_allsum_f64<LPV>(den);
       if (active) {
         done = it + 1;
         constexpr int first_test = (STOP == 1) ? 3 : WIND + 1;
         static_assert(STOP != 2 || first_test >= 4, "the increment ring holds 4 valid slots from it = 3 on");
-        if (it >= first_test && sqrt(num) / (sqrt(den) + floor_eps) < a.tol) active = false;
+        if (it >= first_test && sqrt(num) / (sqrt(den) + floor_eps) < a.tol) {
+          active = false;
+          if (live) {                           // this problem is finished: write it out now
+            double* wrow = a.w + (int64_t)p * a.ldw;
+#pragma unroll
+            for (int j = 0; j < S; ++j)
+              if (base + j < a.N) wrow[base + j] = w[j];
+          }
+        }
       }
       if (__builtin_amdgcn_ballot_w64(active) == 0) n_stop = it + 1;
     }
   }
 
-  // ---- store the final iterate ---------------------------------------------
+  // ---- store the final iterate (problems stopped by their rule were stored then) -----
   if (live) {
-    double* wrow = a.w + (int64_t)p * a.ldw;
+    if (STOP == 0 || active) {
+      double* wrow = a.w + (int64_t)p * a.ldw;
 #pragma unroll
-    for (int j = 0; j < S; ++j)
-      if (base + j < a.N) wrow[base + j] = w[j];
+      for (int j = 0; j < S; ++j)
+        if (base + j < a.N) wrow[base + j] = w[j];
+    }
     if (a.n_done && sub == 0) a.n_done[p] = (STOP == 0) ? a.n_iter : done;
   }
 }

@@ -74,6 +74,10 @@ __global__ __launch_bounds__(256, 2) void fista_pair_kernel(FistaArgs a, TapsF<K
   float* lm = reinterpret_cast<float*>(pair_smem + (size_t)16 * S * 16 * sizeof(f2)) + (rslot + sub);
   double* stage_d = reinterpret_cast<double*>(reinterpret_cast<f2*>(pair_smem) + rslot);
   float* stage_f = reinterpret_cast<float*>(pair_smem + (size_t)16 * S * 16 * sizeof(f2)) + rslot;
+  // cost trace only: per-row scratch {lbda_A, lbda_B, ||w_A||_1, ||w_B||_1} behind the mask
+  // region, so that none of them is live in registers across the FIRs (the register peak)
+  float* lj = reinterpret_cast<float*>(pair_smem + (size_t)16 * S * 16 * (sizeof(f2) + sizeof(float))) +
+              (threadIdx.x >> 4) * 4;
   auto lds_sync = [] {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -125,27 +129,32 @@ __global__ __launch_bounds__(256, 2) void fista_pair_kernel(FistaArgs a, TapsF<K
   const double thA = lbA * a.step, thB = lbB * a.step;
   const double nstep = -a.step;
 
-  const float lbfA = (float)lbA, lbfB = (float)lbB;
-  float* JA = WITH_J ? a.J + (int64_t)pA * a.ldj : nullptr;
-  float* JB = WITH_J ? a.J + (int64_t)pB * a.ldj : nullptr;
-  // with WITH_J one more forward pass follows the last iteration to price its iterate
-  for (int it = 0;; ++it) {
-    if (!WITH_J && it >= a.n_iter) break;
+  if constexpr (WITH_J) {
+    lj[0] = (float)lbA;
+    lj[1] = (float)lbB;
+  }
+  // ---- forward pass: r = h * cumsum(w) - y for both problems ------------------------
+  auto forward = [&](f2 (&r)[S]) __attribute__((always_inline)) {
     asm volatile("" ::: "memory");          // keep the LDS reads inside the loop
-    // This translation unit keeps program order (Makefile: PAIRFLAGS), so loads are
-    // placed by hand well ahead of their use: the momentum factor here, y and the mask
-    // one output group ahead inside the FIR.
-    const double beta = (it < a.n_iter) ? a.betas[it] : 0.0;
     // ---- z = cumsum(w) for both problems -----------------------------------
     f2 z[S];
-    f2 l1 = f2{0.f, 0.f};                     // ||w||_1 of the iterate this pass starts from
     z[0] = f2{(float)wA[0], (float)wB[0]};
-    if constexpr (WITH_J) l1 = __builtin_elementwise_abs(z[0]);
+    if constexpr (WITH_J) {
+      // ||w||_1 of the iterate this pass starts from (|.| folds into the add as a source
+      // modifier); reduced over the row now and parked in LDS until the residual is known
+      float l1a = fabsf(z[0].x), l1b = fabsf(z[0].y);
 #pragma unroll
-    for (int j = 1; j < S; ++j) {
-      const f2 wj = f2{(float)wA[j], (float)wB[j]};
-      z[j] = z[j - 1] + wj;
-      if constexpr (WITH_J) l1 += __builtin_elementwise_abs(wj);
+      for (int j = 1; j < S; ++j) {
+        const f2 wj = f2{(float)wA[j], (float)wB[j]};
+        z[j] = z[j - 1] + wj;
+        l1a += fabsf(wj.x);
+        l1b += fabsf(wj.y);
+      }
+      lj[2] = row_allsum(l1a);
+      lj[3] = row_allsum(l1b);
+    } else {
+#pragma unroll
+      for (int j = 1; j < S; ++j) z[j] = z[j - 1] + f2{(float)wA[j], (float)wB[j]};
     }
     {
       const f2 off = f2{row_from_below<1>(row_prefix_incl(z[S - 1].x)),
@@ -173,8 +182,6 @@ __global__ __launch_bounds__(256, 2) void fista_pair_kernel(FistaArgs a, TapsF<K
     // Outputs are produced in groups of G with the tap loop outside, so that G
     // independent accumulator chains sit next to each other in program order (a
     // dependent v_pk_fma_f32 straight after its producer costs a wait state).
-    f2 r[S];
-    f2 sq = f2{0.f, 0.f};                      // ||r||^2, accumulated as the residual is produced
     f2 ypre[G];                               // -y and mask of the group about to start
     float mpre[G];
 #pragma unroll
@@ -195,11 +202,9 @@ __global__ __launch_bounds__(256, 2) void fista_pair_kernel(FistaArgs a, TapsF<K
       if constexpr (j0 + G < S) {             // issue the next group's LDS reads now
 #pragma unroll
         for (int q = 0; q < G; ++q) {
-          constexpr int dummy = 0;
           const int jn = (j0 + G + q < S) ? j0 + G + q : S - 1;
           ypre[q] = ly[jn * 16];
           mpre[q] = lm[jn * 16];
-          (void)dummy;
         }
       }
       static_for<(SKIP0 ? 1 : 0), KT>([&](auto mc) {
@@ -212,24 +217,12 @@ __global__ __launch_bounds__(256, 2) void fista_pair_kernel(FistaArgs a, TapsF<K
         });
       });
 #pragma unroll
-      for (int q = 0; q < gn; ++q) {
-        r[j0 + q] = acc[q] * f2{mcur[q], mcur[q]};
-        if constexpr (WITH_J) sq = __builtin_elementwise_fma(r[j0 + q], r[j0 + q], sq);
-      }
+      for (int q = 0; q < gn; ++q) r[j0 + q] = acc[q] * f2{mcur[q], mcur[q]};
     });
+  };
 
-    if constexpr (WITH_J) {
-      if (it > 0) {
-        const float cA = row_allsum(fmaf(0.5f, sq.x, lbfA * l1.x));
-        const float cB = row_allsum(fmaf(0.5f, sq.y, lbfB * l1.y));
-        if (sub == 0) {
-          if (liveA) JA[it - 1] = cA;
-          if (liveB) JB[it - 1] = cB;
-        }
-      }
-      if (it >= a.n_iter) break;
-    }
-
+  // ---- adjoint pass and update: w <- prox step from the residual r -------------------
+  auto backward = [&](const f2 (&r)[S], const double beta) __attribute__((always_inline)) {
     // ---- window of r: own samples [0, S), halo [S, S+H) from the lanes above ----
     f2 R[S + H];
     static_for<0, S>([&](auto jc) {
@@ -301,6 +294,38 @@ __global__ __launch_bounds__(256, 2) void fista_pair_kernel(FistaArgs a, TapsF<K
         wB[j] = fma(nb1, dB[j], uB[j]);
       }
     }
+  };
+
+  // This translation unit keeps program order (Makefile: PAIRFLAGS), so loads are placed by
+  // hand well ahead of their use: the momentum factor at the top of an iteration, y and the
+  // mask one output group ahead inside the FIR.
+  if constexpr (!WITH_J) {
+    for (int it = 0; it < a.n_iter; ++it) {
+      const double beta = a.betas[it];
+      f2 r[S];
+      forward(r);
+      backward(r, beta);
+    }
+  } else {
+    // cost of iterate k+1 = residual of the forward pass of iteration k+1: the loop is
+    // rotated (forward pass at the bottom, one peeled in front) so that it has a single
+    // exit and the iterate stays in the same registers around the back edge
+    f2 r[S];
+    forward(r);
+    for (int it = 0; it < a.n_iter; ++it) {
+      const double beta = a.betas[it];
+      backward(r, beta);
+      forward(r);
+      f2 sq = r[0] * r[0];                      // ||r||^2 of the new iterate
+#pragma unroll
+      for (int j = 1; j < S; ++j) sq = __builtin_elementwise_fma(r[j], r[j], sq);
+      const float cA = fmaf(0.5f, row_allsum(sq.x), lj[0] * lj[2]);
+      const float cB = fmaf(0.5f, row_allsum(sq.y), lj[1] * lj[3]);
+      if (sub == 0) {
+        if (liveA) a.J[(int64_t)pA * a.ldj + it] = cA;
+        if (liveB) a.J[(int64_t)pB * a.ldj + it] = cB;
+      }
+    }
   }
 
   // epilogue: strips -> LDS -> coalesced stores (the y/mask contents are dead now)
@@ -330,9 +355,10 @@ int launch_pair(const FistaArgs& a, const double* taps, int K, bool with_j, hipS
   const auto tf = make_taps_f<KT>(taps, K);
   const int64_t rows = ((int64_t)a.P + 1) / 2;
   const dim3 grid((unsigned)((rows * 16 + 255) / 256)), block(256);
-  const size_t lds = (size_t)16 * S * 16 * (sizeof(f2) + sizeof(float));
+  const size_t lds = (size_t)16 * S * 16 * (sizeof(f2) + sizeof(float)) + (with_j ? 16 * 4 * sizeof(float) : 0);
   const bool skip0 = KT > 1 && tf.pr[0].x == 0.0f;      // leading tap exactly zero
-  if (with_j) hipLaunchKernelGGL((fista_pair_kernel<S, KT, true, false>), grid, block, lds, st, a, tf);
+  if (with_j && skip0) hipLaunchKernelGGL((fista_pair_kernel<S, KT, true, true>), grid, block, lds, st, a, tf);
+  else if (with_j) hipLaunchKernelGGL((fista_pair_kernel<S, KT, true, false>), grid, block, lds, st, a, tf);
   else if (skip0) hipLaunchKernelGGL((fista_pair_kernel<S, KT, false, true>), grid, block, lds, st, a, tf);
   else hipLaunchKernelGGL((fista_pair_kernel<S, KT, false, false>), grid, block, lds, st, a, tf);
   return 0;

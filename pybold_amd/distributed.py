@@ -129,7 +129,7 @@ class HipOps:
     def normal_eq(self, W, Y, K):
         Z = self.s.integ_op(W)
         if self.work is None:
-            self.work = torch.empty((512 * (K * K + K + 1),), dtype=torch.float64, device=Y.device)
+            self.work = torch.empty((2048 * (K * K + K + 1),), dtype=torch.float64, device=Y.device)
         return self.s.hrf_normal_eq(Z, Y, K, work=self.work)
 
     def theta_fit(self, ne, bounds):            # -> theta (1,), F(theta) (1,), taps (K,)

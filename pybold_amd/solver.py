@@ -455,10 +455,8 @@ def spm_hrf_batch(deltas, t_r, dur, dt=0.001, p_delay=6, undershoot=16.0, p_disp
     lib = _lib.load()
     dev = deltas.device
     d = deltas.to(torch.float64).contiguous()
-    n_fine = int(float(dur) / dt)
-    t = np.linspace(0, dur, n_fine)[::int(t_r / dt)]
-    t_dev = torch.from_numpy(np.ascontiguousarray(t)).to(dev)
-    M, K = d.numel(), len(t)
+    t_dev = _sample_times_on(dev, t_r, dur, dt)
+    M, K = d.numel(), t_dev.numel()
     out = torch.empty((M, K), dtype=torch.float64, device=dev)
     with torch.cuda.device(dev):
         rc = lib.pb_spm_hrf(d.data_ptr(), M, t_dev.data_ptr(), K, p_delay / p_disp, dt / p_disp,
@@ -520,7 +518,7 @@ def hrf_normal_eq(Z, Y, n_taps, per_voxel=False, work=None):
     else:
         out = torch.empty((ne,), dtype=torch.float64, device=dev)
         if work is None or work.numel() < ne:
-            work = torch.empty((512 * ne,), dtype=torch.float64, device=dev)
+            work = torch.empty((2048 * ne,), dtype=torch.float64, device=dev)
         work_ptr, work_len = work.data_ptr(), work.numel()
     with torch.cuda.device(dev):
         rc = fn(Z.data_ptr(), _ld(Z) if V else N, Y.data_ptr(), _ld(Y) if V else N, V, N, K,
@@ -535,6 +533,20 @@ def hrf_sample_times(t_r, dur, dt=0.001):
     return np.ascontiguousarray(np.linspace(0, dur, int(float(dur) / dt))[::int(t_r / dt)])
 
 
+_times_cache = {}
+
+
+def _sample_times_on(dev, t_r, dur, dt=0.001):
+    """The HRF sample times as a device tensor, uploaded once per (device, t_r, dur): a
+    pageable host-to-device copy would otherwise synchronise every call."""
+    key = (dev.type, dev.index, float(t_r), float(dur), float(dt))
+    t = _times_cache.get(key)
+    if t is None:
+        t = torch.from_numpy(hrf_sample_times(t_r, dur, dt)).to(dev)
+        _times_cache[key] = t
+    return t
+
+
 def theta_fit(ne, t_r, dur, bounds, n_refine=3, dt=0.001, p_delay=6, undershoot=16.0, p_disp=1.0,
               u_disp=1.0, p_u_ratio=0.167):
     """``argmin_theta 0.5 ||y - h(theta) * z||^2`` over ``bounds = (lo, hi)`` from normal
@@ -545,12 +557,11 @@ def theta_fit(ne, t_r, dur, bounds, n_refine=3, dt=0.001, p_delay=6, undershoot=
     one = ne.dim() == 1
     ne2 = _rows(ne.reshape(1, -1) if one else ne, torch.float64, "ne")
     dev = ne2.device
-    t = hrf_sample_times(t_r, dur, dt)
-    K = len(t)
+    t_dev = _sample_times_on(dev, t_r, dur, dt)
+    K = t_dev.numel()
     if ne2.shape[1] != int(lib.pb_hrf_normal_eq_len(K)):
         raise ValueError("normal equations do not match an HRF of %d taps" % K)
     M = ne2.shape[0]
-    t_dev = torch.from_numpy(t).to(dev)
     theta = torch.empty((M,), dtype=torch.float64, device=dev)
     cost = torch.empty((M,), dtype=torch.float64, device=dev)
     taps = torch.empty((M, K), dtype=torch.float64, device=dev)

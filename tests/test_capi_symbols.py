@@ -52,10 +52,10 @@ def test_version_and_dispatch_table(lib):
     assert lib.pb_fista_has_fast_path(300, 49) == 0
     assert lib.pb_fista_has_fast_path(300, 5000) == 0
     assert lib.pb_fista_has_fast_path(0, 30) == 0
-    # dispatch of a plain solve: pair kernel for machine-filling batches, single-row
-    # kernel for small ones and whenever a cost trace or a stop rule is requested
+    # dispatch of a plain solve: pair kernel for machine-filling batches (with or without
+    # the cost trace), single-row kernel for small ones and whenever a stop rule is requested
     assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 0, 6) == 2
-    assert lib.pb_fista_which_kernel(300, 30, 100000, 1, 0, 6) == 1
+    assert lib.pb_fista_which_kernel(300, 30, 100000, 1, 0, 6) == 2      # cost trace: pair form too
     assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 2, 6) == 1
     assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 2, 4) == 0
     assert lib.pb_fista_which_kernel(300, 30, 1, 0, 0, 6) == 1

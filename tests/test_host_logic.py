@@ -120,3 +120,29 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(root, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text, f
                 assert "pybold_oracle" not in text and "fista_oracle" not in text, f
+
+
+def test_bench_job_layout_and_self_launch_guard():
+    """bench.py: strong scaling shards BASELINE config 3's 100k voxels over the ranks
+    (12 500 per GPU at 8), weak gives every rank its own batch; `--gpus N` from a bare shell
+    on a machine with fewer GPUs fails cleanly before anything touches a GPU."""
+    import os
+    import subprocess
+    import sys
+    import bench
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for world in (1, 2, 4, 8, 3, 7):
+        spans = [bench.job_layout(100000, "strong", world, r) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == 100000 and all(s[2] == 100000 for s in spans)
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))          # contiguous, disjoint
+        assert max(s[1] - s[0] for s in spans) == -(-100000 // world)
+        weak = [bench.job_layout(100000, "weak", world, r) for r in range(world)]
+        assert all(w[1] - w[0] == 100000 and w[2] == 100000 * world for w in weak)
+    assert bench.job_layout(100000, "strong", 8, 3)[1] - bench.job_layout(100000, "strong", 8, 3)[0] == 12500
+    assert bench.flops_per_voxel_iter(300, 30) == 39600.0                   # SURVEY 8d
+    import torch
+    if torch.cuda.device_count() < 2:
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"],
+                           env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 2 and "needs 2 GPUs" in r.stderr and r.stdout.strip() == ""
