@@ -9,15 +9,15 @@ examples/icassp_2019/simulation.py:62-72), executed for all voxels at once:
            (``pb_gram_frobenius`` gives the V Lipschitz constants);
   theta-step  per voxel ``argmin_theta 0.5 ||y_v - h(theta) * z_v||^2`` over the
            bounds.  The reference calls SciPy's L-BFGS-B once per voxel with a
-           finite-difference gradient (:329-333); a per-voxel Python optimiser
-           cannot be batched, so the same bounded 1-D problem is solved by a
-           parallel section search: every launch prices ``n_grid`` dilations per
-           voxel (``pb_spm_hrf`` + ``pb_hrf_cost_pv``) and the bracket shrinks
-           around the best one.  It returns the minimiser over the whole
-           interval, which is L-BFGS-B's answer whenever the cost is unimodal on
-           the bounds (the reference's own early termination, factr = 1e7, leaves
-           theta accurate to ~1e-5; parity with ``bd`` is therefore asserted at
-           1e-3, not at the solver's 1e-5).
+           finite-difference gradient (:329-333), every evaluation a pass over the
+           voxel's data; a per-voxel Python optimiser cannot be batched.  The cost is
+           a quadratic form in the K taps, so ONE pass (``pb_hrf_normal_eq``) yields
+           every voxel's ``(G, b, yy)`` and the bounded 1-D problem is solved on those
+           numbers by a section search closed with a parabola vertex
+           (``pb_theta_fit``).  It returns the minimiser over the whole interval,
+           which is L-BFGS-B's answer whenever the cost is unimodal on the bounds, to
+           better accuracy than the reference's own early termination (factr = 1e7
+           leaves theta accurate to ~1e-5).
 
 The single-voxel ``bd`` keeps SciPy in the loop and is the exact reference
 semantic; ``bd`` dispatches 2-D inputs here.
@@ -29,11 +29,22 @@ from . import solver
 from .hrf_model import MAX_DELTA, MIN_DELTA
 
 
-def fit_dilations(Z, Y, t_r, hrf_dur, bounds, n_grid=17, n_refine=9):
+def fit_dilations(Z, Y, t_r, hrf_dur, bounds, n_refine=3):
     """Per-voxel ``argmin`` of ``hrf_fit_err`` (pybold/bold_signal.py:217-222) over
-    ``[lo, hi]`` by parallel section search.  ``Z`` float64, ``Y`` float32, CUDA
-    ``(V, N)``.  Returns ``(theta (V,), cost (V,))`` float64 CUDA tensors; the
-    bracket shrinks by ``(n_grid - 1) / 2`` per launch (1.3 -> 1e-8 in 9)."""
+    ``[lo, hi]``.  ``Z`` float64, ``Y`` float32 (or float64), CUDA ``(V, N)``.  Two launches
+    whatever the number of candidates: ``pb_hrf_normal_eq`` (one pass over the data: the cost
+    is a quadratic form in the taps) and ``pb_theta_fit`` (section search + parabola vertex
+    on those numbers, 64 dilations per refinement).  Returns ``(theta (V,), cost (V,),
+    taps (V, K))`` float64 CUDA tensors."""
+    K = len(solver.hrf_sample_times(t_r, hrf_dur))
+    ne = solver.hrf_normal_eq(Z, Y, K, per_voxel=True)
+    return solver.theta_fit(ne, t_r, hrf_dur, bounds[0], n_refine=n_refine)
+
+
+def fit_dilations_grid(Z, Y, t_r, hrf_dur, bounds, n_grid=17, n_refine=9):
+    """The same minimiser by pricing every candidate with a pass over the data
+    (``pb_spm_hrf`` + ``pb_hrf_cost_pv``, 17 dilations per launch, bracket / 8 per launch):
+    the round-1 form, kept as an independent check of :func:`fit_dilations`."""
     dev = Z.device
     V = Z.shape[0]
     lo, hi = bounds[0]
@@ -112,9 +123,12 @@ def bd_batch(Y, t_r, lbda=1.0, theta_0=None, z_0=None, hrf_dur=20.0, bounds=None
         Wn = z_step(W, taps)
         W = Wn if bool(active.all()) else torch.where(active[:, None], Wn, W)
         Z = solver.integ_op(W)
-        th_new, _ = fit_dilations(Z, Y, t_r, hrf_dur, bounds)
-        theta = torch.where(active, th_new, theta)
-        taps = solver.spm_hrf_batch(theta, t_r, hrf_dur)
+        th_new, _, taps_new = fit_dilations(Z, Y, t_r, hrf_dur, bounds)
+        if bool(active.all()):
+            theta, taps = th_new, taps_new
+        else:
+            theta = torch.where(active, th_new, theta)
+            taps = torch.where(active[:, None], taps_new, taps)
         record(W, taps, 1.0e-30)
         if verbose > 0:
             print("bd_batch outer %d: median theta %.4f, median J %.6f"

@@ -28,17 +28,17 @@ constexpr int NE_THREADS = 256;
 __host__ __device__ inline int ne_len(int K) { return K * K + K + 1; }
 
 // Layout of one normal-equation set: G row-major [K][K], then b [K], then yy.
-// Shared mode (PER_VOXEL = false): block B sums its voxels into part[B][ne_len]; a second
-// kernel adds the blocks in a fixed order (deterministic).  PER_VOXEL: out[v][ne_len].
 // One voxel at a time per workgroup; SUB adjacent lanes share one role (SUB = 4 for K <= 31):
 //   role r <  K   autocorrelation lag r        (G diagonals)
 //        r < 2K   cross-correlation lag r-K    (b)
 //        r = 2K   yy
-// The sums over j < N-K have no truncation point inside them, so the SUB lanes of a role
-// split them (stride SUB) and fold with two shuffles; lane 0 of the role then walks the last
-// K samples alone, recording the running sum at each truncation point.
-// LDS: z[N] y[N] (float64) and, in shared mode, acc[ne_len].
-template <typename TY, bool PER_VOXEL>
+// The sums over j < jb = N-K have no truncation point inside them ("bulk"), so the SUB lanes
+// of a role split them (stride SUB); only the last K samples ("tail") need the running sum
+// at every truncation point.  LDS: z[N] y[N] (float64).
+
+// One set per voxel: out[v][ne_len].  Lane 0 of a role walks the tail alone and stores the
+// running sum at each truncation point.
+template <typename TY>
 __global__ __launch_bounds__(NE_THREADS) void normal_eq_kernel(const double* z, int64_t ldz,
                                                                const TY* y, int64_t ldy, int V,
                                                                int N, int K, int sub_log2,
@@ -51,11 +51,7 @@ __global__ __launch_bounds__(NE_THREADS) void normal_eq_kernel(const double* z, 
   const bool worker = role < 2 * K + 1;
   double* lz = reinterpret_cast<double*>(smem);
   double* ly = lz + N;
-  double* acc = ly + N;
-  if constexpr (!PER_VOXEL) {
-    for (int e = threadIdx.x; e < ne; e += NE_THREADS) acc[e] = 0.0;
-  }
-  const int jb = N > K ? N - K : 0;            // sums over j < jb are truncation-free
+  const int jb = N > K ? N - K : 0;
   for (int v = blockIdx.x; v < V; v += gridDim.x) {
     __syncthreads();                           // previous voxel fully consumed
     {
@@ -67,7 +63,7 @@ __global__ __launch_bounds__(NE_THREADS) void normal_eq_kernel(const double* z, 
       }
     }
     __syncthreads();
-    double* dst = PER_VOXEL ? out + (int64_t)v * ne : acc;
+    double* dst = out + (int64_t)v * ne;
     double r = 0.0;
     if (worker) {
       if (role < K) {                          // autocorrelation, bulk part
@@ -89,34 +85,93 @@ __global__ __launch_bounds__(NE_THREADS) void normal_eq_kernel(const double* z, 
           r = fma(lz[j], lz[j + d], r);
           const int mp = N - 1 - j;            // m' = max(m, m') < K here, m = m' - d
           const int m = mp - d;
-          if constexpr (PER_VOXEL) {
-            dst[m * K + mp] = r;
-            dst[mp * K + m] = r;
-          } else {
-            dst[m * K + mp] += r;
-            if (d) dst[mp * K + m] += r;
-          }
+          dst[m * K + mp] = r;
+          dst[mp * K + m] = r;
         }
-        if constexpr (PER_VOXEL) {
-          // series shorter than the HRF: truncation point before j = 0 -> empty sums
-          for (int mp = (N > d ? N : d); mp < K; ++mp) {
-            const int m = mp - d;
-            dst[m * K + mp] = 0.0;
-            dst[mp * K + m] = 0.0;
-          }
+        // series shorter than the HRF: truncation point before j = 0 -> empty sums
+        for (int mp = (N > d ? N : d); mp < K; ++mp) {
+          const int m = mp - d;
+          dst[m * K + mp] = 0.0;
+          dst[mp * K + m] = 0.0;
         }
       } else if (role < 2 * K) {
-        const int m = role - K;
-        if constexpr (PER_VOXEL) dst[K * K + m] = r; else dst[K * K + m] += r;
+        dst[K * K + (role - K)] = r;
       } else {
-        if constexpr (PER_VOXEL) dst[K * K + K] = r; else dst[K * K + K] += r;
+        dst[K * K + K] = r;
       }
     }
   }
-  if constexpr (!PER_VOXEL) {
+}
+
+// Sum over the voxels of the block: part[blockIdx.x][ne_len] (a second kernel adds the blocks
+// in a fixed order: deterministic).  Summed over voxels, the running sums become
+//   G[m][m'] = BULK_d + sum_{j' <= j} P_d[j'],   P_d[j'] = sum_v z_v[jb+j'] z_v[jb+j'+d]
+// so nothing in the voxel loop depends on the previous step: every lane accumulates its
+// bulk terms in a register and its share of the tail products P in LDS (own entries only),
+// and the prefix sums over j' are taken once per block at the end.
+// LDS: z[N] y[N] P[K*K].
+template <typename TY>
+__global__ __launch_bounds__(NE_THREADS) void normal_eq_sum_kernel(const double* z, int64_t ldz,
+                                                                   const TY* y, int64_t ldy, int V,
+                                                                   int N, int K, int sub_log2,
+                                                                   double* part_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int SUB = 1 << sub_log2;
+  const int ne = ne_len(K);
+  const int role = threadIdx.x >> sub_log2;
+  const int sub = threadIdx.x & (SUB - 1);
+  const bool worker = role < 2 * K + 1;
+  double* lz = reinterpret_cast<double*>(smem);
+  double* ly = lz + N;
+  double* P = ly + N;
+  for (int e = threadIdx.x; e < K * K; e += NE_THREADS) P[e] = 0.0;
+  const int jb = N > K ? N - K : 0;
+  const int d = role;                          // autocorrelation roles
+  const int tail = (worker && role < K && N - d > jb) ? N - d - jb : 0;   // truncation points of lag d
+  double acc = 0.0;
+  for (int v = blockIdx.x; v < V; v += gridDim.x) {
     __syncthreads();
-    double* part = out + (int64_t)blockIdx.x * ne;
-    for (int e = threadIdx.x; e < ne; e += NE_THREADS) part[e] = acc[e];
+    {
+      const double* zr = z + (int64_t)v * ldz;
+      const TY* yr = y + (int64_t)v * ldy;
+      for (int i = threadIdx.x; i < N; i += NE_THREADS) {
+        lz[i] = zr[i];
+        ly[i] = (double)yr[i];
+      }
+    }
+    __syncthreads();
+    if (worker) {
+      if (role < K) {
+        for (int j = sub; j < jb; j += SUB) acc = fma(lz[j], lz[j + d], acc);
+        for (int jj = sub; jj < tail; jj += SUB)
+          P[d * K + jj] = fma(lz[jb + jj], lz[jb + jj + d], P[d * K + jj]);
+      } else if (role < 2 * K) {
+        const int m = role - K;
+        for (int j = sub; j < N - m; j += SUB) acc = fma(lz[j], ly[j + m], acc);
+      } else {
+        for (int i = sub; i < N; i += SUB) acc = fma(ly[i], ly[i], acc);
+      }
+    }
+  }
+  for (int o = SUB >> 1; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);     // fixed order
+  double* part = part_out + (int64_t)blockIdx.x * ne;
+  for (int e = threadIdx.x; e < ne; e += NE_THREADS) part[e] = 0.0;          // entries with no sample
+  __syncthreads();
+  if (worker && sub == 0) {
+    if (role < K) {
+      double r = acc;
+      for (int jj = 0; jj < tail; ++jj) {
+        r += P[d * K + jj];
+        const int mp = N - 1 - (jb + jj);
+        const int m = mp - d;
+        part[m * K + mp] = r;
+        part[mp * K + m] = r;
+      }
+    } else if (role < 2 * K) {
+      part[K * K + (role - K)] = acc;
+    } else {
+      part[K * K + K] = acc;
+    }
   }
 }
 

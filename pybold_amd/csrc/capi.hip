@@ -220,13 +220,13 @@ int normal_eq_impl(const double* z_dev, int64_t ldz, const TY* y_dev, int64_t ld
   const int ne = pb::ne_len(K);
   int sub_log2 = 0;                            // lanes per role: 4 for K <= 31, 2 for K <= 63
   while ((2 * K + 1) << (sub_log2 + 1) <= pb::NE_THREADS && sub_log2 < 2) ++sub_log2;
-  const int64_t nd = 2 * (int64_t)N + (per_voxel ? 0 : ne);
+  const int64_t nd = 2 * (int64_t)N + (per_voxel ? 0 : (int64_t)K * K);
   if (nd > LDS_DOUBLES_MAX) return fail(PB_ERR_INVALID, "%s: N=%d K=%d exceeds LDS", name, N, K);
   const size_t lds = (size_t)nd * sizeof(double);
   if (per_voxel) {
     if (V == 0) return PB_OK;
     if (!z_dev || !y_dev || !out_dev) return fail(PB_ERR_INVALID, "%s: NULL pointer", name);
-    hipLaunchKernelGGL((pb::normal_eq_kernel<TY, true>), dim3(V < 65536 ? V : 65536),
+    hipLaunchKernelGGL((pb::normal_eq_kernel<TY>), dim3(V < 65536 ? V : 65536),
                        dim3(pb::NE_THREADS), lds, (hipStream_t)stream, z_dev, ldz, y_dev, ldy, V, N, K,
                        sub_log2, out_dev);
     return check_launch(name);
@@ -240,7 +240,7 @@ int normal_eq_impl(const double* z_dev, int64_t ldz, const TY* y_dev, int64_t ld
     if (blocks < 1 || !work_dev)
       return fail(PB_ERR_INVALID, "%s: work buffer must hold at least %d doubles", name, ne);
     if (!z_dev || !y_dev) return fail(PB_ERR_INVALID, "%s: NULL pointer", name);
-    hipLaunchKernelGGL((pb::normal_eq_kernel<TY, false>), dim3(blocks), dim3(pb::NE_THREADS), lds,
+    hipLaunchKernelGGL((pb::normal_eq_sum_kernel<TY>), dim3(blocks), dim3(pb::NE_THREADS), lds,
                        (hipStream_t)stream, z_dev, ldz, y_dev, ldy, V, N, K, sub_log2, work_dev);
   } else {
     blocks = 0;

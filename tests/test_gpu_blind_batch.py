@@ -109,10 +109,17 @@ def test_section_search_finds_the_scipy_minimiser(golden):
     t_r, dur = float(g["t_r"]), float(g["hrf_dur"])
     Z = np.stack([g["z"], g["z"]])
     Y = np.stack([g["y"], 0.5 * g["y"]])
-    theta, cost = blind.fit_dilations(d64(Z), d32(Y), t_r, dur, [(0.6, 1.9)])
+    theta, cost, taps = blind.fit_dilations(d64(Z), d64(Y), t_r, dur, [(0.6, 1.9)])
     h = orc.spm_hrf(float(theta[0]), t_r, dur, False)[0]
+    np.testing.assert_allclose(taps[0].cpu().numpy(), h, rtol=1e-10, atol=1e-14)
+    print("fit_dilations vs hrf_estim: rel err of h %.2e" % (np.linalg.norm(h - g["h"]) / np.linalg.norm(g["h"])))
     assert np.linalg.norm(h - g["h"]) / np.linalg.norm(g["h"]) < 1e-4     # hrf_estim's answer
     assert float(cost[0]) <= min(g["J"]) * (1 + 1e-9)                     # at least as good
+    # the pass-per-candidate search of round 1 lands on the same dilations
+    th_grid, c_grid = blind.fit_dilations_grid(d64(Z), d64(Y), t_r, dur, [(0.6, 1.9)])
+    np.testing.assert_allclose(theta.cpu().numpy(), th_grid.cpu().numpy(), atol=2e-7)
+    th32, _, _ = blind.fit_dilations(d64(Z), d32(Y), t_r, dur, [(0.6, 1.9)])   # float32 y of a batch
+    np.testing.assert_allclose(th32.cpu().numpy(), theta.cpu().numpy(), atol=1e-6)
 
 
 def test_bd_batch_tracks_single_voxel_bd(golden):
@@ -122,11 +129,15 @@ def test_bd_batch_tracks_single_voxel_bd(golden):
     Y = np.stack([y, 0.8 * y, y[::-1].copy()])
     x, z, w, h, d = pybold_amd.bd(Y, t_r, lbda=lbda, hrf_dur=dur, nb_iter=5)
     assert x.shape == Y.shape and h.shape == (3, len(g["h"])) and d["J"].shape == (7, 3)
-    np.testing.assert_allclose(d["J"][:, 0], g["J"], rtol=1e-3)           # golden = voxel 0
-    assert np.linalg.norm(h[0] - g["h"]) / np.linalg.norm(g["h"]) < 1e-3
-    assert np.linalg.norm(x[0] - g["x"]) / np.linalg.norm(g["x"]) < 1e-3
-    assert np.linalg.norm(w[0] - g["diff_z"]) / np.linalg.norm(g["diff_z"]) < 5e-3
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    errs = dict(J=np.abs(d["J"][:, 0] / g["J"] - 1).max(), h=rel(h[0], g["h"]), x=rel(x[0], g["x"]),
+                diff_z=rel(w[0], g["diff_z"]))
+    print("bd batch (float32 y, float32 FIRs, exact theta minimiser) vs golden:",
+          {k: "%.2e" % v for k, v in errs.items()})
+    # golden = voxel 0.  The batch path differs from the reference by float32 storage of y,
+    # float32 FIRs in the z-step and an exact theta minimiser where L-BFGS-B stops ~1e-5 early
+    assert errs["J"] < 1e-6 and errs["h"] < 1e-5 and errs["x"] < 1e-5 and errs["diff_z"] < 1e-5
     # and against the SciPy-in-the-loop single-voxel path for another voxel
     xs, zs, ws, hs, ds = pybold_amd.bd(Y[2], t_r, lbda=lbda, hrf_dur=dur, nb_iter=5)
-    np.testing.assert_allclose(d["J"][:, 2], ds["J"], rtol=1e-3)
-    assert np.linalg.norm(h[2] - hs) / np.linalg.norm(hs) < 1e-3
+    np.testing.assert_allclose(d["J"][:, 2], ds["J"], rtol=1e-5)
+    assert rel(h[2], hs) < 1e-5

@@ -96,3 +96,105 @@ def test_regularisation_path_config5_slice(setup):
     for i in (0, 7, 19):
         Wi, _, _ = solver.fista_solve(Ysub, hrf, float(lbdas[i]), step, 50)
         assert rel_rows_t(Wp[:, i, :], Wi) < 1e-6       # may run on different kernels
+
+
+# ---- every BASELINE config at full size (round 2) ----------------------------------------
+def sample_vs_oracle(W, Y, idx, hrf, lbda, step, n_iter, W0=None):
+    sel = torch.from_numpy(idx).cuda()
+    Ys = Y[sel].cpu().numpy().astype(np.float64)
+    lb = lbda if np.ndim(lbda) == 0 else np.asarray(lbda)[idx]
+    Wo, _, _ = c_oracle.fista_batch(Ys, hrf, lb, step, n_iter, W0=W0, threads=8)
+    Wg = W[sel].cpu().numpy()
+    return float((np.linalg.norm(Wg - Wo, axis=1) / (np.linalg.norm(Wo, axis=1) + 1e-300)).max())
+
+
+def test_config2_ten_thousand_voxels(setup):
+    """BASELINE config 2: 10k voxels x 300 scans, fixed HRF, L1 deconv, 500 iterations; the
+    dispatch decision for this size is what the library reports and is register-resident;
+    64 voxels against the C oracle."""
+    solver, hrf, Y = setup
+    step = 1.0 / LIP
+    Y2 = Y[:10000].contiguous()
+    name = solver.which_kernel(N, len(hrf), 10000)
+    assert "register-resident" in name
+    W, _, n_done = solver.fista_solve(Y2, hrf, 1.0, step, 500)
+    assert int(n_done.min()) == 500 and bool(torch.isfinite(W).all())
+    idx = np.random.RandomState(2).choice(10000, 64, replace=False)
+    err = sample_vs_oracle(W, Y2, idx, hrf, 1.0, step, 500)
+    print("config 2 (%s): max rel err of 64 voxels vs C oracle %.2e" % (name, err))
+    assert err < 1e-5
+    # the same voxels inside the 100k batch of config 3 (other kernel form / packing)
+    W3, _, _ = solver.fista_solve(Y, hrf, 1.0, step, 500)
+    assert rel_rows_t(W3[:10000], W) < 1e-6
+
+
+def test_config5_regularisation_path_full_size(setup):
+    """BASELINE config 5: 50k voxels x 20 lambdas = 10^6 problems sharing y rows,
+    lambda = logspace(-2, 0, 20) * lambda_max,v with lambda_max,v = ||H^T y_v||_inf from the
+    device helper; 500 iterations; a sample of (voxel, lambda) problems vs the C
+    oracle; at lambda_max the path ends in the all-zero solution."""
+    solver, hrf, Y = setup
+    step = 1.0 / LIP
+    V5, L = 50000, 20
+    Y5 = Y[:V5].contiguous()
+    lmax = solver.lambda_max(Y5, hrf)                                   # (V5,) on the device
+    grid = torch.logspace(-2, 0, L, dtype=torch.float64, device="cuda")
+    lam = (lmax[:, None] * grid[None, :]).reshape(-1)                   # (V5 * L,)
+    W, _, n_done = solver.fista_solve(Y5, hrf, lam, step, 500, y_rep=L)
+    assert W.shape == (V5 * L, N) and int(n_done.min()) == 500 and bool(torch.isfinite(W).all())
+    assert "register-resident" in solver.which_kernel(N, len(hrf), V5 * L)
+    rng = np.random.RandomState(5)
+    vox, li = rng.choice(V5, 48, replace=False), rng.randint(0, L, 48)
+    Ys = Y5[torch.from_numpy(vox).cuda()].cpu().numpy().astype(np.float64)
+    lams = lam.cpu().numpy()[vox * L + li]
+    Wo, _, _ = c_oracle.fista_batch(Ys, hrf, lams, step, 500, threads=8)
+    Wg = W[torch.from_numpy(vox * L + li).cuda()].cpu().numpy()
+    err = (np.linalg.norm(Wg - Wo, axis=1) / (np.linalg.norm(Wo, axis=1) + 1e-300)).max()
+    print("config 5: max rel err of 48 (voxel, lambda) problems vs C oracle %.2e" % err)
+    assert err < 1e-5
+    # top of the path: the first prox step thresholds everything at lambda_max (beta_0 = 0)
+    W1, _, _ = solver.fista_solve(Y5[:512].contiguous(), hrf, lmax[:512] * (1 + 1e-5), step, 1)
+    assert float(W1.abs().max()) == 0.0
+    # sparsity grows along the path (more weight on the L1 term)
+    Wv = W.reshape(V5, L, N)[:256]
+    l1 = Wv.abs().sum(dim=2)
+    assert bool((l1[:, -1] <= l1[:, 0]).all())
+
+
+def test_config4_shared_hrf_full_size():
+    """BASELINE config 4: 50k voxels, N = 300, K = 27 (TR 0.75 s, 20 s HRF), true dilation
+    0.7, theta_0 = 2.0, lambda = 1.7, 20 outer x 100 inner iterations, Frobenius step, shared
+    theta fitted on the device.  Cost decreases monotonically; the normal equations of two
+    25k-voxel shards add up to those of the whole batch (what the all-reduce computes) and
+    give the same dilation; a 64-voxel sample of the first z-step matches the oracle."""
+    from oracle import pybold_oracle as orc
+    from pybold_amd import data, distributed, solver
+    from pybold_amd.utils import gram_frobenius
+    t_r, dur, V4 = 0.75, 20.0, 50000
+    h_true = orc.spm_hrf(0.7, t_r, dur, False)[0]
+    Y4, _, _ = data.gen_rnd_bloc_bold_batch(V4, dur=3.75, tr=t_r, hrf=h_true, nb_events=5, avg_dur=12.0,
+                                            std_dur=1.0, snr=10.0, seed=4)
+    assert Y4.shape == (V4, 300) and len(h_true) == 27
+    W, h, d = distributed.bd_shared(Y4, t_r, lbda=1.7, theta_0=2.0, hrf_dur=dur, nb_iter=20, nb_inner=100)
+    print("config 4: theta trajectory", np.round(d["theta"], 5), "J[-1] = %.6f" % d["J"][-1])
+    assert len(d["J"]) == 22 and d["J"][0] == 1.0 and (np.diff(d["J"]) < 0).all()
+    assert 0.6 <= d["theta"][-1] < d["theta"][1] <= 1.9
+    np.testing.assert_allclose(h, orc.spm_hrf(float(d["theta"][-1]), t_r, dur, False)[0], rtol=1e-10, atol=1e-14)
+    # shard additivity of the theta-step at full size (2 x 25k == 50k)
+    Z = solver.integ_op(W)
+    ne = solver.hrf_normal_eq(Z, Y4, 27)
+    ne2 = solver.hrf_normal_eq(Z[:25000], Y4[:25000], 27) + solver.hrf_normal_eq(Z[25000:], Y4[25000:], 27)
+    np.testing.assert_allclose(ne2.cpu().numpy(), ne.cpu().numpy(), rtol=1e-11)
+    th, f, _ = solver.theta_fit(ne, t_r, dur, (0.6, 1.9))
+    th2, f2, _ = solver.theta_fit(ne2, t_r, dur, (0.6, 1.9))
+    assert abs(float(th[0]) - float(th2[0])) < 1e-9
+    assert float(f[0]) == pytest.approx(float(solver.hrf_cost(Z, Y4, orc.spm_hrf(float(th[0]), t_r, dur, False)[0]).sum()),
+                                        rel=1e-7)                       # quadratic form == direct cost
+    # first z-step (theta_0 = 2.0, from zero) of a 64-voxel sample against the oracle
+    W0, h0, d0 = distributed.bd_shared(Y4, t_r, lbda=1.7, theta_0=2.0, hrf_dur=dur, nb_iter=0, nb_inner=100)
+    h20 = orc.spm_hrf(2.0, t_r, dur, False)[0]
+    np.testing.assert_allclose(h0, h20, rtol=1e-10, atol=1e-14)
+    idx = np.random.RandomState(4).choice(V4, 64, replace=False)
+    err = sample_vs_oracle(W0, Y4, idx, h20, 1.7, 1.0 / gram_frobenius(h20, 300), 100)
+    print("config 4: first z-step, max rel err of 64 voxels vs C oracle %.2e" % err)
+    assert err < 1e-5
