@@ -36,6 +36,12 @@ def load():
             ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
             ctypes.c_double, ctypes.c_void_p, ctypes.c_double, ctypes.c_int, ctypes.c_void_p,
             ctypes.c_void_p, ctypes.c_int]
+        lib.oracle_deconv_auto_lbda_batch.restype = None
+        lib.oracle_deconv_auto_lbda_batch.argtypes = [
+            ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+            ctypes.c_void_p, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_int,
+            ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         _lib = lib
     return _lib
 
@@ -57,3 +63,23 @@ def fista_batch(Y, hrf, lbda, step, n_iter, W0=None, want_J=False, threads=0):
                                   int(n_iter), W.ctypes.data,
                                   J.ctypes.data if J is not None else None, int(threads))
     return W, J, used
+
+
+def deconv_auto_lbda_batch(Y, hrf, sigma, lipschitz, early_stopping=True, tol=1.0e-6, wind=6,
+                           nb_iter=1000, nb_sub_iter=1000, threads=0):
+    """C form of pybold_oracle.deconv_auto_lbda for every row of Y (one noise level per row).
+    Returns (W (V, N), J, R, G as (V, nb_iter) arrays padded with NaN, n_outer (V,))."""
+    lib = load()
+    Y = np.ascontiguousarray(np.atleast_2d(Y), dtype=np.float64)
+    V, N = Y.shape
+    h = np.ascontiguousarray(hrf, dtype=np.float64)
+    sig = np.ascontiguousarray(np.broadcast_to(np.asarray(sigma, dtype=np.float64), (V,)))
+    W = np.zeros((V, N))
+    J, R, G = (np.full((V, nb_iter), np.nan) for _ in range(3))
+    n_outer = np.zeros(V, dtype=np.int32)
+    lib.oracle_deconv_auto_lbda_batch(Y.ctypes.data, V, N, h.ctypes.data, len(h), sig.ctypes.data,
+                                      float(lipschitz), int(bool(early_stopping)), float(tol),
+                                      int(wind), int(nb_iter), int(nb_sub_iter), W.ctypes.data,
+                                      J.ctypes.data, R.ctypes.data, G.ctypes.data,
+                                      n_outer.ctypes.data, int(threads))
+    return W, J, R, G, n_outer

@@ -71,7 +71,9 @@ def bd_batch(Y, t_r, lbda=1.0, theta_0=None, z_0=None, hrf_dur=20.0, bounds=None
     at :324, theta-step, normalised ``J``/``r`` and raw ``g`` per outer iteration,
     final z-step).  Returns ``(X, Z, W, H, d)``: float64 CUDA ``(V, N)`` x3, the
     per-voxel HRFs ``(V, K)`` and ``d`` with ``'J'``, ``'r'``, ``'g'`` as
-    ``(nb_iter + 2, V)`` arrays and ``'theta'`` ``(V,)``."""
+    ``(nb_iter + 2, V)`` arrays and ``'theta'`` ``(V,)``.  ``lbda`` and ``theta_0`` may
+    hold one value per voxel.  With ``early_stopping=False`` and ``verbose=0`` the whole loop
+    runs without a single host synchronisation."""
     dev = Y.device
     V, n = Y.shape
     if bounds is None:
@@ -97,6 +99,10 @@ def bd_batch(Y, t_r, lbda=1.0, theta_0=None, z_0=None, hrf_dur=20.0, bounds=None
         W = torch.cat([torch.zeros((V, 1), dtype=torch.float64, device=dev),
                        Z0[:, 1:] - Z0[:, :-1]], dim=1)
         X, _ = solver.fista_outputs_pp(W, taps)
+    if torch.is_tensor(lbda) or np.ndim(lbda) > 0:          # one lambda per voxel
+        lbda = torch.as_tensor(lbda, dtype=torch.float64).to(dev).reshape(-1)
+        if lbda.numel() != V:
+            raise ValueError("lbda must be a scalar or hold one value per voxel")
     Yd = Y.double()
     r0 = ((X - Yd) ** 2).sum(dim=1)
     g0 = W.abs().sum(dim=1)
@@ -106,8 +112,10 @@ def bd_batch(Y, t_r, lbda=1.0, theta_0=None, z_0=None, hrf_dur=20.0, bounds=None
 
     def z_step(W, taps):
         steps = 1.0 / solver.gram_frobenius_batch(taps, n)
+        # without early stopping every voxel advances: iterate in place, no host sync at all
         Wn, _ = solver.fista_solve_pp(Y, taps, steps, lbda, int(nb_iter), W0=W,
-                                      stop="loops" if early_stopping else None, tol=tol)
+                                      stop="loops" if early_stopping else None, tol=tol,
+                                      inplace=not early_stopping)
         return Wn
 
     def record(W, taps, eps):
@@ -121,10 +129,11 @@ def bd_batch(Y, t_r, lbda=1.0, theta_0=None, z_0=None, hrf_dur=20.0, bounds=None
 
     for idx in range(nb_iter):
         Wn = z_step(W, taps)
-        W = Wn if bool(active.all()) else torch.where(active[:, None], Wn, W)
+        all_active = (not early_stopping) or bool(active.all())
+        W = Wn if all_active else torch.where(active[:, None], Wn, W)
         Z = solver.integ_op(W)
         th_new, _, taps_new = fit_dilations(Z, Y, t_r, hrf_dur, bounds)
-        if bool(active.all()):
+        if all_active:
             theta, taps = th_new, taps_new
         else:
             theta = torch.where(active, th_new, theta)

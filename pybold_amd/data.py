@@ -14,7 +14,10 @@ no per-voxel Python loop:
     overlapping draws, data.py:212-213; here the free space between blocks is
     drawn directly);
   * clean signal = causal convolution with the HRF (data.py:324);
-  * white Gaussian noise rescaled to the exact SNR in dB (data.py:436-444).
+  * white Gaussian noise rescaled to the exact SNR in dB (data.py:436-444), one SNR for
+    the batch or one per voxel.
+
+``gen_regular_bloc_bold_batch`` is the batched regular block design (data.py:10-41).
 """
 import numpy as np
 import torch
@@ -52,7 +55,43 @@ def gen_rnd_bloc_bold_batch(n_voxels, dur=5, tr=1.0, hrf=None, nb_events=5, avg_
     blocks = inside.any(dim=1).to(torch.float64)
     clean = solver.conv(blocks, np.asarray(hrf, dtype=np.float64))
     noise = torch.randn((V, N), generator=gen, device=dev, dtype=torch.float64)
-    scale = clean.norm(dim=1, keepdim=True) / (noise.norm(dim=1, keepdim=True) +
+    return (clean + _scale_noise(noise, clean, snr)).to(torch.float32), clean, blocks
+
+
+def _scale_noise(noise, clean, snr):
+    """``add_gaussian_noise`` (pybold/data.py:436-444) row-wise: the unit draw is rescaled so
+    that ``20 log10(||clean|| / ||noise||) = snr`` exactly; ``snr`` is a scalar or one value
+    per voxel."""
+    ratio = clean.norm(dim=1, keepdim=True) / (noise.norm(dim=1, keepdim=True) +
                                                np.finfo(np.float64).eps)
-    noise = noise * scale / np.sqrt(10.0 ** (snr / 10.0))
-    return (clean + noise).to(torch.float32), clean, blocks
+    snr = torch.as_tensor(snr, dtype=torch.float64, device=clean.device).reshape(-1, 1)
+    return noise * ratio / torch.sqrt(10.0 ** (snr / 10.0))
+
+
+def gen_regular_bloc_bold_batch(n_voxels, dur=10, tr=1.0, dur_bloc=30.0, hrf=None, snr=1.0, seed=0,
+                                device=None, centered=True):
+    """Batched ``gen_regular_bloc_bold`` (pybold/data.py:10-41): the innovation alternates
+    +1 / -1 every ``int(dur_bloc / tr)`` samples from sample 0 (:14-16), the block signal is
+    its cumulative sum, both centred (:20-22), the clean BOLD signal is ``hrf * blocks``
+    (:34, on the GPU), and every voxel gets its own white-noise draw rescaled to the exact
+    SNR (scalar or per voxel).  Returns ``(noisy float32 (V, N), clean float64 (N,),
+    blocks float64 (N,), innovation float64 (N,))`` as CUDA tensors."""
+    if hrf is None:
+        raise ValueError("an HRF is required")
+    dev = solver.device(device)
+    N = int(dur * 60 / tr)
+    V = int(n_voxels)
+    i_s = torch.zeros((N,), dtype=torch.float64, device=dev)
+    marks = torch.arange(0, N, int(dur_bloc / tr), device=dev)
+    i_s[marks] = -1.0
+    i_s[marks[::2]] = 1.0
+    ai_s = torch.cumsum(i_s, dim=0)
+    if centered:
+        ai_s = ai_s - ai_s.mean()
+        i_s = i_s - i_s.mean()
+    clean = solver.conv(ai_s.reshape(1, N), np.asarray(hrf, dtype=np.float64))[0]
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(int(seed))
+    noise = torch.randn((V, N), generator=gen, device=dev, dtype=torch.float64)
+    noisy = clean[None, :] + _scale_noise(noise, clean[None, :].expand(V, N), snr)
+    return noisy.to(torch.float32), clean, ai_s, i_s

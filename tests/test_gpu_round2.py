@@ -282,3 +282,42 @@ def test_vector_theta0_in_bd_batch(solver):
         blind.bd_batch(dev32(Y), T_R, theta_0=np.ones(5), nb_iter=1)
     with pytest.raises(ValueError):
         blind.bd_batch(dev32(Y), T_R, theta_0=np.full(6, 2.5), nb_iter=1)
+
+
+def test_deconv_auto_lambda_at_reference_defaults(golden):
+    """deconv(lbda=None) with the reference's DEFAULT settings (nb_iter=1000,
+    nb_sub_iter=1000, tol=1e-6, wind=6: pybold/bold_signal.py:13-14) -- on the golden inputs
+    no stop rule ever fires, i.e. 1000 outer x 1000 inner iterations per voxel -- against the
+    C form of the oracle's restatement of :99-214 (same noise level).  1-D: float64 kernels,
+    tight; a 16-voxel batch: float32-FIR kernels with the in-kernel window rule.
+    (The branch itself stays parity-unpinned: no reference-side vectors exist, see DESIGN.)"""
+    import time
+    import pybold_amd
+    from oracle import c_oracle
+    g = golden("grid")
+    hrf, lip = g["hrf"], float(g["lip_s0"])
+    Y = np.stack([g["y_s%d" % (s % 4)] * (1.0 + 0.05 * (s // 4)) for s in range(16)])
+    sigma = np.array([orc.mad_daub_noise_est(y) for y in Y])
+    Wo, Jo, Ro, Go, n_outer = c_oracle.deconv_auto_lbda_batch(Y, hrf, sigma, lip, threads=16)
+    Y32 = Y.astype(np.float32).astype(np.float64)
+    sigma32 = np.array([orc.mad_daub_noise_est(y) for y in Y32])
+    Wo32, Jo32, _, _, n_outer32 = c_oracle.deconv_auto_lbda_batch(Y32, hrf, sigma32, lip, threads=16)
+    assert (n_outer == 1000).all()
+    t0 = time.perf_counter()
+    np.random.seed(0)
+    x, z, dz, J, R, G = pybold_amd.deconv(Y[1], 1.0, hrf, lbda=None)
+    t1 = time.perf_counter()
+    assert isinstance(J, list) and len(J) == 1000
+    e = rel_rows(dz, Wo[1])
+    print("deconv(lbda=None) defaults, 1-D: %.1f s, rel err diff_z %.2e, J %.2e"
+          % (t1 - t0, e, np.abs(np.array(J) / Jo[1] - 1).max()))
+    assert e < 1e-8
+    np.testing.assert_allclose(J, Jo[1], rtol=1e-9)
+    np.random.seed(0)
+    X, Z, W, Jb, Rb, Gb = pybold_amd.deconv(Y, 1.0, hrf, lbda=None)
+    t2 = time.perf_counter()
+    eb = rel_rows(W, Wo32)
+    print("deconv(lbda=None) defaults, 16-voxel batch: %.1f s, max rel err diff_z %.2e, J %.2e"
+          % (t2 - t1, eb, np.nanmax(np.abs(Jb.T / Jo32 - 1))))
+    assert Jb.shape == (1000, 16) and eb < 1e-4
+    np.testing.assert_allclose(Jb.T, Jo32, rtol=1e-4)
