@@ -44,6 +44,9 @@ extern "C" {
 #define PB_FLAG_FORCE_PAIR 8u     /* plain solves: always two problems per DPP row
                                      (fista_pair_kernel); default = whichever the dispatch
                                      model expects to finish first for this problem count */
+#define PB_FLAG_FORCE_WIDE 16u    /* always one problem per wave (fista_fast_kernel, 64 lanes) */
+#define PB_FLAG_ONE_LAUNCH 32u    /* never split a plain solve into a full-rounds launch and a
+                                     remainder launch (see pb_fista_solve) */
 
 /* early-stop rules (evaluated per problem, inside the kernel) */
 #define PB_STOP_NONE 0
@@ -70,7 +73,10 @@ int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mod
  * Fused FISTA-like solver: n_iter iterations of the recurrence of
  *   deconv (fixed-lambda loop)   pybold/bold_signal.py:62-72
  *   _loops_deconv                pybold/bold_signal.py:259-276
- * for P independent problems in ONE launch, state resident on chip:
+ * for P independent problems, state resident on chip, in ONE launch -- or, for a plain
+ * solve (no stop rule) whose problem count does not fill the machine evenly, in TWO launches
+ * on the same stream: the whole rounds of waves on the densest kernel form and the
+ * remainder on whichever form finishes it first (PB_FLAG_ONE_LAUNCH turns that off):
  *
  *   u = w - step * H^T (H w - y)      H = toeplitz(taps) . cumsum
  *   p = soft(u, lbda_p * step)        pybold/linear.py:73-113, convolution.py:105-132

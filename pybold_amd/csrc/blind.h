@@ -175,14 +175,17 @@ __global__ __launch_bounds__(NE_THREADS) void normal_eq_sum_kernel(const double*
   }
 }
 
-// out[e] = sum_b part[b][e], b in fixed order (nblocks may be 0: an empty shard gives zeros)
+// out[e] = sum_b part[b][e]: one workgroup per entry e, the blocks dealt over its threads
+// (stride NE_THREADS) and folded by the fixed tree of block_sum -- the summation order
+// depends on nblocks only, never on timing (nblocks may be 0: an empty shard gives zeros).
 __global__ __launch_bounds__(NE_THREADS) void normal_eq_reduce_kernel(const double* part, int nblocks,
                                                                       int ne, double* out) {
-  const int e = blockIdx.x * NE_THREADS + threadIdx.x;
-  if (e >= ne) return;
+  __shared__ double red[2 * GEN_WAVES];
+  const int e = blockIdx.x;
   double s = 0.0;
-  for (int b = 0; b < nblocks; ++b) s += part[(int64_t)b * ne + e];
-  out[e] = s;
+  for (int b = threadIdx.x; b < nblocks; b += NE_THREADS) s += part[(int64_t)b * ne + e];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) out[e] = s;
 }
 
 struct HrfModel {        // two-gamma SPM HRF, un-normalised (pybold/hrf_model.py:25-31)

@@ -114,13 +114,22 @@ const FastEntry* pick_fast(int N, int K) {
   return best;
 }
 
-// Which of the two register-resident kernels finishes a plain solve of P problems first.
-// Both keep two waves per SIMD; a wave of the pair kernel carries 8 problems at ~0.905 of
-// the per-problem cost, a wave of the single-row kernel 4.  The last, partially filled
-// round of waves costs about 0.55 of a round when at most half full (the waves then run
-// alone on their SIMDs) and a full round otherwise (measured crossovers:
-// tools/ab_pair_sizes.py).
-bool pair_is_faster(int P) {
+// ---- dispatch of a plain solve (no stop rule) over the register-resident forms --------
+// All forms keep two waves per SIMD and are VALU-issue bound, so a launch costs "rounds":
+// waves / (CUs x 4 SIMDs x 2), a last partial round at most half full costing ~0.55 of a
+// round (its waves run alone on their SIMDs), a fuller one a whole round.  Per round:
+//   pair   8 problems per wave   1.0   (the unit: 16 384 problems on MI355X)
+//   fast1  4 problems per wave   COST_FAST1 of it for half as many problems
+//   wide   1 problem  per wave   COST_WIDE  of it for an eighth as many (short series only)
+// (measured: tools/ab_forms.py, profiles/).  A problem count that is not a whole number of
+// pair rounds is therefore split: whole rounds on the pair kernel, the remainder on whichever
+// form finishes it first, as a second launch on the same stream (the first launch ends with
+// every SIMD draining at once, so running the remainder after it costs what overlapping
+// would).
+constexpr double COST_FAST1 = 0.55, COST_WIDE = 0.17, COST_PARTIAL = 0.55;
+enum Form { FORM_GENERIC = 0, FORM_FAST1 = 1, FORM_PAIR = 2, FORM_WIDE = 3 };
+
+double wave_slots() {
   static const double slots = [] {
     int dev = 0;
     hipDeviceProp_t prop;
@@ -128,12 +137,44 @@ bool pair_is_faster(int P) {
       return 2048.0;
     return (double)prop.multiProcessorCount * 4.0 * 2.0;
   }();
-  auto finish = [&](double waves, double wave_cost) {
-    const double r = waves / slots;
-    const double whole = std::floor(r), part = r - whole;
-    return wave_cost * (whole + (part == 0.0 ? 0.0 : (part <= 0.5 ? 0.55 : 1.0)));
-  };
-  return finish(std::ceil(P / 8.0), 2.0 * 0.905) < finish(std::ceil(P / 4.0), 1.0);
+  return slots;
+}
+
+double form_cost(int form, int P) {
+  const int per_wave = form == FORM_PAIR ? 8 : (form == FORM_FAST1 ? 4 : 1);
+  const double unit = form == FORM_PAIR ? 1.0 : (form == FORM_FAST1 ? COST_FAST1 : COST_WIDE);
+  const double r = std::ceil((double)P / per_wave) / wave_slots();
+  const double whole = std::floor(r), part = r - whole;
+  return unit * (whole + (part == 0.0 ? 0.0 : (part <= 0.5 ? COST_PARTIAL : 1.0)));
+}
+
+// cheapest single form for P problems among those available
+int best_form(int P, bool has_pair, bool has_wide, double* cost = nullptr) {
+  int best = FORM_FAST1;
+  double c = form_cost(FORM_FAST1, P);
+  if (has_pair && P >= 2 && form_cost(FORM_PAIR, P) < c) { best = FORM_PAIR; c = form_cost(FORM_PAIR, P); }
+  if (has_wide && form_cost(FORM_WIDE, P) < c) { best = FORM_WIDE; c = form_cost(FORM_WIDE, P); }
+  if (cost) *cost = c;
+  return best;
+}
+
+struct Plan {          // problems [0, n_main) on the pair kernel, [n_main, P) on `tail_form`
+  int n_main;
+  int tail_form;
+};
+
+Plan plan_plain(int P, bool has_pair, bool has_wide, bool one_launch) {
+  Plan single{0, best_form(P, has_pair, has_wide)};
+  if (!has_pair || one_launch) return single;
+  const int round = (int)wave_slots() * 8;
+  const int n_main = (P / round) * round;
+  if (n_main == 0 || n_main == P) return single;
+  double c_single, c_tail;
+  best_form(P, has_pair, has_wide, &c_single);
+  const int tail = best_form(P - n_main, has_pair, has_wide, &c_tail);
+  // 0.02 round ~ the launch boundary and ramp of the second launch
+  if ((double)(n_main / round) + c_tail + 0.02 < c_single) return Plan{n_main, tail};
+  return single;
 }
 
 template <int KIND>
@@ -245,8 +286,8 @@ int normal_eq_impl(const double* z_dev, int64_t ldz, const TY* y_dev, int64_t ld
   } else {
     blocks = 0;
   }
-  hipLaunchKernelGGL(pb::normal_eq_reduce_kernel, dim3((ne + pb::NE_THREADS - 1) / pb::NE_THREADS),
-                     dim3(pb::NE_THREADS), 0, (hipStream_t)stream, work_dev, blocks, ne, out_dev);
+  hipLaunchKernelGGL(pb::normal_eq_reduce_kernel, dim3(ne), dim3(pb::NE_THREADS), 0,
+                     (hipStream_t)stream, work_dev, blocks, ne, out_dev);
   return check_launch(name);
 }
 }  // namespace
@@ -261,7 +302,15 @@ int pb_fista_has_fast_path(int N, int K) {
   return (N >= 1 && K >= 1 && (pick_fast(N, K) || pick_wide(N, K))) ? 1 : 0;
 }
 
+// the one-problem-per-wave entry worth using for SHORT series (the cheapest-per-problem tail
+// form): only entries whose strips are at most 8 samples
+static const WideEntry* pick_wide_small(int N, int K) {
+  const WideEntry* we = pick_wide(N, K);
+  return (we && we->S <= 8) ? we : nullptr;
+}
+
 int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mode, int wind) {
+  (void)with_cost_trace;
   if (N < 1 || K < 1 || P < 1) return 0;
   const FastEntry* fe = pick_fast(N, K);
   if (fe && stop_mode == PB_STOP_WINDOW && (wind != 6 || fe->S > 20)) fe = nullptr;
@@ -270,8 +319,9 @@ int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mod
     if (we && stop_mode == PB_STOP_WINDOW && (wind != 6 || we->S > 20)) we = nullptr;
     return we ? 3 : 0;
   }
-  if (fe->fn_pair && stop_mode == PB_STOP_NONE && P >= 2 && pair_is_faster(P)) return 2;
-  return 1;
+  if (stop_mode != PB_STOP_NONE) return 1;
+  const Plan pl = plan_plain(P, fe->fn_pair != nullptr, pick_wide_small(N, K) != nullptr, false);
+  return pl.n_main > 0 ? FORM_PAIR : pl.tail_form;     // the form that carries most problems
 }
 
 int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, int64_t ldw, int P,
@@ -300,23 +350,46 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
   a.betas = betas_dev; a.J = J_dev; a.J64 = nullptr; a.ldj = ldj; a.n_done = n_done_dev;
   a.step = step; a.lbda = lbda; a.tol = tol;
   a.y_rep = y_rep; a.P = P; a.N = N; a.n_iter = n_iter; a.stop_mode = stop_mode;
-  a.taps_pp = nullptr; a.ldt = 0; a.step_vec = nullptr; a.step_shared = 0; a.K = K;
+  a.taps_pp = nullptr; a.ldt = 0; a.step_vec = nullptr; a.step_shared = 0; a.K = K; a.p0 = 0;
 
   const FastEntry* fe = (flags & PB_FLAG_FORCE_GENERIC) ? nullptr : pick_fast(N, K);
   // the register-resident window rule keeps wind-1 = 5 iterates in VGPRs: wind = 6
   // (the reference default) on entries small enough to hold them; else LDS kernel
   if (fe && stop_mode == PB_STOP_WINDOW && (wind != 6 || fe->S > 20)) fe = nullptr;
+  if (fe && (flags & PB_FLAG_FORCE_WIDE)) fe = nullptr;
   if (fe) {
-    // no stop rule (cost trace or not): two problems per DPP row when that form finishes first
-    if (fe->fn_pair && stop_mode == PB_STOP_NONE && P >= 2 && !(flags & PB_FLAG_NO_PAIR) &&
-        ((flags & PB_FLAG_FORCE_PAIR) || pair_is_faster(P))) {
-      if (fe->fn_pair(a, taps_host, K, J_dev != nullptr, (hipStream_t)stream) != 0)
-        return fail(PB_ERR_INVALID, "pb_fista_solve: pair kernel rejected the launch");
-      return check_launch("fista_pair_kernel");
+    auto run = [&](int form, int p0, int p1) -> int {
+      pb::FistaArgs b = a;
+      b.p0 = p0;
+      b.P = p1;
+      if (form == FORM_PAIR) {
+        if (fe->fn_pair(b, taps_host, K, J_dev != nullptr, (hipStream_t)stream) != 0)
+          return fail(PB_ERR_INVALID, "pb_fista_solve: pair kernel rejected the launch");
+        return check_launch("fista_pair_kernel");
+      }
+      if (form == FORM_WIDE) {
+        const WideEntry* we = pick_wide_small(N, K);
+        if (!we || we->fn(b, taps_host, K, J_dev != nullptr, stop_mode, (hipStream_t)stream) != 0)
+          return fail(PB_ERR_INVALID, "pb_fista_solve: no one-problem-per-wave form");
+        return check_launch("fista_fast_kernel(wide)");
+      }
+      if (fe->fn(b, taps_host, K, J_dev != nullptr, stop_mode, (hipStream_t)stream) != 0)
+        return fail(PB_ERR_INVALID, "pb_fista_solve: no register-resident form for this stop rule");
+      return check_launch("fista_fast_kernel");
+    };
+    if (stop_mode != PB_STOP_NONE || (flags & PB_FLAG_NO_PAIR)) return run(FORM_FAST1, 0, P);
+    if (flags & PB_FLAG_FORCE_PAIR) {
+      if (!fe->fn_pair || P < 2) return run(FORM_FAST1, 0, P);
+      return run(FORM_PAIR, 0, P);
     }
-    if (fe->fn(a, taps_host, K, J_dev != nullptr, stop_mode, (hipStream_t)stream) != 0)
-      return fail(PB_ERR_INVALID, "pb_fista_solve: no register-resident form for this stop rule");
-    return check_launch("fista_fast_kernel");
+    // plain solve: whole rounds on the densest form, the remainder on the cheapest
+    const Plan pl = plan_plain(P, fe->fn_pair != nullptr, pick_wide_small(N, K) != nullptr,
+                               (flags & PB_FLAG_ONE_LAUNCH) != 0);
+    if (pl.n_main > 0) {
+      const int rc = run(FORM_PAIR, 0, pl.n_main);
+      if (rc != PB_OK) return rc;
+    }
+    return run(pl.tail_form, pl.n_main, P);
   }
   // long series: one problem per wave (window rule: wind = 6 and S <= 20, as above)
   if (!(flags & PB_FLAG_FORCE_GENERIC)) {
@@ -375,7 +448,7 @@ int pb_fista_solve_d(const double* y_dev, int64_t ldy, int y_rep, double* w_dev,
   a.betas = betas_dev; a.J = nullptr; a.J64 = J_dev; a.ldj = ldj; a.n_done = n_done_dev;
   a.step = step; a.lbda = lbda; a.tol = tol;
   a.y_rep = y_rep; a.P = P; a.N = N; a.n_iter = n_iter; a.stop_mode = stop_mode;
-  a.taps_pp = nullptr; a.ldt = 0; a.step_vec = nullptr; a.step_shared = 0; a.K = K;
+  a.taps_pp = nullptr; a.ldt = 0; a.step_vec = nullptr; a.step_shared = 0; a.K = K; a.p0 = 0;
   const size_t lds = (size_t)nd * sizeof(double);
   if (J_dev)
     hipLaunchKernelGGL((pb::fista_generic_kernel<true, true>), dim3(P), dim3(pb::GEN_THREADS), lds,
@@ -591,6 +664,7 @@ int pb_fista_solve_pp(const float* y_dev, int64_t ldy, double* w_dev, int64_t ld
   a.step = 0.0; a.lbda = lbda; a.tol = tol;
   a.y_rep = 1; a.P = P; a.N = N; a.n_iter = n_iter; a.stop_mode = stop_mode;
   a.taps_pp = taps_dev; a.ldt = ldt; a.step_vec = step_dev; a.step_shared = (ldt == 0); a.K = K;
+  a.p0 = 0;
 
   const FastEntry* fe = (flags & PB_FLAG_FORCE_GENERIC) ? nullptr : pick_fast(N, K);
   if (fe) {

@@ -54,7 +54,8 @@ struct FistaArgs {
   double lbda;
   double tol;
   int y_rep;
-  int P;
+  int P;                  // problems [p0, P) belong to this launch (row indices are global)
+  int p0;
   int N;
   int n_iter;
   int stop_mode;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
 
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int sub = threadIdx.x & (LPV - 1);  // lane within the problem's segment
-  const int prob = (int)(gid / LPV);
+  const int prob = (int)(gid / LPV) + a.p0;
   const bool live = prob < a.P;
   const int p = live ? prob : a.P - 1;
   const int base = sub * S;

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256, 2) void fista_pair_kernel(FistaArgs a, TapsF<K
   const int sub = threadIdx.x & 15;
   const int row = gid >> 4;
   const int base = sub * S;
-  const int pA0 = 2 * row, pB0 = 2 * row + 1;
+  const int pA0 = 2 * row + a.p0, pB0 = 2 * row + 1 + a.p0;
   const bool liveA = pA0 < a.P, liveB = pB0 < a.P;
   const int pA = liveA ? pA0 : a.P - 1;
   const int pB = liveB ? pB0 : a.P - 1;
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void fista_pair_kernel(FistaArgs a, TapsF<K
 template <int S, int KT>
 int launch_pair(const FistaArgs& a, const double* taps, int K, bool with_j, hipStream_t st) {
   const auto tf = make_taps_f<KT>(taps, K);
-  const int64_t rows = ((int64_t)a.P + 1) / 2;
+  const int64_t rows = ((int64_t)(a.P - a.p0) + 1) / 2;
   const dim3 grid((unsigned)((rows * 16 + 255) / 256)), block(256);
   const size_t lds = (size_t)16 * S * 16 * (sizeof(f2) + sizeof(float)) + (with_j ? 16 * 4 * sizeof(float) : 0);
   const bool skip0 = KT > 1 && tf.pr[0].x == 0.0f;      // leading tap exactly zero

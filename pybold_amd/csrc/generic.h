@@ -383,7 +383,7 @@ __global__ __launch_bounds__(GEN_THREADS) void fista_generic_kernel(FistaArgs a_
   double* k = b + N;
   double* red = k + K;
   double* hist = red + 2 * GEN_WAVES;
-  const int p = blockIdx.x;
+  const int p = blockIdx.x + a_.p0;
   const TY* yr = [&] {
     if constexpr (F64IO) return a_.y64 + (int64_t)(p / a_.y_rep) * a_.ldy;
     else return a_.y + (int64_t)(p / a_.y_rep) * a_.ldy;

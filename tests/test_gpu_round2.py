@@ -286,8 +286,8 @@ def test_vector_theta0_in_bd_batch(solver):
 
 def test_deconv_auto_lambda_at_reference_defaults(golden):
     """deconv(lbda=None) with the reference's DEFAULT settings (nb_iter=1000,
-    nb_sub_iter=1000, tol=1e-6, wind=6: pybold/bold_signal.py:13-14) -- on the golden inputs
-    no stop rule ever fires, i.e. 1000 outer x 1000 inner iterations per voxel -- against the
+    nb_sub_iter=1000, tol=1e-6, wind=6: pybold/bold_signal.py:13-14) -- up to 1000 outer x
+    1000 inner iterations per voxel, some voxels leaving early on the alpha rule -- against the
     C form of the oracle's restatement of :99-214 (same noise level).  1-D: float64 kernels,
     tight; a 16-voxel batch: float32-FIR kernels with the in-kernel window rule.
     (The branch itself stays parity-unpinned: no reference-side vectors exist, see DESIGN.)"""
@@ -302,7 +302,7 @@ def test_deconv_auto_lambda_at_reference_defaults(golden):
     Y32 = Y.astype(np.float32).astype(np.float64)
     sigma32 = np.array([orc.mad_daub_noise_est(y) for y in Y32])
     Wo32, Jo32, _, _, n_outer32 = c_oracle.deconv_auto_lbda_batch(Y32, hrf, sigma32, lip, threads=16)
-    assert (n_outer == 1000).all()
+    assert n_outer[1] == 1000 and n_outer.min() > 6
     t0 = time.perf_counter()
     np.random.seed(0)
     x, z, dz, J, R, G = pybold_amd.deconv(Y[1], 1.0, hrf, lbda=None)
@@ -320,4 +320,7 @@ def test_deconv_auto_lambda_at_reference_defaults(golden):
     print("deconv(lbda=None) defaults, 16-voxel batch: %.1f s, max rel err diff_z %.2e, J %.2e"
           % (t2 - t1, eb, np.nanmax(np.abs(Jb.T / Jo32 - 1))))
     assert Jb.shape == (1000, 16) and eb < 1e-4
+    # same voxels leave the outer loop at the same outer iteration (NaN padding after it)
+    np.testing.assert_array_equal(np.isnan(Jb.T), np.isnan(Jo32))
+    np.testing.assert_array_equal((~np.isnan(Jb.T)).sum(axis=1), n_outer32)
     np.testing.assert_allclose(Jb.T, Jo32, rtol=1e-4)
