@@ -116,17 +116,20 @@ const FastEntry* pick_fast(int N, int K) {
 
 // ---- dispatch of a plain solve (no stop rule) over the register-resident forms --------
 // All forms keep two waves per SIMD and are VALU-issue bound, so a launch costs "rounds":
-// waves / (CUs x 4 SIMDs x 2), a last partial round at most half full costing ~0.55 of a
-// round (its waves run alone on their SIMDs), a fuller one a whole round.  Per round:
-//   pair   8 problems per wave   1.0   (the unit: 16 384 problems on MI355X)
-//   fast1  4 problems per wave   COST_FAST1 of it for half as many problems
-//   wide   1 problem  per wave   COST_WIDE  of it for an eighth as many (short series only)
-// (measured: tools/ab_forms.py, profiles/).  A problem count that is not a whole number of
-// pair rounds is therefore split: whole rounds on the pair kernel, the remainder on whichever
-// form finishes it first, as a second launch on the same stream (the first launch ends with
-// every SIMD draining at once, so running the remainder after it costs what overlapping
-// would).
-constexpr double COST_FAST1 = 0.55, COST_WIDE = 0.17, COST_PARTIAL = 0.55;
+// waves / (CUs x 4 SIMDs x 2), a last partial round at most half full costing ~0.56 of a
+// round (its waves run alone on their SIMDs), a fuller one a whole round, plus a fixed
+// ~0.03-0.05 for launch, prologue and epilogue.  Unit = one full round of the pair kernel
+// (16 384 problems, ~3.0 ms for 500 iterations of N = 300, K = 30 on MI355X).  Measured
+// (tools/ab_forms.py, profiles/r2_ab_forms.txt):
+//   pair   8 problems per wave   1.00 per round
+//   fast1  4 problems per wave   0.56 per round of half as many problems
+//   wide   1 problem  per wave   0.165 per round of an eighth as many (short series only)
+// A problem count that is not a whole number of rounds is therefore split: whole rounds on
+// the pair (or single-row) kernel, the remainder on whichever form finishes it first, as a
+// second launch on the same stream (the first launch ends with every SIMD draining at once,
+// so running the remainder after it costs what overlapping would).
+constexpr double COST_FAST1 = 0.56, COST_WIDE = 0.165, COST_PARTIAL = 0.56;
+constexpr double COST_LAUNCH = 0.03, COST_LAUNCH_WIDE = 0.05;
 enum Form { FORM_GENERIC = 0, FORM_FAST1 = 1, FORM_PAIR = 2, FORM_WIDE = 3 };
 
 double wave_slots() {
@@ -140,12 +143,14 @@ double wave_slots() {
   return slots;
 }
 
+int problems_per_wave(int form) { return form == FORM_PAIR ? 8 : (form == FORM_FAST1 ? 4 : 1); }
+
 double form_cost(int form, int P) {
-  const int per_wave = form == FORM_PAIR ? 8 : (form == FORM_FAST1 ? 4 : 1);
   const double unit = form == FORM_PAIR ? 1.0 : (form == FORM_FAST1 ? COST_FAST1 : COST_WIDE);
-  const double r = std::ceil((double)P / per_wave) / wave_slots();
+  const double r = std::ceil((double)P / problems_per_wave(form)) / wave_slots();
   const double whole = std::floor(r), part = r - whole;
-  return unit * (whole + (part == 0.0 ? 0.0 : (part <= 0.5 ? COST_PARTIAL : 1.0)));
+  return (form == FORM_WIDE ? COST_LAUNCH_WIDE : COST_LAUNCH) +
+         unit * (whole + (part == 0.0 ? 0.0 : (part <= 0.5 ? COST_PARTIAL : 1.0)));
 }
 
 // cheapest single form for P problems among those available
@@ -158,23 +163,30 @@ int best_form(int P, bool has_pair, bool has_wide, double* cost = nullptr) {
   return best;
 }
 
-struct Plan {          // problems [0, n_main) on the pair kernel, [n_main, P) on `tail_form`
+struct Plan {          // problems [0, n_main) on `main_form`, [n_main, P) on `tail_form`
   int n_main;
+  int main_form;
   int tail_form;
 };
 
 Plan plan_plain(int P, bool has_pair, bool has_wide, bool one_launch) {
-  Plan single{0, best_form(P, has_pair, has_wide)};
-  if (!has_pair || one_launch) return single;
-  const int round = (int)wave_slots() * 8;
-  const int n_main = (P / round) * round;
-  if (n_main == 0 || n_main == P) return single;
-  double c_single, c_tail;
-  best_form(P, has_pair, has_wide, &c_single);
-  const int tail = best_form(P - n_main, has_pair, has_wide, &c_tail);
-  // 0.02 round ~ the launch boundary and ramp of the second launch
-  if ((double)(n_main / round) + c_tail + 0.02 < c_single) return Plan{n_main, tail};
-  return single;
+  double c_best;
+  Plan best{0, FORM_GENERIC, best_form(P, has_pair, has_wide, &c_best)};
+  if (one_launch) return best;
+  for (int main_form : {FORM_PAIR, FORM_FAST1}) {
+    if (main_form == FORM_PAIR && !has_pair) continue;
+    const int round = (int)wave_slots() * problems_per_wave(main_form);
+    const int n_main = (P / round) * round;
+    if (n_main == 0 || n_main == P) continue;
+    double c_tail;
+    const int tail = best_form(P - n_main, has_pair, has_wide, &c_tail);
+    const double c = form_cost(main_form, n_main) + c_tail;
+    if (c < c_best) {
+      c_best = c;
+      best = Plan{n_main, main_form, tail};
+    }
+  }
+  return best;
 }
 
 template <int KIND>
@@ -319,9 +331,9 @@ int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mod
     if (we && stop_mode == PB_STOP_WINDOW && (wind != 6 || we->S > 20)) we = nullptr;
     return we ? 3 : 0;
   }
-  if (stop_mode != PB_STOP_NONE) return 1;
-  const Plan pl = plan_plain(P, fe->fn_pair != nullptr, pick_wide_small(N, K) != nullptr, false);
-  return pl.n_main > 0 ? FORM_PAIR : pl.tail_form;     // the form that carries most problems
+  const Plan pl = plan_plain(P, fe->fn_pair != nullptr && stop_mode == PB_STOP_NONE,
+                             pick_wide_small(N, K) != nullptr, false);
+  return pl.n_main > 0 ? pl.main_form : pl.tail_form;   // the form that carries most problems
 }
 
 int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, int64_t ldw, int P,
@@ -377,16 +389,18 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
         return fail(PB_ERR_INVALID, "pb_fista_solve: no register-resident form for this stop rule");
       return check_launch("fista_fast_kernel");
     };
-    if (stop_mode != PB_STOP_NONE || (flags & PB_FLAG_NO_PAIR)) return run(FORM_FAST1, 0, P);
+    if (flags & PB_FLAG_NO_PAIR) return run(FORM_FAST1, 0, P);
     if (flags & PB_FLAG_FORCE_PAIR) {
-      if (!fe->fn_pair || P < 2) return run(FORM_FAST1, 0, P);
+      if (!fe->fn_pair || P < 2 || stop_mode != PB_STOP_NONE) return run(FORM_FAST1, 0, P);
       return run(FORM_PAIR, 0, P);
     }
-    // plain solve: whole rounds on the densest form, the remainder on the cheapest
-    const Plan pl = plan_plain(P, fe->fn_pair != nullptr, pick_wide_small(N, K) != nullptr,
+    // whole rounds on the densest form, the remainder on the cheapest (the pair form has no
+    // stop rules; the one-problem-per-wave form has them all)
+    const bool pair_ok = fe->fn_pair != nullptr && stop_mode == PB_STOP_NONE;
+    const Plan pl = plan_plain(P, pair_ok, pick_wide_small(N, K) != nullptr,
                                (flags & PB_FLAG_ONE_LAUNCH) != 0);
     if (pl.n_main > 0) {
-      const int rc = run(FORM_PAIR, 0, pl.n_main);
+      const int rc = run(pl.main_form, 0, pl.n_main);
       if (rc != PB_OK) return rc;
     }
     return run(pl.tail_form, pl.n_main, P);
