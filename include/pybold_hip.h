@@ -45,6 +45,8 @@ extern "C" {
                                      (fista_pair_kernel); default = whichever the dispatch
                                      model expects to finish first for this problem count */
 #define PB_FLAG_FORCE_WIDE 16u    /* always one problem per wave (fista_fast_kernel, 64 lanes) */
+#define PB_FLAG_DIRECT_FIR 64u    /* pair form: direct K-tap FIRs (fista_pair_kernel) instead of the
+                                     2-parallel fast FIRs (fista_pair_ffa_kernel) */
 #define PB_FLAG_ONE_LAUNCH 32u    /* never split a plain solve into a full-rounds launch and a
                                      remainder launch (see pb_fista_solve) */
 

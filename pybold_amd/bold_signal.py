@@ -16,7 +16,9 @@ Deviations from the reference, all deliberate:
     does at :261; every caller rebinds the returned array);
   * ``deconv(lbda=None)`` (noise-driven lambda search, :99-214) estimates the
     noise level with an in-package db3 detail band instead of PyWavelets
-    (``utils.mad_daub_noise_est``; parity of that estimate is unpinned).
+    (``utils.mad_daub_noise_est``; parity of that estimate is unpinned); with early
+    stopping it computes in float64 end to end, batches included (see
+    ``_deconv_auto_lbda``).
 There is no CPU fallback: without the HIP library or a GPU these raise.
 """
 import numpy as np
@@ -122,6 +124,15 @@ def _deconv_auto_lbda(y, hrf, early_stopping, tol, wind, nb_iter, nb_sub_iter, v
     y_host = y.detach().cpu().numpy() if torch.is_tensor(y) else np.asarray(y, dtype=np.float64)
     sigma = np.atleast_1d(mad_daub_noise_est(y_host))
     Y, one_d = _y_to_device(y)
+    if early_stopping and Y.dtype != torch.float64:
+        # The inner window rule compares iterates with gradient points (the aliasing of
+        # :65/:72), so its criterion tends to a CONSTANT proportional to lambda instead of 0;
+        # the lambda search drives lambda down until that constant crosses `tol`, i.e. the
+        # decision "stop the inner solve after 8 iterations or run all of them" sits on a
+        # knife edge where the 1e-7 rounding of the float32-FIR kernels flips it (measured:
+        # whole trajectories diverge).  This branch therefore runs on the all-float64 kernel
+        # (one workgroup per voxel), which takes the reference's decisions.
+        Y = torch.from_numpy(np.ascontiguousarray(np.atleast_2d(y_host), dtype=np.float64)).to(Y.device)
     V, n = Y.shape
     dev = Y.device
     hrf = np.asarray(hrf, dtype=np.float64)

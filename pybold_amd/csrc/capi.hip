@@ -11,6 +11,7 @@
 #include "generic.h"
 #include "launch_fast.h"
 #include "fista_pair.h"
+#include "fista_pair_ffa.h"
 #include "blind.h"
 
 namespace {
@@ -45,6 +46,7 @@ struct FastEntry {
   fast_launch_fn fn;
   fast_launch_pp_fn fn_pp;
   pair_launch_fn fn_pair;     // two-problems-per-row kernel (S <= 20, KT <= 32 only), else nullptr
+  pair_launch_fn fn_pair_ffa; // the same with 2-parallel fast FIRs (fista_pair_ffa.h)
 };
 
 }  // namespace
@@ -54,7 +56,8 @@ namespace pb {
 #define PB_FAST(S, KT)                                                                              \
   extern template int launch_fast<S, KT>(const FistaArgs&, const double*, int, bool, int, hipStream_t); \
   extern template int launch_fast_pp<S, KT>(const FistaArgs&, int, hipStream_t);            \
-  extern template int launch_pair<S, KT>(const FistaArgs&, const double*, int, bool, hipStream_t);
+  extern template int launch_pair<S, KT>(const FistaArgs&, const double*, int, bool, hipStream_t); \
+  extern template int launch_pair_ffa<S, KT>(const FistaArgs&, const double*, int, bool, hipStream_t);
 #include "fast_table.inc"
 #undef PB_FAST
 }  // namespace pb
@@ -98,7 +101,12 @@ template <int S, int KT>
 constexpr pair_launch_fn pair_or_null() {
   if constexpr (S <= 20 && KT <= 32) return &pb::launch_pair<S, KT>; else return nullptr;
 }
-#define PB_FAST(S, KT) {S, KT, &pb::launch_fast<S, KT>, &pb::launch_fast_pp<S, KT>, pair_or_null<S, KT>()},
+template <int S, int KT>
+constexpr pair_launch_fn pair_ffa_or_null() {
+  if constexpr (S <= 20 && KT <= 32) return &pb::launch_pair_ffa<S, KT>; else return nullptr;
+}
+#define PB_FAST(S, KT) \
+  {S, KT, &pb::launch_fast<S, KT>, &pb::launch_fast_pp<S, KT>, pair_or_null<S, KT>(), pair_ffa_or_null<S, KT>()},
 const FastEntry kFast[] = {
 #include "fast_table.inc"
 };
@@ -375,7 +383,9 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
       b.p0 = p0;
       b.P = p1;
       if (form == FORM_PAIR) {
-        if (fe->fn_pair(b, taps_host, K, J_dev != nullptr, (hipStream_t)stream) != 0)
+        const pair_launch_fn fn = (fe->fn_pair_ffa && !(flags & PB_FLAG_DIRECT_FIR)) ? fe->fn_pair_ffa
+                                                                                      : fe->fn_pair;
+        if (fn(b, taps_host, K, J_dev != nullptr, (hipStream_t)stream) != 0)
           return fail(PB_ERR_INVALID, "pb_fista_solve: pair kernel rejected the launch");
         return check_launch("fista_pair_kernel");
       }

@@ -1,0 +1,438 @@
+// Register-resident fused FISTA kernel, "pair" form with 2-parallel fast FIRs.
+//
+// Same mapping, recurrence and numerics as fista_pair.h (two problems per 16-lane DPP row,
+// every per-sample quantity a float2 over the two problems, float64 iterate and update);
+// what changes is the arithmetic of the two K-tap FIRs, 70 % of that kernel's instructions.
+// Split window and taps into even and odd phases (pair index n, window position q = 2n / 2n+1):
+//
+//   forward   x(2n)   = A[n] + B[n-1]            A = h0 * Ze,  B = h1 * Zo,
+//             x(2n+1) = C[n] - A[n] - B[n]       C = (h0 + h1) * (Ze + Zo)
+//   adjoint   c(2n)   = A'[n] + C'[n]            A' = h0 . (Re - Ro),  B' = h1 . (Re[+1] - Ro),
+//             c(2n+1) = B'[n] + C'[n]            C' = (h0 + h1) . Ro
+//
+// (h0[k] = h[2k], h1[k] = h[2k+1]; "*" causal convolution, "." correlation): three
+// half-length filters on half-rate sequences instead of four, i.e. 3/4 of the multiply-adds
+// for a few packed adds before and after.  At S = 19, K = 30 with the zero leading tap of an
+// SPM HRF skipped: 440 + 53 packed instructions per forward FIR instead of 551, 425 + 67 per
+// adjoint FIR.
+//
+// Registers: the summed windows cost ~34 VGPRs more than the direct form has left, so the
+// float64 iterate of problem B is parked in LDS between its two uses of an iteration (the
+// padding mask, which used to sit there, is computed on the fly for the few samples that can
+// be padded at all); y is stored pre-combined as the initial values of the accumulator
+// chains.  LDS per 16-lane row: yc [S][16] float2, wB [S][16] float64 (+16 B for the cost
+// trace): 78.1 KB per workgroup, two workgroups per CU.
+#pragma once
+#include "common.h"
+#include "fista_fast.h"
+#include "fista_pair.h"
+
+namespace pb {
+
+// taps as (h0[k], h1[k]) pairs and the sums hs[k] = h0[k] + h1[k] packed two per SGPR pair
+template <int KT>
+struct TapsFFA {
+  static constexpr int KE = (KT + 1) / 2;
+  f2 pr[KE];
+  f2 sm[(KE + 1) / 2];
+};
+
+template <int KT>
+inline TapsFFA<KT> make_taps_ffa(const double* taps, int K) {
+  TapsFFA<KT> t;
+  auto h = [&](int m) -> float { return (m < K) ? (float)taps[m] : 0.0f; };
+  constexpr int KE = TapsFFA<KT>::KE;
+  for (int k = 0; k < KE; ++k) t.pr[k] = f2{h(2 * k), h(2 * k + 1)};
+  for (int i = 0; i < (KE + 1) / 2; ++i) {
+    auto hs = [&](int k) -> float { return k < KE ? h(2 * k) + h(2 * k + 1) : 0.0f; };
+    t.sm[i] = f2{hs(2 * i), hs(2 * i + 1)};
+  }
+  return t;
+}
+
+template <int S, int KT, bool WITH_J = false, bool SKIP0 = false>
+__global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, TapsFFA<KT> taps) {
+  constexpr int H = KT - 1;
+  constexpr int D = (H + S - 1) / S;
+  constexpr int KE = (KT + 1) / 2;          // taps per phase
+  constexpr int WL = H + S;                 // window length
+  constexpr int NW = (WL + 1) / 2;          // window pairs
+  constexpr int GN = 2;                     // pairs per accumulator group (6 chains)
+  static_assert(D <= 15, "halo spans more than one DPP row");
+
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int sub = threadIdx.x & 15;
+  const int row = gid >> 4;
+  const int base = sub * S;
+  const int pA0 = 2 * row + a.p0, pB0 = 2 * row + 1 + a.p0;
+  const bool liveA = pA0 < a.P, liveB = pB0 < a.P;
+  const int pA = liveA ? pA0 : a.P - 1;
+  const int pB = liveB ? pB0 : a.P - 1;
+
+  extern __shared__ __attribute__((aligned(16))) char pair_smem[];
+  const int rslot = (threadIdx.x >> 4) * S * 16;
+  f2* ly = reinterpret_cast<f2*>(pair_smem) + (rslot + sub);                       // yc[j] at ly[j*16]
+  double* lw = reinterpret_cast<double*>(pair_smem + (size_t)16 * S * 16 * sizeof(f2)) + (rslot + sub);
+  double* stage_d = reinterpret_cast<double*>(reinterpret_cast<f2*>(pair_smem) + rslot);
+  float* stage_f = reinterpret_cast<float*>(pair_smem + (size_t)16 * S * 16 * sizeof(f2)) + 2 * rslot;
+  float* lj = reinterpret_cast<float*>(pair_smem + (size_t)16 * S * 16 * (sizeof(f2) + sizeof(double))) +
+              (threadIdx.x >> 4) * 4;
+  auto lds_sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+
+  double wA[S];
+  {
+    const float* yA = a.y + (int64_t)(pA / a.y_rep) * a.ldy;
+    const float* yB = a.y + (int64_t)(pB / a.y_rep) * a.ldy;
+    const double* rA = a.w + (int64_t)pA * a.ldw;
+    const double* rB = a.w + (int64_t)pB * a.ldw;
+    // coalesced read -> LDS (natural order) -> strips (see fista_pair.h)
+    auto load_w = [&](const double* row, double* strip) {
+#pragma unroll
+      for (int k = 0; k < S; ++k) {
+        const int i = k * 16 + sub;
+        stage_d[i] = (i < a.N) ? row[i] : 0.0;
+      }
+      lds_sync();
+#pragma unroll
+      for (int j = 0; j < S; ++j) strip[j] = stage_d[base + j];
+      lds_sync();
+    };
+    double wB[S];
+    load_w(rA, wA);
+    load_w(rB, wB);
+    float ya[S], yb[S];
+    auto load_y = [&](const float* row, float* strip) {
+#pragma unroll
+      for (int k = 0; k < S; ++k) {
+        const int i = k * 16 + sub;
+        stage_f[i] = (i < a.N) ? row[i] : 0.0f;
+      }
+      lds_sync();
+#pragma unroll
+      for (int j = 0; j < S; ++j) strip[j] = stage_f[base + j];
+      lds_sync();
+    };
+    load_y(yA, ya);
+    load_y(yB, yb);
+    // y as the initial values of the forward accumulator chains: the output at an even
+    // window position starts its A chain from -y_j, the one at an odd position its C chain
+    // from -(y_j + y_{j-1}) (y_{j-1} only if that even position is an output of this lane)
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      const bool odd_q = ((H + j) & 1) != 0;
+      const bool with_prev = odd_q && j >= 1;
+      ly[j * 16] = f2{ya[j] + (with_prev ? ya[j - 1] : 0.0f), yb[j] + (with_prev ? yb[j - 1] : 0.0f)};
+      lw[j * 16] = wB[j];
+    }
+  }
+  const double lbA = a.lbda_vec ? a.lbda_vec[pA] : a.lbda;
+  const double lbB = a.lbda_vec ? a.lbda_vec[pB] : a.lbda;
+  const double thA = lbA * a.step, thB = lbB * a.step;
+  const double nstep = -a.step;
+  if constexpr (WITH_J) {
+    lj[0] = (float)lbA;
+    lj[1] = (float)lbB;
+  }
+  // samples that can be padding in SOME lane: j >= jpad (uniform); sample j of this lane is
+  // real iff j < jlim = N - base, i.e. mask = saturate(jlim - j) as a float
+  const int jpad = (a.N - 15 * S > 0) ? a.N - 15 * S : 0;
+  const float jlimf = (float)(a.N - base);
+
+  auto tap0 = [&](auto kc) -> f2 { return taps.pr[decltype(kc)::value].xx; };
+  auto tap1 = [&](auto kc) -> f2 { return taps.pr[decltype(kc)::value].yy; };
+  auto taps_sum = [&](auto kc) -> f2 {
+    constexpr int k = decltype(kc)::value;
+    const f2 p = taps.sm[k / 2];
+    return (k % 2 == 0) ? p.xx : p.yy;
+  };
+
+  // ---- forward pass: r = h * cumsum(w) - y for both problems ------------------------
+  auto forward = [&](f2 (&r)[S]) __attribute__((always_inline)) {
+    asm volatile("" ::: "memory");          // keep the LDS reads inside the loop
+    f2 z[S];
+    {
+      double wb[S];
+#pragma unroll
+      for (int j = 0; j < S; ++j) wb[j] = lw[j * 16];
+      z[0] = f2{(float)wA[0], (float)wb[0]};
+      if constexpr (WITH_J) {
+        float l1a = fabsf(z[0].x), l1b = fabsf(z[0].y);
+#pragma unroll
+        for (int j = 1; j < S; ++j) {
+          const f2 wj = f2{(float)wA[j], (float)wb[j]};
+          z[j] = z[j - 1] + wj;
+          l1a += fabsf(wj.x);
+          l1b += fabsf(wj.y);
+        }
+        lj[2] = row_allsum(l1a);
+        lj[3] = row_allsum(l1b);
+      } else {
+#pragma unroll
+        for (int j = 1; j < S; ++j) z[j] = z[j - 1] + f2{(float)wA[j], (float)wb[j]};
+      }
+    }
+    {
+      const f2 off = f2{row_from_below<1>(row_prefix_incl(z[S - 1].x)),
+                        row_from_below<1>(row_prefix_incl(z[S - 1].y))};
+#pragma unroll
+      for (int j = 0; j < S; ++j) z[j] += off;
+    }
+    // window of z in phases: Z[2n] = Ze[n], Z[2n+1] = Zo[n]; halo [0, H) from the lanes below
+    f2 Z[2 * NW];
+    if constexpr (WL % 2 == 1) Z[WL] = f2{0.f, 0.f};
+    static_for<0, S>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      Z[H + j] = z[j];
+    });
+    static_for<1, D + 1>([&](auto dc) {
+      constexpr int d = decltype(dc)::value;
+      static_for<0, S>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int e = H - d * S + j;
+        if constexpr (e >= 0) Z[e] = dpp_zero2<DPP_ROW_SHR + d>(z[j]);
+      });
+    });
+
+    constexpr int q_lo = H, q_hi = H + S - 1;
+    constexpr int n_lo = q_lo / 2, n_hi = q_hi / 2;
+    auto has_even = [](int n) constexpr { return 2 * n >= q_lo && 2 * n <= q_hi; };
+    auto has_odd = [](int n) constexpr { return 2 * n + 1 >= q_lo && 2 * n + 1 <= q_hi; };
+    f2 ZS[NW];                                // Ze + Zo, filled just before its first use
+    static_for<(n_lo - KE + 1 > 0 ? n_lo - KE + 1 : 0), n_lo>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      ZS[i] = Z[2 * i] + Z[2 * i + 1];
+    });
+    f2 b_prev = f2{0.f, 0.f};
+    if constexpr (has_even(n_lo)) {           // B[n_lo - 1] for the first even output
+      static_for<0, KE>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (2 * k + 1 < KT && n_lo - 1 - k >= 0)
+          b_prev = __builtin_elementwise_fma(tap1(kc), Z[2 * (n_lo - 1 - k) + 1], b_prev);
+      });
+    }
+    static_for<0, (n_hi - n_lo + GN) / GN>([&](auto gc) {
+      constexpr int n0 = n_lo + decltype(gc)::value * GN;
+      constexpr int gn = (n_hi - n0 + 1 < GN) ? n_hi - n0 + 1 : GN;
+      f2 ca[gn], cb[gn], cc[gn];
+      static_for<0, gn>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int n = n0 + i;
+        ZS[n] = Z[2 * n] + Z[2 * n + 1];
+        // chain inits: -y of the even output on A, -(y_odd + y_even) on C
+        if constexpr (has_even(n)) ca[i] = -ly[(2 * n - H) * 16]; else ca[i] = f2{0.f, 0.f};
+        if constexpr (has_odd(n)) cc[i] = -ly[(2 * n + 1 - H) * 16]; else cc[i] = f2{0.f, 0.f};
+        cb[i] = f2{0.f, 0.f};
+      });
+      static_for<0, KE>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        static_for<0, gn>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          constexpr int n = n0 + i;
+          if constexpr (!(SKIP0 && k == 0))
+            ca[i] = __builtin_elementwise_fma(tap0(kc), Z[2 * (n - k)], ca[i]);
+          if constexpr (2 * k + 1 < KT && (has_odd(n) || has_even(n + 1)))
+            cb[i] = __builtin_elementwise_fma(tap1(kc), Z[2 * (n - k) + 1], cb[i]);
+          if constexpr (has_odd(n))
+            cc[i] = __builtin_elementwise_fma(taps_sum(kc), ZS[n - k], cc[i]);
+        });
+      });
+      static_for<0, gn>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int n = n0 + i;
+        const f2 bp = (i == 0) ? b_prev : cb[i > 0 ? i - 1 : 0];
+        if constexpr (has_even(n)) r[2 * n - H] = ca[i] + bp;
+        if constexpr (has_odd(n)) r[2 * n + 1 - H] = cc[i] - (ca[i] + cb[i]);
+      });
+      b_prev = cb[gn - 1];
+    });
+    // zero the residual behind sample N-1: only trailing samples of a strip can be padding,
+    // the others skip the multiply on a scalar branch (the empty asm keeps it a branch and
+    // the comparison inside the loop: hoisted, the 19 conditions would spill the SGPR file)
+    int jp = jpad;
+    float jl = jlimf;
+    asm volatile("" : "+s"(jp), "+v"(jl));    // opaque per iteration: nothing below is hoisted
+    // every residual exists before the first branch (else the accumulator chains of the later
+    // samples are sunk between the branches, one lone dependent chain after the other)
+#pragma unroll
+    for (int j = 0; j < S; ++j) asm volatile("" : "+v"(r[j]));
+    static_for<0, S>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if (j >= jp) {
+        asm volatile("");
+        const float m = __builtin_amdgcn_fmed3f(jl - (float)j, 0.0f, 1.0f);
+        r[j] = r[j] * f2{m, m};
+      }
+    });
+  };
+
+  // ---- adjoint pass and update: w <- prox step from the residual r -------------------
+  auto backward = [&](const f2 (&r)[S], const double beta) __attribute__((always_inline)) {
+    f2 R[2 * NW];                             // own samples [0, S), halo [S, S+H) from above
+    if constexpr (WL % 2 == 1) R[WL] = f2{0.f, 0.f};
+    static_for<0, S>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      R[j] = r[j];
+    });
+    static_for<1, D + 1>([&](auto dc) {
+      constexpr int d = decltype(dc)::value;
+      static_for<0, S>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int e = d * S + j;
+        if constexpr (e < S + H) R[e] = dpp_zero2<DPP_ROW_SHL + d>(r[j]);
+      });
+    });
+    // g(2n) = A'[n] + C'[n], g(2n+1) = B'[n] + C'[n]
+    constexpr int n_hi = (S - 1) / 2;
+    auto has_odd = [](int n) constexpr { return 2 * n + 1 <= S - 1; };
+    f2 UA[NW], UB[NW];                        // Re - Ro, Re[+1] - Ro: filled just before first use
+    static_for<0, KE - 1>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      UA[i] = R[2 * i] - R[2 * i + 1];
+      if constexpr (2 * i + 2 < 2 * NW) UB[i] = R[2 * i + 2] - R[2 * i + 1];
+    });
+    f2 g[S];
+    static_for<0, (n_hi + GN) / GN>([&](auto gc) {
+      constexpr int n0 = decltype(gc)::value * GN;
+      constexpr int gn = (n_hi - n0 + 1 < GN) ? n_hi - n0 + 1 : GN;
+      f2 ca[gn], cb[gn], cc[gn];
+      static_for<0, gn>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int e = n0 + i + KE - 1;    // newest window pair this group touches
+        if constexpr (e < NW) {
+          UA[e] = R[2 * e] - R[2 * e + 1];
+          if constexpr (2 * e + 2 < 2 * NW) UB[e] = R[2 * e + 2] - R[2 * e + 1];
+          else UB[e] = -R[2 * e + 1];
+        }
+        ca[i] = f2{0.f, 0.f};
+        cb[i] = f2{0.f, 0.f};
+        cc[i] = f2{0.f, 0.f};
+      });
+      static_for<0, KE>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        static_for<0, gn>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          constexpr int n = n0 + i;
+          if constexpr (n + k < NW) {
+            if constexpr (!(SKIP0 && k == 0))
+              ca[i] = __builtin_elementwise_fma(tap0(kc), UA[n + k], ca[i]);
+            if constexpr (2 * k + 1 < KT && has_odd(n))
+              cb[i] = __builtin_elementwise_fma(tap1(kc), UB[n + k], cb[i]);
+            cc[i] = __builtin_elementwise_fma(taps_sum(kc), R[2 * (n + k) + 1], cc[i]);
+          }
+        });
+      });
+      static_for<0, gn>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int n = n0 + i;
+        g[2 * n] = ca[i] + cc[i];
+        if constexpr (has_odd(n)) g[2 * n + 1] = cb[i] + cc[i];
+      });
+    });
+#pragma unroll
+    for (int j = S - 2; j >= 0; --j) g[j] += g[j + 1];
+    {
+      const f2 off = f2{row_from_above<1>(row_suffix_incl(g[0].x)),
+                        row_from_above<1>(row_suffix_incl(g[0].y))};
+#pragma unroll
+      for (int j = 0; j < S; ++j) g[j] += off;
+    }
+
+    // ---- gradient step, prox, momentum (float64), per problem ------------------
+    const double nb1 = -(1.0 + beta);
+    {
+      double uA[S], uB[S], dA[S], dB[S];
+#pragma unroll
+      for (int j = 0; j < S; ++j) uB[j] = lw[j * 16];      // problem B's iterate comes back from LDS
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        uA[j] = fma(nstep, (double)g[j].x, wA[j]);
+        uB[j] = fma(nstep, (double)g[j].y, uB[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        dA[j] = fmax(uA[j], -thA);
+        dB[j] = fmax(uB[j], -thB);
+      }
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        dA[j] = fmin(dA[j], thA);
+        dB[j] = fmin(dB[j], thB);
+      }
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        wA[j] = fma(nb1, dA[j], uA[j]);
+        lw[j * 16] = fma(nb1, dB[j], uB[j]);
+      }
+    }
+  };
+
+  if constexpr (!WITH_J) {
+    for (int it = 0; it < a.n_iter; ++it) {
+      const double beta = a.betas[it];
+      f2 r[S];
+      forward(r);
+      backward(r, beta);
+    }
+  } else {
+    f2 r[S];
+    forward(r);
+    for (int it = 0; it < a.n_iter; ++it) {
+      const double beta = a.betas[it];
+      backward(r, beta);
+      forward(r);
+      f2 sq = r[0] * r[0];
+#pragma unroll
+      for (int j = 1; j < S; ++j) sq = __builtin_elementwise_fma(r[j], r[j], sq);
+      const float cA = fmaf(0.5f, row_allsum(sq.x), lj[0] * lj[2]);
+      const float cB = fmaf(0.5f, row_allsum(sq.y), lj[1] * lj[3]);
+      if (sub == 0) {
+        if (liveA) a.J[(int64_t)pA * a.ldj + it] = cA;
+        if (liveB) a.J[(int64_t)pB * a.ldj + it] = cB;
+      }
+    }
+  }
+
+  // epilogue: strips -> LDS -> coalesced stores (problem B's strip is read back first)
+  double wBf[S];
+#pragma unroll
+  for (int j = 0; j < S; ++j) wBf[j] = lw[j * 16];
+  auto store_w = [&](const double* strip, double* row, bool live) {
+    lds_sync();
+#pragma unroll
+    for (int j = 0; j < S; ++j) stage_d[base + j] = strip[j];
+    lds_sync();
+    if (live) {
+#pragma unroll
+      for (int k = 0; k < S; ++k) {
+        const int i = k * 16 + sub;
+        if (i < a.N) row[i] = stage_d[i];
+      }
+    }
+  };
+  store_w(wA, a.w + (int64_t)pA * a.ldw, liveA);
+  store_w(wBf, a.w + (int64_t)pB * a.ldw, liveB);
+  if (a.n_done && sub == 0) {
+    if (liveA) a.n_done[pA] = a.n_iter;
+    if (liveB) a.n_done[pB] = a.n_iter;
+  }
+}
+
+template <int S, int KT>
+int launch_pair_ffa(const FistaArgs& a, const double* taps, int K, bool with_j, hipStream_t st) {
+  const auto tf = make_taps_ffa<KT>(taps, K);
+  const int64_t rows = ((int64_t)(a.P - a.p0) + 1) / 2;
+  const dim3 grid((unsigned)((rows * 16 + 255) / 256)), block(256);
+  const size_t lds = (size_t)16 * S * 16 * (sizeof(f2) + sizeof(double)) + 16 * 4 * sizeof(float);
+  const bool skip0 = KT > 1 && tf.pr[0].x == 0.0f;      // leading tap exactly zero
+  if (with_j && skip0) hipLaunchKernelGGL((fista_pair_ffa_kernel<S, KT, true, true>), grid, block, lds, st, a, tf);
+  else if (with_j) hipLaunchKernelGGL((fista_pair_ffa_kernel<S, KT, true, false>), grid, block, lds, st, a, tf);
+  else if (skip0) hipLaunchKernelGGL((fista_pair_ffa_kernel<S, KT, false, true>), grid, block, lds, st, a, tf);
+  else hipLaunchKernelGGL((fista_pair_ffa_kernel<S, KT, false, false>), grid, block, lds, st, a, tf);
+  return 0;
+}
+
+}  // namespace pb

@@ -37,7 +37,7 @@ def rel_rows_t(a, b):
 def test_full_batch_properties(setup):
     solver, hrf, Y = setup
     step = 1.0 / LIP
-    for force in ("fast1", "fast2"):          # both register-resident kernels
+    for force in ("fast1", "fast2", "fast2d"):          # both register-resident kernels
         W, _, n_done = solver.fista_solve(Y, hrf, 1.0, step, 60, force=force)
         assert W.shape == (V, N) and bool(torch.isfinite(W).all()) and int(n_done.min()) == 60
         # batch independence (bitwise): odd-sized slice, different workgroup/row packing

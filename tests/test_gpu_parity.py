@@ -44,7 +44,7 @@ def grid_inputs(golden):
     return g, Y, g["hrf"], float(g["lip_s0"])
 
 
-@pytest.mark.parametrize("force", ["fast1", "fast2", "generic"])
+@pytest.mark.parametrize("force", ["fast1", "fast2", "fast2d", "generic"])
 def test_fista_vs_golden_grid(pa, golden, force):
     """lambda x iterations grid of SURVEY 8c case 3 (captures k=0 and the aliasing)."""
     _, solver = pa
@@ -61,7 +61,7 @@ def test_fista_vs_golden_grid(pa, golden, force):
             assert rel_rows(W, Wo) < EPS
 
 
-@pytest.mark.parametrize("force", ["fast1", "fast2", "generic"])
+@pytest.mark.parametrize("force", ["fast1", "fast2", "fast2d", "generic"])
 def test_outputs_and_cost_trace(pa, golden, force):
     _, solver = pa
     g = golden("case1")
@@ -117,7 +117,7 @@ def test_edge_shapes_fast_and_generic_agree_with_oracle(pa, N, K):
     H = orc.DenseH(hrf, N, N)
     lip = 1.1 * np.linalg.norm(H.K.dot(np.tril(np.ones((N, N)))), 2) ** 2 + 1e-12
     Wo = orc.fista_batch(Y.astype(np.float32).astype(np.float64), hrf, 0.05, 1.0 / lip, 40)
-    for force in ("fast1", "fast2", "generic"):
+    for force in ("fast1", "fast2", "fast2d", "generic"):
         if force != "generic" and not solver.has_fast_path(N, K):
             continue
         W, _, _ = solver.fista_solve(dev32(Y), hrf, 0.05, 1.0 / lip, 40, force=force)
@@ -168,7 +168,7 @@ def test_lambda_zero_and_huge(pa, golden):
     g, Y, hrf, lip = grid_inputs(golden)
     Y32 = Y.astype(np.float32).astype(np.float64)
     for lbda in (0.0, 1e9):
-        for force in ("fast1", "fast2", "generic"):
+        for force in ("fast1", "fast2", "fast2d", "generic"):
             W, _, _ = solver.fista_solve(dev32(Y), hrf, lbda, 1.0 / lip, 20, force=force)
             Wo = orc.fista_batch(Y32, hrf, lbda, 1.0 / lip, 20)
             assert rel_rows(W.cpu().numpy(), Wo) < EPS, (lbda, force)
@@ -183,7 +183,7 @@ def test_many_problems_partial_last_block(pa, golden):
     g, Y, hrf, lip = grid_inputs(golden)
     Yb = np.tile(Y, (9, 1))[:35] * np.linspace(0.5, 1.5, 35)[:, None]
     Wo = orc.fista_batch(Yb.astype(np.float32).astype(np.float64), hrf, 1.0, 1.0 / lip, 25)
-    for force in ("fast1", "fast2"):
+    for force in ("fast1", "fast2", "fast2d"):
         W, _, n_done = solver.fista_solve(dev32(Yb), hrf, 1.0, 1.0 / lip, 25, force=force)
         assert rel_rows(W.cpu().numpy(), Wo) < EPS, force
         assert (n_done.cpu().numpy() == 25).all()
@@ -233,6 +233,29 @@ def test_deconv_early_stopping_goldens(pa, golden):
         assert len(J) == n_ref, (tol, len(J))
         assert rel_rows(dz, g["dz_%g" % tol]) < EPS
         assert rel_rows(x, g["x_%g" % tol]) < EPS
+
+
+@pytest.mark.parametrize("force", ["fast1", "wide", "generic", None])
+def test_window_rule_in_the_batch_kernels(pa, golden, force):
+    """The golden stop iterations (26 / 77 / 191 / 311) through the float32-FIR batch kernels
+    (1-D API calls run the float64 kernel): single-row and one-problem-per-wave forms with
+    the increment ring, the LDS kernel, and the library's own choice; a row with another
+    scale stops on its own."""
+    _, solver = pa
+    g = golden("early_stop")
+    y, hrf, lip = g["y"], g["hrf"], float(g["lipschitz"])
+    Yb = np.stack([y, y, 3.0 * y, y, y[::-1].copy()])
+    for tol, n_ref in ((0.1, 26), (0.03, 77), (0.01, 191), (0.005, 311)):
+        W, J, nd = solver.fista_solve(dev32(Yb), hrf, 1.0, 1.0 / lip, 1000, want_J=True, stop="window",
+                                      tol=tol, wind=6, force=force)
+        nd = nd.cpu().numpy()
+        assert (nd[[0, 1, 3]] == n_ref).all(), (force, tol, nd)
+        assert rel_rows(W.cpu().numpy()[[0, 1, 3]], np.stack([g["dz_%g" % tol]] * 3)) < EPS
+        Jn = J.cpu().numpy()
+        assert np.isfinite(Jn[0, :n_ref]).all() and np.isnan(Jn[0, n_ref:]).all()
+        ref = orc.deconv_fixed_lbda(Yb[2].astype(np.float32).astype(np.float64), hrf, 1.0, nb_iter=1000,
+                                    tol=tol, lipschitz=lip, dense=False)
+        assert nd[2] == ref[4], (force, tol, nd[2], ref[4])
 
 
 def test_deconv_batch_matches_single(pa, golden):
@@ -526,7 +549,7 @@ def test_inputs_are_not_modified(pa, golden):
         assert rel_rows(W[s], g["dz_s%d_l1_n10" % s]) < EPS
 
 
-@pytest.mark.parametrize("force", ["fast1", "fast2", "generic"])
+@pytest.mark.parametrize("force", ["fast1", "fast2", "fast2d", "generic"])
 def test_bad_voxels_do_not_contaminate_neighbours(pa, golden, force):
     """Voxels are independent problems: NaN / Inf / huge values in one of them must
     leave every other voxel of the wave, row pair and workgroup bit-identical."""

@@ -31,7 +31,7 @@ def test_random_shapes_all_kernels(V, N, K, lbda, n_iter, warm, per_problem, rs)
     Yd = torch.from_numpy(Y.astype(np.float32)).cuda()
     W0d = torch.from_numpy(W0).cuda() if warm else None
     scale = np.abs(ref).max() + 1e-30
-    for force in ("fast1", "fast2", "generic"):
+    for force in ("fast1", "fast2", "fast2d", "generic"):
         if force != "generic" and not solver.has_fast_path(N, K):
             continue
         W, _, n_done = solver.fista_solve(Yd, hrf, lam, 1.0 / lip, n_iter, W0=W0d, force=force)
