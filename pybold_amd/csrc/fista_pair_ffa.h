@@ -50,7 +50,7 @@ inline TapsFFA<KT> make_taps_ffa(const double* taps, int K) {
   return t;
 }
 
-template <int S, int KT, bool WITH_J = false, bool SKIP0 = false>
+template <int S, int KT, bool WITH_J = false, bool SKIP0 = false, bool WB_LDS = false>
 __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, TapsFFA<KT> taps) {
   constexpr int H = KT - 1;
   constexpr int D = (H + S - 1) / S;
@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
   };
 
   double wA[S];
+  double wBr[WB_LDS ? 1 : S];               // problem B's iterate: registers, or parked in LDS
   {
     const float* yA = a.y + (int64_t)(pA / a.y_rep) * a.ldy;
     const float* yB = a.y + (int64_t)(pB / a.y_rep) * a.ldy;
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
       const bool odd_q = ((H + j) & 1) != 0;
       const bool with_prev = odd_q && j >= 1;
       ly[j * 16] = f2{ya[j] + (with_prev ? ya[j - 1] : 0.0f), yb[j] + (with_prev ? yb[j - 1] : 0.0f)};
-      lw[j * 16] = wB[j];
+      if constexpr (WB_LDS) lw[j * 16] = wB[j]; else wBr[j] = wB[j];
     }
   }
   const double lbA = a.lbda_vec ? a.lbda_vec[pA] : a.lbda;
@@ -157,7 +158,9 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
     {
       double wb[S];
 #pragma unroll
-      for (int j = 0; j < S; ++j) wb[j] = lw[j * 16];
+      for (int j = 0; j < S; ++j) {
+        if constexpr (WB_LDS) wb[j] = lw[j * 16]; else wb[j] = wBr[j];
+      }
       z[0] = f2{(float)wA[0], (float)wb[0]};
       if constexpr (WITH_J) {
         float l1a = fabsf(z[0].x), l1b = fabsf(z[0].y);
@@ -346,7 +349,9 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
     {
       double uA[S], uB[S], dA[S], dB[S];
 #pragma unroll
-      for (int j = 0; j < S; ++j) uB[j] = lw[j * 16];      // problem B's iterate comes back from LDS
+      for (int j = 0; j < S; ++j) {
+        if constexpr (WB_LDS) uB[j] = lw[j * 16]; else uB[j] = wBr[j];
+      }
 #pragma unroll
       for (int j = 0; j < S; ++j) {
         uA[j] = fma(nstep, (double)g[j].x, wA[j]);
@@ -365,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
 #pragma unroll
       for (int j = 0; j < S; ++j) {
         wA[j] = fma(nb1, dA[j], uA[j]);
-        lw[j * 16] = fma(nb1, dB[j], uB[j]);
+        if constexpr (WB_LDS) lw[j * 16] = fma(nb1, dB[j], uB[j]); else wBr[j] = fma(nb1, dB[j], uB[j]);
       }
     }
   };
@@ -399,7 +404,9 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
   // epilogue: strips -> LDS -> coalesced stores (problem B's strip is read back first)
   double wBf[S];
 #pragma unroll
-  for (int j = 0; j < S; ++j) wBf[j] = lw[j * 16];
+  for (int j = 0; j < S; ++j) {
+    if constexpr (WB_LDS) wBf[j] = lw[j * 16]; else wBf[j] = wBr[j];
+  }
   auto store_w = [&](const double* strip, double* row, bool live) {
     lds_sync();
 #pragma unroll
