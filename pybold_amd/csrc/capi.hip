@@ -127,16 +127,16 @@ const FastEntry* pick_fast(int N, int K) {
 // waves / (CUs x 4 SIMDs x 2), a last partial round at most half full costing ~0.56 of a
 // round (its waves run alone on their SIMDs), a fuller one a whole round, plus a fixed
 // ~0.03-0.05 for launch, prologue and epilogue.  Unit = one full round of the pair kernel
-// (16 384 problems, ~3.0 ms for 500 iterations of N = 300, K = 30 on MI355X).  Measured
+// (16 384 problems, ~2.73 ms for 500 iterations of N = 300, K = 30 on MI355X).  Measured
 // (tools/ab_forms.py, profiles/r2_ab_forms.txt):
-//   pair   8 problems per wave   1.00 per round
-//   fast1  4 problems per wave   0.56 per round of half as many problems
-//   wide   1 problem  per wave   0.165 per round of an eighth as many (short series only)
+//   pair   8 problems per wave   1.00 per round (2-parallel fast FIRs)
+//   fast1  4 problems per wave   0.63 per round of half as many problems
+//   wide   1 problem  per wave   0.19 per round of an eighth as many (short series only)
 // A problem count that is not a whole number of rounds is therefore split: whole rounds on
 // the pair (or single-row) kernel, the remainder on whichever form finishes it first, as a
 // second launch on the same stream (the first launch ends with every SIMD draining at once,
 // so running the remainder after it costs what overlapping would).
-constexpr double COST_FAST1 = 0.56, COST_WIDE = 0.165, COST_PARTIAL = 0.56;
+constexpr double COST_FAST1 = 0.63, COST_WIDE = 0.19, COST_PARTIAL = 0.56;
 constexpr double COST_LAUNCH = 0.03, COST_LAUNCH_WIDE = 0.05;
 enum Form { FORM_GENERIC = 0, FORM_FAST1 = 1, FORM_PAIR = 2, FORM_WIDE = 3 };
 

@@ -16,12 +16,13 @@
 // SPM HRF skipped: 440 + 53 packed instructions per forward FIR instead of 551, 425 + 67 per
 // adjoint FIR.
 //
-// Registers: the summed windows cost ~34 VGPRs more than the direct form has left, so the
-// float64 iterate of problem B is parked in LDS between its two uses of an iteration (the
-// padding mask, which used to sit there, is computed on the fly for the few samples that can
-// be padded at all); y is stored pre-combined as the initial values of the accumulator
-// chains.  LDS per 16-lane row: yc [S][16] float2, wB [S][16] float64 (+16 B for the cost
-// trace): 78.1 KB per workgroup, two workgroups per CU.
+// Registers: the summed windows are produced just before their first use and die as the
+// outputs advance, so that both float64 iterates still fit (240 VGPRs, two waves per SIMD);
+// the padding mask is no longer read from LDS but computed on the fly, on a scalar branch,
+// for the few trailing samples of a strip that can be padded at all; y is stored
+// pre-combined as the initial values of the accumulator chains.  (WB_LDS = true parks the
+// iterate of problem B in LDS between its two uses of an iteration instead: 206 VGPRs, but
+// 57 more LDS operations per iteration and 3 % slower; kept for larger S.)
 #pragma once
 #include "common.h"
 #include "fista_fast.h"
@@ -74,8 +75,11 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
   f2* ly = reinterpret_cast<f2*>(pair_smem) + (rslot + sub);                       // yc[j] at ly[j*16]
   double* lw = reinterpret_cast<double*>(pair_smem + (size_t)16 * S * 16 * sizeof(f2)) + (rslot + sub);
   double* stage_d = reinterpret_cast<double*>(reinterpret_cast<f2*>(pair_smem) + rslot);
-  float* stage_f = reinterpret_cast<float*>(pair_smem + (size_t)16 * S * 16 * sizeof(f2)) + 2 * rslot;
-  float* lj = reinterpret_cast<float*>(pair_smem + (size_t)16 * S * 16 * (sizeof(f2) + sizeof(double))) +
+  // second region: float [S][16] staging rows (prologue) -- float64 when it also parks wB
+  constexpr size_t R2 = WB_LDS ? sizeof(double) : sizeof(float);
+  float* stage_f = reinterpret_cast<float*>(pair_smem + (size_t)16 * S * 16 * sizeof(f2)) +
+                   (WB_LDS ? 2 : 1) * rslot;
+  float* lj = reinterpret_cast<float*>(pair_smem + (size_t)16 * S * 16 * (sizeof(f2) + R2)) +
               (threadIdx.x >> 4) * 4;
   auto lds_sync = [] {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -433,7 +437,7 @@ int launch_pair_ffa(const FistaArgs& a, const double* taps, int K, bool with_j, 
   const auto tf = make_taps_ffa<KT>(taps, K);
   const int64_t rows = ((int64_t)(a.P - a.p0) + 1) / 2;
   const dim3 grid((unsigned)((rows * 16 + 255) / 256)), block(256);
-  const size_t lds = (size_t)16 * S * 16 * (sizeof(f2) + sizeof(double)) + 16 * 4 * sizeof(float);
+  const size_t lds = (size_t)16 * S * 16 * (sizeof(f2) + sizeof(float)) + 16 * 4 * sizeof(float);
   const bool skip0 = KT > 1 && tf.pr[0].x == 0.0f;      // leading tap exactly zero
   if (with_j && skip0) hipLaunchKernelGGL((fista_pair_ffa_kernel<S, KT, true, true>), grid, block, lds, st, a, tf);
   else if (with_j) hipLaunchKernelGGL((fista_pair_ffa_kernel<S, KT, true, false>), grid, block, lds, st, a, tf);
