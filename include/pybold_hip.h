@@ -71,6 +71,13 @@ int pb_fista_has_fast_path(int N, int K);
  * one problem per wave (long series).  Host-only query. */
 int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mode, int wind);
 
+/* How pb_fista_solve (no flags) lays P problems out: problems [0, *n_main) in one launch of
+ * kernel form *main_form (whole rounds of waves; 0 problems = no such launch) and
+ * [*n_main, P) in a launch of *tail_form (forms numbered as pb_fista_which_kernel).
+ * Host-only query; any output pointer may be NULL. */
+int pb_fista_plan(int N, int K, int P, int stop_mode, int wind, int* n_main, int* main_form,
+                  int* tail_form);
+
 /*
  * Fused FISTA-like solver: n_iter iterations of the recurrence of
  *   deconv (fixed-lambda loop)   pybold/bold_signal.py:62-72

@@ -33,6 +33,7 @@ SIGNATURES = {
     "pb_last_error": (ctypes.c_char_p, []),
     "pb_fista_has_fast_path": (_c_int, [_c_int, _c_int]),
     "pb_fista_which_kernel": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int]),
+    "pb_fista_plan": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
     "pb_fista_solve": (_c_int, [
         _ptr, _c_i64, _c_int,            # y_dev, ldy, y_rep
         _ptr, _c_i64, _c_int, _c_int,    # w_dev, ldw, P, N

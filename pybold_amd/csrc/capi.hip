@@ -344,6 +344,28 @@ int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mod
   return pl.n_main > 0 ? pl.main_form : pl.tail_form;   // the form that carries most problems
 }
 
+int pb_fista_plan(int N, int K, int P, int stop_mode, int wind, int* n_main, int* main_form,
+                  int* tail_form) {
+  int nm = 0, mf = 0, tf = 0;
+  if (N >= 1 && K >= 1 && P >= 1) {
+    const FastEntry* fe = pick_fast(N, K);
+    if (fe && stop_mode == PB_STOP_WINDOW && (wind != 6 || fe->S > 20)) fe = nullptr;
+    if (fe) {
+      const Plan pl = plan_plain(P, fe->fn_pair != nullptr && stop_mode == PB_STOP_NONE,
+                                 pick_wide_small(N, K) != nullptr, false);
+      nm = pl.n_main; mf = pl.n_main > 0 ? pl.main_form : 0; tf = pl.tail_form;
+    } else {
+      const WideEntry* we = pick_wide(N, K);
+      if (we && stop_mode == PB_STOP_WINDOW && (wind != 6 || we->S > 20)) we = nullptr;
+      tf = we ? FORM_WIDE : FORM_GENERIC;
+    }
+  }
+  if (n_main) *n_main = nm;
+  if (main_form) *main_form = mf;
+  if (tail_form) *tail_form = tf;
+  return PB_OK;
+}
+
 int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, int64_t ldw, int P,
                    int N, const double* taps_host, const double* taps_dev, int K, double step,
                    double lbda,

@@ -99,7 +99,7 @@ def has_fast_path(n_scans, n_taps):
 
 
 KERNEL_NAMES = {0: "fista_generic_kernel (LDS)", 1: "fista_fast_kernel (register-resident)",
-                2: "fista_pair_kernel (register-resident, two problems per row)",
+                2: "fista_pair_ffa_kernel (register-resident, two problems per row, fast FIRs)",
                 3: "fista_fast_kernel (register-resident, one problem per wave)"}
 
 
@@ -107,6 +107,16 @@ def which_kernel(n_scans, n_taps, n_problems, want_J=False, stop=None, wind=6):
     """Name of the kernel :func:`fista_solve` dispatches to for this call shape."""
     return KERNEL_NAMES[_lib.load().pb_fista_which_kernel(
         int(n_scans), int(n_taps), int(n_problems), int(bool(want_J)), _STOP[stop], int(wind))]
+
+
+def launch_plan(n_scans, n_taps, n_problems, stop=None, wind=6):
+    """``(n_main, main kernel, tail kernel)``: how :func:`fista_solve` lays the problems out --
+    the first ``n_main`` (whole rounds of waves) in one launch, the rest in a second one."""
+    import ctypes
+    nm, mf, tf = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    _lib.load().pb_fista_plan(int(n_scans), int(n_taps), int(n_problems), _STOP[stop], int(wind),
+                              ctypes.byref(nm), ctypes.byref(mf), ctypes.byref(tf))
+    return nm.value, (KERNEL_NAMES[mf.value] if nm.value else None), KERNEL_NAMES[tf.value]
 
 
 def fista_solve(Y, hrf, lbda, step, n_iter, W0=None, want_J=False, stop=None,
