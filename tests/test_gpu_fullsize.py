@@ -96,6 +96,12 @@ def test_regularisation_path_config5_slice(setup):
     for i in (0, 7, 19):
         Wi, _, _ = solver.fista_solve(Ysub, hrf, float(lbdas[i]), step, 50)
         assert rel_rows_t(Wp[:, i, :], Wi) < 1e-6       # may run on different kernels
+    idx = np.array([3, 777, 1999])                      # and against the C oracle
+    Ys = Ysub[torch.from_numpy(idx).cuda()].cpu().numpy().astype(np.float64)
+    for i in (0, 19):
+        Wo, _, _ = c_oracle.fista_batch(Ys, hrf, float(lbdas[i]), step, 50, threads=4)
+        Wg = Wp[torch.from_numpy(idx).cuda(), i, :].cpu().numpy()
+        assert (np.linalg.norm(Wg - Wo, axis=1) / np.linalg.norm(Wo, axis=1)).max() < 1e-5
 
 
 # ---- every BASELINE config at full size (round 2) ----------------------------------------

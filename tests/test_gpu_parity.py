@@ -189,9 +189,11 @@ def test_many_problems_partial_last_block(pa, golden):
         assert (n_done.cpu().numpy() == 25).all()
     # per-problem lambda and shared y rows through the pair kernel
     lam = np.tile([0.1, 1.0, 10.0], 35)
-    W, _, _ = solver.fista_solve(dev32(Yb), hrf, lam, 1.0 / lip, 10, y_rep=3, force="fast2")
-    W1, _, _ = solver.fista_solve(dev32(Yb), hrf, lam, 1.0 / lip, 10, y_rep=3, force="fast1")
-    assert rel_rows(W.cpu().numpy(), W1.cpu().numpy()) < 1e-6
+    Wref = orc.fista_batch(np.repeat(Yb, 3, axis=0).astype(np.float32).astype(np.float64), hrf, lam,
+                           1.0 / lip, 10)
+    for force in ("fast2", "fast2d", "fast1", "wide", None):
+        W, _, _ = solver.fista_solve(dev32(Yb), hrf, lam, 1.0 / lip, 10, y_rep=3, force=force)
+        assert rel_rows(W.cpu().numpy(), Wref) < EPS, force
 
 
 def test_loops_deconv_goldens(pa, golden):
