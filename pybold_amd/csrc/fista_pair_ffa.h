@@ -58,7 +58,10 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
   constexpr int KE = (KT + 1) / 2;          // taps per phase
   constexpr int WL = H + S;                 // window length
   constexpr int NW = (WL + 1) / 2;          // window pairs
-  constexpr int GN = 2;                     // pairs per accumulator group (6 chains)
+#ifndef PB_FFA_GN
+#define PB_FFA_GN 2
+#endif
+  constexpr int GN = PB_FFA_GN;             // pairs per accumulator group (3 chains each)
   static_assert(D <= 15, "halo spans more than one DPP row");
 
   const int gid = blockIdx.x * 256 + threadIdx.x;

@@ -584,3 +584,38 @@ def test_errors_are_loud(pa, golden):
         solver.fista_solve(dev32(Y), np.ones(5000), 1.0, 1.0, 5, force="fast")
     with pytest.raises(TypeError):
         solver.fista_solve(torch.zeros(4, 300), hrf, 1.0, 1.0, 5)   # CPU tensor
+
+
+@pytest.mark.parametrize("force", ["fast1", "wide"])
+def test_window_rule_resolution(pa, golden, force):
+    """How finely the in-kernel window rule (float32 increments, packed float32 norms)
+    resolves the criterion: with `tol` set 1e-5 (relative) above / below the oracle's
+    criterion value at some iteration k0, the float32-FIR kernels stop exactly where the
+    float64 oracle does, on either side (measured: still exact at 1e-6)."""
+    _, solver = pa
+    g = golden("early_stop")
+    y, hrf, lip = g["y"].astype(np.float32).astype(np.float64), g["hrf"], float(g["lipschitz"])
+    # criterion trace of the reference recurrence (oracle restatement, float64)
+    H = orc._MatrixFreeH(hrf)
+    Hty, step, th = H.adj(y), 1.0 / lip, 1.0 / lip
+    w, hist, t_old, crit = np.zeros_like(y), [], 1.0, {}
+    for k in range(400):
+        u = w - step * (H.adj(H.op(w)) - Hty)
+        if k > 0 and hist:
+            hist[-1] = u
+        p = orc.soft_threshold(u, th)
+        t = 0.5 * (1.0 + np.sqrt(1.0 + 4.0 * t_old ** 2))
+        w = p + (t_old - 1.0) / t * (p - (u if k > 0 else 0.0))
+        t_old = t
+        hist.append(w)
+        hist = hist[-6:]
+        if k > 6:
+            old, new = np.mean(hist[:-3], axis=0), np.mean(hist[-3:], axis=0)
+            crit[k] = np.linalg.norm(new - old) / (np.linalg.norm(new) + 1e-10)
+    for k0 in (40, 150, 300):
+        assert all(crit[k] > crit[k0] * 1.002 for k in range(7, k0)), "criterion not monotone here"
+        k_next = min(k for k in range(k0 + 1, 400) if crit[k] < crit[k0] * (1 - 1e-5))
+        for tol, n_ref in ((crit[k0] * (1 + 1e-5), k0 + 1), (crit[k0] * (1 - 1e-5), k_next + 1)):
+            W, _, nd = solver.fista_solve(dev32(np.stack([y, y])), hrf, 1.0, step, 1000, stop="window",
+                                          tol=tol, wind=6, force=force)
+            assert nd.cpu().numpy().tolist() == [n_ref, n_ref], (force, k0, tol, nd, n_ref)
