@@ -47,6 +47,7 @@ struct FastEntry {
   fast_launch_pp_fn fn_pp;
   pair_launch_fn fn_pair;     // two-problems-per-row kernel (S <= 20, KT <= 32 only), else nullptr
   pair_launch_fn fn_pair_ffa; // the same with 2-parallel fast FIRs (fista_pair_ffa.h)
+  int (*fn_pair_dev)(const pb::FistaArgs&, hipStream_t);   // ... reading ONE shared HRF from device memory
 };
 
 }  // namespace
@@ -57,7 +58,8 @@ namespace pb {
   extern template int launch_fast<S, KT>(const FistaArgs&, const double*, int, bool, int, hipStream_t); \
   extern template int launch_fast_pp<S, KT>(const FistaArgs&, int, hipStream_t);            \
   extern template int launch_pair<S, KT>(const FistaArgs&, const double*, int, bool, hipStream_t); \
-  extern template int launch_pair_ffa<S, KT>(const FistaArgs&, const double*, int, bool, hipStream_t);
+  extern template int launch_pair_ffa<S, KT>(const FistaArgs&, const double*, int, bool, hipStream_t); \
+  extern template int launch_pair_ffa_dev<S, KT>(const FistaArgs&, hipStream_t);
 #include "fast_table.inc"
 #undef PB_FAST
 }  // namespace pb
@@ -105,8 +107,13 @@ template <int S, int KT>
 constexpr pair_launch_fn pair_ffa_or_null() {
   if constexpr (S <= 20 && KT <= 32) return &pb::launch_pair_ffa<S, KT>; else return nullptr;
 }
-#define PB_FAST(S, KT) \
-  {S, KT, &pb::launch_fast<S, KT>, &pb::launch_fast_pp<S, KT>, pair_or_null<S, KT>(), pair_ffa_or_null<S, KT>()},
+template <int S, int KT>
+constexpr int (*pair_dev_or_null())(const pb::FistaArgs&, hipStream_t) {
+  if constexpr (S <= 20 && KT <= 32) return &pb::launch_pair_ffa_dev<S, KT>; else return nullptr;
+}
+#define PB_FAST(S, KT)                                                                             \
+  {S, KT, &pb::launch_fast<S, KT>, &pb::launch_fast_pp<S, KT>, pair_or_null<S, KT>(),             \
+   pair_ffa_or_null<S, KT>(), pair_dev_or_null<S, KT>()},
 const FastEntry kFast[] = {
 #include "fast_table.inc"
 };
@@ -714,6 +721,27 @@ int pb_fista_solve_pp(const float* y_dev, int64_t ldy, double* w_dev, int64_t ld
 
   const FastEntry* fe = (flags & PB_FLAG_FORCE_GENERIC) ? nullptr : pick_fast(N, K);
   if (fe) {
+    // ONE shared HRF, no stop rule: the pair form (taps read from device memory) wherever the
+    // dispatch model of plain solves would use it, the per-problem-taps kernel elsewhere
+    if (ldt == 0 && stop_mode == PB_STOP_NONE && fe->fn_pair_dev && P >= 2 &&
+        !(flags & (PB_FLAG_NO_PAIR | PB_FLAG_DIRECT_FIR))) {
+      Plan pl{0, FORM_GENERIC, FORM_PAIR};
+      if (!(flags & PB_FLAG_FORCE_PAIR)) pl = plan_plain(P, true, false, (flags & PB_FLAG_ONE_LAUNCH) != 0);
+      auto run = [&](int form, int p0, int p1) -> int {
+        pb::FistaArgs b = a;
+        b.p0 = p0;
+        b.P = p1;
+        const int bad = (form == FORM_PAIR) ? fe->fn_pair_dev(b, (hipStream_t)stream)
+                                            : fe->fn_pp(b, stop_mode, (hipStream_t)stream);
+        if (bad) return fail(PB_ERR_INVALID, "pb_fista_solve_pp: launch rejected");
+        return check_launch(form == FORM_PAIR ? "fista_pair_ffa_kernel(shared taps)" : "fista_fast_kernel(pp)");
+      };
+      if (pl.n_main > 0) {
+        const int rc = run(pl.main_form, 0, pl.n_main);
+        if (rc != PB_OK) return rc;
+      }
+      return run(pl.tail_form, pl.n_main, P);
+    }
     if (fe->fn_pp(a, stop_mode, (hipStream_t)stream) != 0)
       return fail(PB_ERR_INVALID, "pb_fista_solve_pp: launch rejected");
     return check_launch("fista_fast_kernel(pp)");

@@ -51,8 +51,12 @@ inline TapsFFA<KT> make_taps_ffa(const double* taps, int K) {
   return t;
 }
 
-template <int S, int KT, bool WITH_J = false, bool SKIP0 = false, bool WB_LDS = false>
-__global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, TapsFFA<KT> taps) {
+// TAPS_DEV: the HRF and the step are read from device memory (a.taps_pp: K float64 shared by
+// every problem, a.step_vec[0]) instead of the kernel arguments -- the shared-HRF blind step,
+// whose taps come out of pb_theta_fit without passing through the host.  Uniform loads: the
+// taps still end up in SGPRs.
+template <int S, int KT, bool WITH_J = false, bool SKIP0 = false, bool WB_LDS = false, bool TAPS_DEV = false>
+__global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, TapsFFA<KT> taps_arg) {
   constexpr int H = KT - 1;
   constexpr int D = (H + S - 1) / S;
   constexpr int KE = (KT + 1) / 2;          // taps per phase
@@ -137,10 +141,27 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
       if constexpr (WB_LDS) lw[j * 16] = wB[j]; else wBr[j] = wB[j];
     }
   }
+  TapsFFA<KT> taps = taps_arg;
+  double step = a.step;
+  if constexpr (TAPS_DEV) {
+    auto uni = [](float v) -> float {       // wave-uniform value -> SGPR
+      return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+    };
+    auto h = [&](int m) -> float { return (m < a.K) ? (float)a.taps_pp[m] : 0.0f; };
+#pragma unroll
+    for (int k = 0; k < KE; ++k) taps.pr[k] = f2{uni(h(2 * k)), uni(h(2 * k + 1))};
+#pragma unroll
+    for (int i = 0; i < (KE + 1) / 2; ++i) {
+      const float s0 = (2 * i < KE) ? h(4 * i) + h(4 * i + 1) : 0.0f;
+      const float s1 = (2 * i + 1 < KE) ? h(4 * i + 2) + h(4 * i + 3) : 0.0f;
+      taps.sm[i] = f2{uni(s0), uni(s1)};
+    }
+    step = a.step_vec[0];
+  }
   const double lbA = a.lbda_vec ? a.lbda_vec[pA] : a.lbda;
   const double lbB = a.lbda_vec ? a.lbda_vec[pB] : a.lbda;
-  const double thA = lbA * a.step, thB = lbB * a.step;
-  const double nstep = -a.step;
+  const double thA = lbA * step, thB = lbB * step;
+  const double nstep = -step;
   if constexpr (WITH_J) {
     lj[0] = (float)lbA;
     lj[1] = (float)lbB;
@@ -433,6 +454,17 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
     if (liveA) a.n_done[pA] = a.n_iter;
     if (liveB) a.n_done[pB] = a.n_iter;
   }
+}
+
+// shared HRF and step in device memory (a.taps_pp, a.step_vec[0]); no cost trace
+template <int S, int KT>
+int launch_pair_ffa_dev(const FistaArgs& a, hipStream_t st) {
+  const TapsFFA<KT> none{};
+  const int64_t rows = ((int64_t)(a.P - a.p0) + 1) / 2;
+  const dim3 grid((unsigned)((rows * 16 + 255) / 256)), block(256);
+  const size_t lds = (size_t)16 * S * 16 * (sizeof(f2) + sizeof(float)) + 16 * 4 * sizeof(float);
+  hipLaunchKernelGGL((fista_pair_ffa_kernel<S, KT, false, false, false, true>), grid, block, lds, st, a, none);
+  return 0;
 }
 
 template <int S, int KT>

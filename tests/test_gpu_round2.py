@@ -327,3 +327,27 @@ def test_deconv_auto_lambda_at_reference_defaults(golden):
     np.testing.assert_array_equal(np.isnan(Jb.T)[robust], np.isnan(Jo)[robust])
     np.testing.assert_array_equal((~np.isnan(Jb.T)).sum(axis=1)[robust], n_outer[robust])
     np.testing.assert_allclose(Jb.T[robust], Jo[robust], rtol=1e-8)
+
+
+def test_shared_taps_pair_kernel_at_scale(solver, golden):
+    """Shared HRF read from device memory on a machine-filling batch: the pair kernel with
+    fast FIRs carries the whole rounds, the per-problem-taps kernel the remainder; both against
+    the C oracle and against the host-taps solver."""
+    from oracle import c_oracle
+    from pybold_amd.utils import gram_frobenius
+    g = golden("loops_deconv")
+    h = g["h"]                                   # K = 27, h[0] = 0
+    rng = np.random.RandomState(1)
+    P, N = 20000, 300
+    Y = rng.randn(P, N).astype(np.float32)
+    step = 1.0 / gram_frobenius(h, N)
+    Yd = torch.from_numpy(Y).cuda()
+    Ws, _ = solver.fista_solve_pp(Yd, dev64(h), dev64([step]), 1.7, 60)
+    Wh, _, _ = solver.fista_solve(Yd, h, 1.7, step, 60)
+    assert rel_rows(Ws.cpu().numpy(), Wh.cpu().numpy()) < 1e-6
+    idx = np.concatenate([rng.choice(16384, 24, replace=False), 16384 + rng.choice(P - 16384, 24, replace=False)])
+    Wo, _, _ = c_oracle.fista_batch(Y[idx].astype(np.float64), h, 1.7, step, 60, threads=8)
+    assert rel_rows(Ws.cpu().numpy()[idx], Wo) < 1e-5
+    for force in ("fast2", "fast1"):
+        Wf, _ = solver.fista_solve_pp(Yd, dev64(h), dev64([step]), 1.7, 60, force=force)
+        assert rel_rows(Wf.cpu().numpy()[idx], Wo) < 1e-5, force
