@@ -230,15 +230,19 @@ int pb_spm_hrf(const double* deltas_dev, int M, const double* t_dev, int K,
  * theta-step, whose finite-difference L-BFGS-B is sensitive to the last digits of the cost
  * (pybold/bold_signal.py:217-222, :329-333).
  *
- * pb_fista_solve_d    pb_fista_solve on the any-size LDS kernel, all float64: y float64,
- *                     cost trace J float64 [P][ldj]; taps from device memory.
+ * pb_fista_solve_d    pb_fista_solve in float64 end to end: y float64, cost trace J float64
+ *                     [P][ldj].  Register-resident kernel (one problem per wave,
+ *                     fista_exact_kernel) for series of up to 640 scans with HRFs of up to
+ *                     32 taps when taps_host is given (window rule: wind = 6); otherwise, or
+ *                     with PB_FLAG_FORCE_GENERIC, the any-size LDS kernel, which reads the taps
+ *                     from taps_dev.  Either taps pointer may be NULL if the other kernel runs.
  * pb_fista_stats_d, pb_hrf_cost_d, pb_hrf_cost_pv_d   as their float32-y namesakes.
  */
 int pb_fista_solve_d(const double* y_dev, int64_t ldy, int y_rep, double* w_dev, int64_t ldw,
-                     int P, int N, const double* taps_dev, int K, double step, double lbda,
-                     const double* lbda_dev, const double* betas_dev, int n_iter,
-                     double* J_dev, int64_t ldj, int stop_mode, double tol, int wind,
-                     int32_t* n_done_dev, void* stream);
+                     int P, int N, const double* taps_host, const double* taps_dev, int K,
+                     double step, double lbda, const double* lbda_dev, const double* betas_dev,
+                     int n_iter, double* J_dev, int64_t ldj, int stop_mode, double tol, int wind,
+                     int32_t* n_done_dev, unsigned flags, void* stream);
 int pb_fista_stats_d(const double* w_dev, int64_t ldw, const double* y_dev, int64_t ldy,
                      int y_rep, int P, int N, const double* taps_dev, int K,
                      double* r2_dev, double* l1_dev, void* stream);

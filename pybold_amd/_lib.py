@@ -76,12 +76,12 @@ SIGNATURES = {
     "pb_fista_solve_d": (_c_int, [
         _ptr, _c_i64, _c_int,            # y_dev (float64), ldy, y_rep
         _ptr, _c_i64, _c_int, _c_int,    # w_dev, ldw, P, N
-        _ptr, _c_int,                    # taps_dev, K
+        _ptr, _ptr, _c_int,              # taps_host, taps_dev, K
         _c_dbl, _c_dbl, _ptr,            # step, lbda, lbda_dev
         _ptr, _c_int,                    # betas_dev, n_iter
         _ptr, _c_i64,                    # J_dev (float64), ldj
         _c_int, _c_dbl, _c_int, _ptr,    # stop_mode, tol, wind, n_done_dev
-        _ptr]),                          # stream
+        ctypes.c_uint, _ptr]),           # flags, stream
     "pb_fista_stats_d": (_c_int, [_ptr, _c_i64, _ptr, _c_i64, _c_int, _c_int, _c_int, _ptr,
                                   _c_int, _ptr, _ptr, _ptr]),
     "pb_hrf_cost_d": (_c_int, [_ptr, _c_i64, _ptr, _c_i64, _c_int, _c_int, _ptr,

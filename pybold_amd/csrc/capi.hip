@@ -12,6 +12,7 @@
 #include "launch_fast.h"
 #include "fista_pair.h"
 #include "fista_pair_ffa.h"
+#include "fista_exact.h"
 #include "blind.h"
 
 namespace {
@@ -88,6 +89,37 @@ const WideEntry kWide[] = {
 #include "wide_table.inc"
 };
 #undef PB_WIDE
+
+typedef int (*exact_launch_fn)(const pb::FistaArgs&, const double* taps, int K, bool with_j, int stop,
+                               hipStream_t);
+struct ExactEntry {
+  int S, KT;
+  exact_launch_fn fn;
+};
+}  // namespace
+namespace pb {
+#define PB_EXACT(S, KT) \
+  extern template int launch_exact<S, KT>(const FistaArgs&, const double*, int, bool, int, hipStream_t);
+#include "exact_table.inc"
+#undef PB_EXACT
+}  // namespace pb
+namespace {
+#define PB_EXACT(S, KT) {S, KT, &pb::launch_exact<S, KT>},
+const ExactEntry kExact[] = {
+#include "exact_table.inc"
+};
+#undef PB_EXACT
+
+// all-float64 register-resident form (one problem per wave): cheapest entry that holds (N, K)
+const ExactEntry* pick_exact(int N, int K) {
+  const ExactEntry* best = nullptr;
+  const int s_need = (N + 63) / 64;
+  for (const ExactEntry& e : kExact) {
+    if (e.S < s_need || e.KT < K) continue;
+    if (!best || (int64_t)e.S * e.KT < (int64_t)best->S * best->KT) best = &e;
+  }
+  return best;
+}
 
 const WideEntry* pick_wide(int N, int K) {
   const WideEntry* best = nullptr;
@@ -475,10 +507,10 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
 }
 
 int pb_fista_solve_d(const double* y_dev, int64_t ldy, int y_rep, double* w_dev, int64_t ldw,
-                     int P, int N, const double* taps_dev, int K, double step, double lbda,
-                     const double* lbda_dev, const double* betas_dev, int n_iter, double* J_dev,
-                     int64_t ldj, int stop_mode, double tol, int wind, int32_t* n_done_dev,
-                     void* stream) {
+                     int P, int N, const double* taps_host, const double* taps_dev, int K,
+                     double step, double lbda, const double* lbda_dev, const double* betas_dev,
+                     int n_iter, double* J_dev, int64_t ldj, int stop_mode, double tol, int wind,
+                     int32_t* n_done_dev, unsigned flags, void* stream) {
   if (P < 0 || N < 1 || K < 1 || n_iter < 0 || y_rep < 1)
     return fail(PB_ERR_INVALID, "pb_fista_solve_d: bad size (P=%d N=%d K=%d n_iter=%d y_rep=%d)", P,
                 N, K, n_iter, y_rep);
@@ -489,19 +521,31 @@ int pb_fista_solve_d(const double* y_dev, int64_t ldy, int y_rep, double* w_dev,
     return fail(PB_ERR_INVALID, "pb_fista_solve_d: unknown stop_mode %d", stop_mode);
   if (stop_mode == PB_STOP_WINDOW && wind < 2)
     return fail(PB_ERR_INVALID, "pb_fista_solve_d: wind must be >= 2");
+  // register-resident float64 form (one problem per wave) when the shape has an entry and
+  // the host copy of the taps is given; the window rule there is the reference default wind = 6
+  const ExactEntry* ee = (taps_host && !(flags & PB_FLAG_FORCE_GENERIC)) ? pick_exact(N, K) : nullptr;
+  if (ee && stop_mode == PB_STOP_WINDOW && wind != 6) ee = nullptr;
+  if (!ee && (flags & PB_FLAG_FORCE_FAST))
+    return fail(PB_ERR_INVALID, "pb_fista_solve_d: no register-resident float64 kernel for N=%d K=%d", N, K);
   const int64_t nd = 3 * (int64_t)N + K + 2 * pb::GEN_WAVES +
                      (stop_mode == PB_STOP_WINDOW ? (int64_t)wind * N : 0);
-  if (nd > LDS_DOUBLES_MAX)
+  if (!ee && nd > LDS_DOUBLES_MAX)
     return fail(PB_ERR_INVALID, "pb_fista_solve_d: N=%d K=%d wind=%d exceeds LDS", N, K, wind);
   if (P == 0) return PB_OK;
-  if (!y_dev || !w_dev || !taps_dev || (n_iter > 0 && !betas_dev))
+  if (!y_dev || !w_dev || (!ee && !taps_dev) || (n_iter > 0 && !betas_dev))
     return fail(PB_ERR_INVALID, "pb_fista_solve_d: NULL pointer");
+  if (P > (1 << 25)) return fail(PB_ERR_INVALID, "pb_fista_solve_d: more than 2^25 problems per launch");
   pb::FistaArgs a;
   a.y = nullptr; a.y64 = y_dev; a.ldy = ldy; a.w = w_dev; a.ldw = ldw; a.lbda_vec = lbda_dev;
   a.betas = betas_dev; a.J = nullptr; a.J64 = J_dev; a.ldj = ldj; a.n_done = n_done_dev;
   a.step = step; a.lbda = lbda; a.tol = tol;
   a.y_rep = y_rep; a.P = P; a.N = N; a.n_iter = n_iter; a.stop_mode = stop_mode;
   a.taps_pp = nullptr; a.ldt = 0; a.step_vec = nullptr; a.step_shared = 0; a.K = K; a.p0 = 0;
+  if (ee) {
+    if (ee->fn(a, taps_host, K, J_dev != nullptr, stop_mode, (hipStream_t)stream) != 0)
+      return fail(PB_ERR_INVALID, "pb_fista_solve_d: launch rejected");
+    return check_launch("fista_exact_kernel");
+  }
   const size_t lds = (size_t)nd * sizeof(double);
   if (J_dev)
     hipLaunchKernelGGL((pb::fista_generic_kernel<true, true>), dim3(P), dim3(pb::GEN_THREADS), lds,

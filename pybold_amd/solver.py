@@ -125,8 +125,9 @@ def fista_solve(Y, hrf, lbda, step, n_iter, W0=None, want_J=False, stop=None,
     (pybold/bold_signal.py:62-72, :259-276) for every row of ``Y`` in one launch.
 
     Y     float32 CUDA ``(V, N)`` (the batch layout; register-resident kernels), or
-          float64 CUDA ``(V, N)``: all-float64 LDS kernel (``pb_fista_solve_d``), the
-          reference's arithmetic end to end -- what the 1-D calls of the API use
+          float64 CUDA ``(V, N)``: float64 end to end (``pb_fista_solve_d``: register-resident
+          one-problem-per-wave kernel for N <= 640, K <= 32, else the LDS kernel), the
+          reference's arithmetic -- what the 1-D calls of the API use
     hrf   1-D array of K taps (host)
     lbda  scalar, or array/tensor of ``V * y_rep`` per-problem values
     step  ``1 / L``
@@ -163,16 +164,18 @@ def fista_solve(Y, hrf, lbda, step, n_iter, W0=None, want_J=False, stop=None,
         J.fill_(float("nan"))
     n_done = torch.empty((P,), dtype=torch.int32, device=dev)
     if f64:
-        if force not in (None, "generic"):
-            raise ValueError("float64 y runs on the all-float64 LDS kernel only")
+        if force not in (None, "generic", "fast"):
+            raise ValueError("float64 y: force must be None, 'fast' (register-resident float64 "
+                             "kernel) or 'generic' (LDS kernel)")
         with torch.cuda.device(dev):
             rc = lib.pb_fista_solve_d(
                 Y.data_ptr(), _ld(Y), int(y_rep), W.data_ptr(), _ld(W), P, N,
-                taps_dev.data_ptr(), taps.size, float(step), lbda_scalar,
+                taps.ctypes.data, taps_dev.data_ptr(), taps.size, float(step), lbda_scalar,
                 lbda_dev.data_ptr() if lbda_dev is not None else None,
                 betas.data_ptr(), int(n_iter),
                 J.data_ptr() if J is not None else None, _ld(J) if J is not None else 0,
-                _STOP[stop], float(tol), int(wind), n_done.data_ptr(), _stream_ptr(dev))
+                _STOP[stop], float(tol), int(wind), n_done.data_ptr(), _FORCE[force],
+                _stream_ptr(dev))
         _lib.check(rc, "pb_fista_solve_d")
         return W, J, n_done
     with torch.cuda.device(dev):

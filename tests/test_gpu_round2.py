@@ -85,15 +85,17 @@ def test_empty_batch_in_every_wrapper(solver, golden):
     assert X.shape == (0, N) and taps.shape[0] == 0
 
 
-def test_float64_solver_is_the_reference_arithmetic(solver, golden):
-    """pb_fista_solve_d: float64 end to end, golden grid at 1e-10 (the float32-FIR
-    kernels are held to 1e-5), cost trace at 1e-12, stop rules exact."""
+@pytest.mark.parametrize("force", ["fast", "generic"])
+def test_float64_solver_is_the_reference_arithmetic(solver, golden, force):
+    """pb_fista_solve_d: float64 end to end -- register-resident one-problem-per-wave kernel
+    ("fast") and LDS kernel ("generic") -- golden grid at 1e-10 (the float32-FIR kernels are
+    held to 1e-5), cost trace at 1e-11."""
     g = golden("grid")
     Y = np.stack([g["y_s%d" % s] for s in range(4)])
     hrf, lip = g["hrf"], float(g["lip_s0"])
     for lbda in (0.1, 1.0, 10.0):
         for nit in (1, 2, 3, 10, 500):
-            W, J, nd = solver.fista_solve(dev64(Y), hrf, lbda, 1.0 / lip, nit, want_J=True)
+            W, J, nd = solver.fista_solve(dev64(Y), hrf, lbda, 1.0 / lip, nit, want_J=True, force=force)
             ref = np.stack([g["dz_s%d_l%g_n%d" % (s, lbda, nit)] for s in range(4)])
             assert rel_rows(W.cpu().numpy(), ref) < 1e-10, (lbda, nit)
             assert J.dtype == torch.float64
@@ -106,7 +108,61 @@ def test_float64_solver_is_the_reference_arithmetic(solver, golden):
     r2, l1 = solver.fista_stats(W, dev64(g1["y"][None]), g1["hrf"])
     assert float(r2[0]) == pytest.approx(np.sum(np.square(g1["x"] - g1["y"])), rel=1e-12)
     with pytest.raises(ValueError):
-        solver.fista_solve(dev64(Y), hrf, 1.0, 1.0 / lip, 5, force="fast")
+        solver.fista_solve(dev64(Y), hrf, 1.0, 1.0 / lip, 5, force="fast2")
+
+
+@pytest.mark.parametrize("force", ["fast", "generic"])
+def test_float64_stop_rules_and_shapes(solver, golden, force):
+    """Both float64 kernels: golden stop iterations of the window rule (26/77/191/311) and of
+    the _loops_deconv rule, cost trace, per-problem lambda with shared y rows, warm start,
+    series of 600 scans (S = 10 entry) and shapes without a register-resident entry."""
+    from pybold_amd._lib import PyboldHipError
+    g = golden("early_stop")
+    y, hrf, lip = g["y"], g["hrf"], float(g["lipschitz"])
+    Yb = np.stack([y, 3.0 * y, y])
+    for tol, n_ref in ((0.1, 26), (0.03, 77), (0.01, 191), (0.005, 311)):
+        W, J, nd = solver.fista_solve(dev64(Yb), hrf, 1.0, 1.0 / lip, 1000, want_J=True, stop="window",
+                                      tol=tol, wind=6, force=force)
+        nd = nd.cpu().numpy()
+        assert nd[0] == n_ref and nd[2] == n_ref, (force, tol, nd)
+        assert rel_rows(W.cpu().numpy()[[0, 2]], np.stack([g["dz_%g" % tol]] * 2)) < 1e-10
+        Jn = J.cpu().numpy()
+        assert np.isfinite(Jn[0, :n_ref]).all() and np.isnan(Jn[0, n_ref:]).all()
+    gl = golden("loops_deconv")
+    yl, hl = gl["y"], gl["h"]
+    from pybold_amd.utils import gram_frobenius
+    stepl = 1.0 / gram_frobenius(hl, len(yl))
+    for nit in (1, 2, 5, 100):
+        for es_on, tol in ((False, 1e-12), (True, 1e-2), (True, 1e-3)):
+            W, _, _ = solver.fista_solve(dev64(yl[None]), hl, 1.7, stepl, nit, stop="loops" if es_on else None,
+                                         tol=tol, force=force)
+            assert rel_rows(W.cpu().numpy(), gl["w_n%d_es%d_tol%g" % (nit, es_on, tol)][None]) < 1e-9, (nit, es_on, tol)
+    W, _, _ = solver.fista_solve(dev64(yl[None]), hl, 1.7, stepl, 5, W0=dev64(gl["w0"][None]), force=force)
+    assert rel_rows(W.cpu().numpy(), gl["w_warm_n5"][None]) < 1e-9
+    # per-problem lambda, shared rows
+    gg = golden("grid")
+    Y = np.stack([gg["y_s%d" % s] for s in range(4)])
+    lam = np.tile([0.1, 1.0, 10.0], 4)
+    W, _, _ = solver.fista_solve(dev64(Y), gg["hrf"], lam, 1.0 / float(gg["lip_s0"]), 10, y_rep=3, force=force)
+    W = W.cpu().numpy().reshape(4, 3, -1)
+    for s in range(4):
+        for i, lb in enumerate((0.1, 1.0, 10.0)):
+            assert rel_rows(W[s, i], gg["dz_s%d_l%g_n10" % (s, lb)]) < 1e-10
+    # other shapes: N = 600 (S = 10), N = 37 / K = 5, and beyond the register-resident table
+    rng = np.random.RandomState(7)
+    for N, K in ((600, 30), (37, 5), (640, 32), (700, 30), (300, 40)):
+        hk = rng.randn(K) * 0.3
+        Yk = rng.randn(6, N)
+        A = orc.toeplitz_from_kernel(hk, N, N).dot(np.tril(np.ones((N, N))))
+        lk = 1.05 * np.linalg.norm(A, 2) ** 2
+        ref = orc.fista_batch(Yk, hk, 0.05, 1.0 / lk, 30)
+        has_entry = N <= 640 and K <= 32
+        if force == "fast" and not has_entry:
+            with pytest.raises(PyboldHipError):
+                solver.fista_solve(dev64(Yk), hk, 0.05, 1.0 / lk, 30, force="fast")
+            continue
+        W, _, _ = solver.fista_solve(dev64(Yk), hk, 0.05, 1.0 / lk, 30, force=force)
+        assert np.abs(W.cpu().numpy() - ref).max() / np.abs(ref).max() < 1e-10, (force, N, K)
 
 
 def test_one_d_api_calls_match_goldens_tightly(golden):
