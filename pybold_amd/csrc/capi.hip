@@ -222,15 +222,18 @@ Plan plan_plain(int P, bool has_pair, bool has_wide, bool one_launch) {
   if (one_launch) return best;
   for (int main_form : {FORM_PAIR, FORM_FAST1}) {
     if (main_form == FORM_PAIR && !has_pair) continue;
-    const int round = (int)wave_slots() * problems_per_wave(main_form);
-    const int n_main = (P / round) * round;
-    if (n_main == 0 || n_main == P) continue;
-    double c_tail;
-    const int tail = best_form(P - n_main, has_pair, has_wide, &c_tail);
-    const double c = form_cost(main_form, n_main) + c_tail;
-    if (c < c_best) {
-      c_best = c;
-      best = Plan{n_main, main_form, tail};
+    // main launch = a whole number of rounds, or of half rounds (every wave alone on its SIMD)
+    const int half = (int)wave_slots() * problems_per_wave(main_form) / 2;
+    for (int unit : {2 * half, half}) {
+      const int n_main = (P / unit) * unit;
+      if (n_main == 0 || n_main == P) continue;
+      double c_tail;
+      const int tail = best_form(P - n_main, has_pair, has_wide, &c_tail);
+      const double c = form_cost(main_form, n_main) + c_tail;
+      if (c < c_best) {
+        c_best = c;
+        best = Plan{n_main, main_form, tail};
+      }
     }
   }
   return best;

@@ -59,7 +59,8 @@ def test_version_and_dispatch_table(lib):
     assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 2, 6) == 1
     assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 2, 4) == 0
     assert lib.pb_fista_which_kernel(300, 30, 1, 0, 0, 6) == 3           # a few short series: one per wave
-    assert lib.pb_fista_which_kernel(300, 30, 10000, 0, 0, 6) == 1       # config 2: single-row kernel
+    assert lib.pb_fista_which_kernel(300, 30, 10000, 0, 0, 6) == 2       # config 2: half a round of pair waves + a remainder
+    assert lib.pb_fista_which_kernel(300, 30, 4096, 0, 0, 6) == 1        # single-row kernel
     assert lib.pb_fista_which_kernel(300, 30, 12500, 0, 0, 6) == 2       # config 3's shard on 8 GPUs
     assert lib.pb_fista_which_kernel(300, 30, 8192, 1, 2, 6) == 1        # stop rules: single-row kernel
     assert lib.pb_fista_which_kernel(300, 30, 3, 1, 2, 6) == 3           # ... or one problem per wave
