@@ -96,8 +96,21 @@ def deconv(y, t_r, hrf, lbda=None, early_stopping=True, tol=1.0e-6,  # noqa
         Y, hrf, lbda, step, int(nb_iter), want_J=True,
         stop="window" if early_stopping else None, tol=tol, wind=wind)
     X, Z = solver.fista_outputs(W, hrf)
+    n_max = max(int(n_done.max()), 1)
+    if one_d.on_device:
+        # CUDA in -> CUDA out: the cost trace is normalised on the device and stays there
+        # (a (V, n_iter) trace of a large batch is hundreds of MB: no PCIe round trip)
+        Jd = J[:, :n_max].to(torch.float64)
+        Jd = Jd / (Jd[:, :1] + 1.0e-30)
+        if verbose > 0:
+            last = Jd.gather(1, (n_done.long() - 1).clamp(min=0)[:, None])
+            print("deconv: {0} voxel(s), {1} iteration(s), final normalised cost "
+                  "{2:.6f}".format(Y.shape[0], n_max, float(last.nanmean())))
+        if one_d:
+            return X[0], Z[0], W[0], Jd[0, :int(n_done[0])], None, None
+        return X, Z, W, Jd, None, None
     n_done = n_done.cpu().numpy()
-    J = J.cpu().numpy().astype(np.float64)[:, :max(int(n_done.max()), 1)]
+    J = J.cpu().numpy().astype(np.float64)[:, :n_max]
     J = J / (J[:, :1] + 1.0e-30)
     if verbose > 0:
         print("deconv: {0} voxel(s), {1} iteration(s), final normalised cost "

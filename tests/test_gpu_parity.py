@@ -315,9 +315,10 @@ def test_device_tensors_in_device_tensors_out(pa, golden):
     np.random.seed(0)
     X, Z, W, J, _, _ = pybold_amd.deconv(dev32(Y), 1.0, hrf, lbda=1.0, nb_iter=10,
                                          early_stopping=False)
-    assert all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float64 for t in (X, Z, W))
+    assert all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float64 for t in (X, Z, W, J))
     for s in range(4):
         assert rel_rows(W[s].cpu().numpy(), g["dz_s%d_l1_n10" % s]) < EPS
+        np.testing.assert_allclose(J[s].cpu().numpy(), g["J_s%d_l1_n10" % s], rtol=2e-5)
     np.random.seed(0)
     x, z, w, J, _, _ = pybold_amd.deconv(dev32(Y[2]), 1.0, hrf, lbda=1.0, nb_iter=10,
                                          early_stopping=False)
