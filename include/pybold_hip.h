@@ -16,8 +16,12 @@
  *   - matrices are row-major, one row per problem ("voxel"), leading dimension
  *     ld* counted in ELEMENTS;
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
- *     all work is enqueued asynchronously on it, nothing is allocated, no
- *     synchronisation is performed (graph-capture safe);
+ *     all work is enqueued asynchronously in its order, no device memory is allocated, no
+ *     host synchronisation is performed (graph-capture safe).  One exception to "on it":
+ *     pb_fista_solve may run the remainder of a plain solve on an internal side stream
+ *     (one per device, created on first use) that forks from and joins back into `stream`
+ *     through events, so the caller sees ordinary stream order; not while `stream` is being
+ *     captured, and never with PB_FLAG_ONE_STREAM;
  *   - return value 0 = success; a negative value = error, text available from
  *     pb_last_error() (thread-local).  No entry point ever falls back to a
  *     CPU computation.
@@ -47,6 +51,7 @@ extern "C" {
 #define PB_FLAG_FORCE_WIDE 16u    /* always one problem per wave (fista_fast_kernel, 64 lanes) */
 #define PB_FLAG_DIRECT_FIR 64u    /* pair form: direct K-tap FIRs (fista_pair_kernel) instead of the
                                      2-parallel fast FIRs (fista_pair_ffa_kernel) */
+#define PB_FLAG_ONE_STREAM 128u    /* never use the internal side stream (see pb_fista_solve) */
 #define PB_FLAG_ONE_LAUNCH 32u    /* never split a plain solve into a full-rounds launch and a
                                      remainder launch (see pb_fista_solve) */
 
@@ -85,7 +90,8 @@ int pb_fista_plan(int N, int K, int P, int stop_mode, int wind, int* n_main, int
  * for P independent problems, state resident on chip, in ONE launch -- or, for a plain
  * solve (no stop rule) whose problem count does not fill the machine evenly, in TWO launches
  * on the same stream: the whole rounds of waves on the densest kernel form and the
- * remainder on whichever form finishes it first (PB_FLAG_ONE_LAUNCH turns that off):
+ * remainder on whichever form finishes it first (PB_FLAG_ONE_LAUNCH turns that off); a
+ * remainder that fits beside half a round of waves runs concurrently on the side stream:
  *
  *   u = w - step * H^T (H w - y)      H = toeplitz(taps) . cumsum
  *   p = soft(u, lbda_p * step)        pybold/linear.py:73-113, convolution.py:105-132

@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cmath>
 #include <cstring>
+#include <map>
+#include <mutex>
 
 #include "fista_fast.h"
 #include "generic.h"
@@ -239,6 +241,87 @@ Plan plan_plain(int P, bool has_pair, bool has_wide, bool one_launch) {
   return best;
 }
 
+// ---- a side stream per device for remainders that fit BESIDE the main launch -----------
+// When a plain solve has between one and two half rounds of pair waves (8 192 < P < 16 384
+// problems on MI355X), a single launch leaves some SIMDs with two 8-problem waves and the
+// others with one.  Measured (tools/conc_probe.py): half a round of pair waves (one per SIMD)
+// on the caller's stream with the remainder on a second stream -- single-row waves (4
+// problems) or one-problem waves -- co-schedules one wave of each per SIMD: 12 288 problems in
+// 0.80 of a round instead of 0.92-1.0, 10 000 in 0.74.  The side stream forks from and joins
+// back into the caller's stream with events (no host synchronisation); it is created on first
+// use, one per device.  Not used while the caller's stream is being captured into a graph, nor
+// for remainders of multi-round launches (measured slower: it unbalances the last round).
+struct SideStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  bool ok = false;
+};
+std::mutex g_side_mutex;
+
+SideStream* side_stream_locked() {      // call with g_side_mutex held
+  static std::map<int, SideStream> per_dev;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  SideStream& ss = per_dev[dev];
+  if (!ss.ok && ss.stream == nullptr) {
+    if (hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking) == hipSuccess &&
+        hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess)
+      ss.ok = true;
+    else
+      (void)hipGetLastError();
+  }
+  return ss.ok ? &ss : nullptr;
+}
+
+bool stream_is_capturing(hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) {
+    (void)hipGetLastError();
+    return true;                         // unknown: stay on one stream
+  }
+  return cs != hipStreamCaptureStatusNone;
+}
+
+struct Piece {
+  int form, p0, p1;
+  bool side;                             // runs on the side stream, beside the first piece
+};
+
+// Plan of a plain solve as up to three pieces.  Sequential part: plan_plain.  If what remains
+// after the whole rounds lies between one and two half rounds of pair waves, it becomes half a
+// round of pair waves with the rest beside it.
+int plan_pieces(int P, bool has_pair, bool has_wide, bool one_launch, bool one_stream, Piece* out) {
+  int n = 0;
+  const int half = (int)wave_slots() * 4;          // problems in half a round of pair waves
+  const int round = 2 * half;
+  if (has_pair && !one_launch && !one_stream && P > half && P < round) {
+    const int rest = P - half;                     // < half
+    const int quarter = half / 2;                  // single-row waves: one per SIMD
+    const int wide_round = (int)wave_slots() / 2;  // one-problem waves: one per SIMD
+    if (has_wide && rest < 2 * wide_round) {       // at most two one-problem waves per SIMD
+      out[n++] = Piece{FORM_PAIR, 0, half, false};
+      out[n++] = Piece{FORM_WIDE, half, P, true};
+      return n;
+    }
+    if (rest <= quarter) {                         // at most one single-row wave per SIMD
+      out[n++] = Piece{FORM_PAIR, 0, half, false};
+      out[n++] = Piece{FORM_FAST1, half, P, true};
+      return n;
+    }
+    if (has_wide && rest - quarter <= wide_round / 2) {
+      out[n++] = Piece{FORM_PAIR, 0, half, false};
+      out[n++] = Piece{FORM_FAST1, half, half + quarter, true};
+      out[n++] = Piece{FORM_WIDE, half + quarter, P, true};
+      return n;
+    }
+  }
+  const Plan pl = plan_plain(P, has_pair, has_wide, one_launch);
+  if (pl.n_main > 0) out[n++] = Piece{pl.main_form, 0, pl.n_main, false};
+  out[n++] = Piece{pl.tail_form, pl.n_main, P, false};
+  return n;
+}
+
 template <int KIND>
 int launch_op(const double* x, int64_t ldx, double* out, int64_t ldo, int V, int n_src, int n_dst,
               const double* taps, int K, void* stream, const char* name) {
@@ -381,9 +464,10 @@ int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mod
     if (we && stop_mode == PB_STOP_WINDOW && (wind != 6 || we->S > 20)) we = nullptr;
     return we ? 3 : 0;
   }
-  const Plan pl = plan_plain(P, fe->fn_pair != nullptr && stop_mode == PB_STOP_NONE,
-                             pick_wide_small(N, K) != nullptr, false);
-  return pl.n_main > 0 ? pl.main_form : pl.tail_form;   // the form that carries most problems
+  Piece pc[3];
+  plan_pieces(P, fe->fn_pair != nullptr && stop_mode == PB_STOP_NONE, pick_wide_small(N, K) != nullptr,
+              false, false, pc);
+  return pc[0].form;                                    // the form that carries most problems
 }
 
 int pb_fista_plan(int N, int K, int P, int stop_mode, int wind, int* n_main, int* main_form,
@@ -393,9 +477,11 @@ int pb_fista_plan(int N, int K, int P, int stop_mode, int wind, int* n_main, int
     const FastEntry* fe = pick_fast(N, K);
     if (fe && stop_mode == PB_STOP_WINDOW && (wind != 6 || fe->S > 20)) fe = nullptr;
     if (fe) {
-      const Plan pl = plan_plain(P, fe->fn_pair != nullptr && stop_mode == PB_STOP_NONE,
-                                 pick_wide_small(N, K) != nullptr, false);
-      nm = pl.n_main; mf = pl.n_main > 0 ? pl.main_form : 0; tf = pl.tail_form;
+      Piece pc[3];
+      const int npc = plan_pieces(P, fe->fn_pair != nullptr && stop_mode == PB_STOP_NONE,
+                                  pick_wide_small(N, K) != nullptr, false, false, pc);
+      if (npc > 1) { nm = pc[0].p1; mf = pc[0].form; tf = pc[1].form; }
+      else { nm = 0; mf = 0; tf = pc[0].form; }
     } else {
       const WideEntry* we = pick_wide(N, K);
       if (we && stop_mode == PB_STOP_WINDOW && (wind != 6 || we->S > 20)) we = nullptr;
@@ -469,15 +555,44 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
       return run(FORM_PAIR, 0, P);
     }
     // whole rounds on the densest form, the remainder on the cheapest (the pair form has no
-    // stop rules; the one-problem-per-wave form has them all)
+    // stop rules; the one-problem-per-wave form has them all); a remainder that fits beside
+    // half a round of pair waves runs on the side stream
     const bool pair_ok = fe->fn_pair != nullptr && stop_mode == PB_STOP_NONE;
-    const Plan pl = plan_plain(P, pair_ok, pick_wide_small(N, K) != nullptr,
-                               (flags & PB_FLAG_ONE_LAUNCH) != 0);
-    if (pl.n_main > 0) {
-      const int rc = run(pl.main_form, 0, pl.n_main);
-      if (rc != PB_OK) return rc;
+    Piece pc[3];
+    const bool one_stream = (flags & PB_FLAG_ONE_STREAM) != 0 || stream_is_capturing((hipStream_t)stream);
+    const int npc = plan_pieces(P, pair_ok, pick_wide_small(N, K) != nullptr,
+                                (flags & PB_FLAG_ONE_LAUNCH) != 0, one_stream, pc);
+    bool any_side = false;
+    for (int i = 0; i < npc; ++i) any_side |= pc[i].side;
+    if (!any_side) {
+      for (int i = 0; i < npc; ++i) {
+        const int rc = run(pc[i].form, pc[i].p0, pc[i].p1);
+        if (rc != PB_OK) return rc;
+      }
+      return PB_OK;
     }
-    return run(pl.tail_form, pl.n_main, P);
+    std::lock_guard<std::mutex> lock(g_side_mutex);
+    SideStream* ss = side_stream_locked();
+    if (!ss) {                                   // no side stream: same pieces, one after the other
+      for (int i = 0; i < npc; ++i) {
+        const int rc = run(pc[i].form, pc[i].p0, pc[i].p1);
+        if (rc != PB_OK) return rc;
+      }
+      return PB_OK;
+    }
+    hipStream_t user = (hipStream_t)stream;
+    if (hipEventRecord(ss->fork, user) != hipSuccess || hipStreamWaitEvent(ss->stream, ss->fork, 0) != hipSuccess)
+      return fail(PB_ERR_HIP, "pb_fista_solve: fork to the side stream failed");
+    int rc_all = PB_OK;
+    for (int i = 0; i < npc && rc_all == PB_OK; ++i) {
+      stream = pc[i].side ? (void*)ss->stream : (void*)user;      // `run` launches on `stream`
+      rc_all = run(pc[i].form, pc[i].p0, pc[i].p1);
+    }
+    stream = (void*)user;
+    // join even after an error so that the caller's stream never runs ahead of the side stream
+    if (hipEventRecord(ss->join, ss->stream) != hipSuccess || hipStreamWaitEvent(user, ss->join, 0) != hipSuccess)
+      return fail(PB_ERR_HIP, "pb_fista_solve: join of the side stream failed");
+    return rc_all;
   }
   // long series: one problem per wave (window rule: wind = 6 and S <= 20, as above)
   if (!(flags & PB_FLAG_FORCE_GENERIC)) {

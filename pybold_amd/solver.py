@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (PB_FLAG_DIRECT_FIR, PB_FLAG_FORCE_FAST, PB_FLAG_FORCE_GENERIC, PB_FLAG_FORCE_PAIR, PB_FLAG_FORCE_WIDE,
+from ._lib import (PB_FLAG_DIRECT_FIR, PB_FLAG_ONE_STREAM, PB_FLAG_FORCE_FAST, PB_FLAG_FORCE_GENERIC, PB_FLAG_FORCE_PAIR, PB_FLAG_FORCE_WIDE,
                    PB_FLAG_NO_PAIR, PB_FLAG_ONE_LAUNCH, PB_STOP_LOOPS, PB_STOP_NONE, PB_STOP_WINDOW)
 
 _STOP = {None: PB_STOP_NONE, "none": PB_STOP_NONE, "loops": PB_STOP_LOOPS,
@@ -17,14 +17,15 @@ _STOP = {None: PB_STOP_NONE, "none": PB_STOP_NONE, "loops": PB_STOP_LOOPS,
 # "fast" = a register-resident kernel (library picks single-row or pair form);
 # "fast1" / "fast2" pin the single-row / two-problems-per-row form
 # "wide" pins the one-problem-per-wave form; "one" = library dispatch restricted to a single launch;
-# "fast2d" / "direct": pair form with direct FIRs instead of the 2-parallel fast FIRs
+# "fast2d" / "direct": pair form with direct FIRs instead of the 2-parallel fast FIRs;
+# "seq": library dispatch without the internal side stream
 _FORCE = {None: 0, "generic": PB_FLAG_FORCE_GENERIC, "fast": PB_FLAG_FORCE_FAST,
           "fast1": PB_FLAG_FORCE_FAST | PB_FLAG_NO_PAIR | PB_FLAG_ONE_LAUNCH,
           "fast2": PB_FLAG_FORCE_FAST | PB_FLAG_FORCE_PAIR | PB_FLAG_ONE_LAUNCH,
           "fast2d": PB_FLAG_FORCE_FAST | PB_FLAG_FORCE_PAIR | PB_FLAG_ONE_LAUNCH | PB_FLAG_DIRECT_FIR,
           "direct": PB_FLAG_DIRECT_FIR,
           "wide": PB_FLAG_FORCE_FAST | PB_FLAG_FORCE_WIDE | PB_FLAG_ONE_LAUNCH,
-          "one": PB_FLAG_ONE_LAUNCH}
+          "one": PB_FLAG_ONE_LAUNCH, "seq": PB_FLAG_ONE_STREAM}
 
 
 def device(dev=None):

@@ -407,3 +407,56 @@ def test_shared_taps_pair_kernel_at_scale(solver, golden):
     for force in ("fast2", "fast1"):
         Wf, _ = solver.fista_solve_pp(Yd, dev64(h), dev64([step]), 1.7, 60, force=force)
         assert rel_rows(Wf.cpu().numpy()[idx], Wo) < 1e-5, force
+
+
+def test_side_stream_remainder(solver, golden):
+    """8 192 < P < 16 384 problems: half a round of pair waves on the caller's stream with the
+    remainder beside it on the library's side stream (fork/join by events).  Same kernels on
+    the same problems as the one-stream plan, so bitwise equal to it; results are complete in
+    the caller's stream order (consumed at once, no synchronisation); repeated calls; a
+    non-default caller stream; graph capture falls back to one stream."""
+    from oracle import c_oracle
+    g = golden("case1")
+    hrf, lip = g["hrf"], float(g["lipschitz"])
+    step = 1.0 / lip
+    rng = np.random.RandomState(3)
+    for P in (8200, 10000, 12288, 12500, 12800):
+        Y = torch.from_numpy(rng.randn(P, 300).astype(np.float32)).cuda()
+        n_main, main_k, tail_k = solver.launch_plan(300, 30, P)
+        assert n_main == 8192 and "two problems per row" in main_k
+        W, _, _ = solver.fista_solve(Y, hrf, 1.0, step, 40)
+        s1 = W.abs().sum()                       # consumer on the caller's stream, right away
+        Wq, _, _ = solver.fista_solve(Y, hrf, 1.0, step, 40, force="seq")
+        assert torch.equal(W, Wq), P
+        assert float(s1) == float(Wq.abs().sum())
+        idx = np.concatenate([rng.choice(8192, 8, replace=False), 8192 + rng.choice(P - 8192, 8, replace=False)])
+        Wo, _, _ = c_oracle.fista_batch(Y.cpu().numpy()[idx].astype(np.float64), hrf, 1.0, step, 40, threads=4)
+        assert rel_rows(W.cpu().numpy()[idx], Wo) < 1e-5
+    # back-to-back calls on a non-default stream, each result consumed in stream order
+    Y = torch.from_numpy(rng.randn(10000, 300).astype(np.float32)).cuda()
+    ref, _, _ = solver.fista_solve(Y, hrf, 1.0, step, 25, force="seq")
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    sums = []
+    with torch.cuda.stream(st):
+        for _ in range(5):
+            W, _, _ = solver.fista_solve(Y, hrf, 1.0, step, 25)
+            sums.append((W - ref).abs().max())
+    st.synchronize()
+    assert all(float(s) == 0.0 for s in sums)
+    # graph capture: no cross-stream work is captured, the replay equals the eager result
+    plan = solver.FistaPlan(Y, hrf, 1.0, step, 25, force=None)
+    plan.run()
+    torch.cuda.synchronize()
+    eager = plan.W.clone()
+    cs = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(cs):
+        plan.run()
+        cs.synchronize()
+        with torch.cuda.graph(graph, stream=cs):
+            plan.run()
+    plan.W.fill_(3.0)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(plan.W, eager) and torch.equal(eager, ref)
