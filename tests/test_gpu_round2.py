@@ -411,8 +411,8 @@ def test_shared_taps_pair_kernel_at_scale(solver, golden):
 
 def test_side_stream_remainder(solver, golden):
     """8 192 < P < 16 384 problems: half a round of pair waves on the caller's stream with the
-    remainder beside it on the library's side stream (fork/join by events).  Same kernels on
-    the same problems as the one-stream plan, so bitwise equal to it; results are complete in
+    remainder beside it on the library's side stream (fork/join by events).  Where the
+    one-stream plan uses the same pieces the results are bitwise equal; results are complete in
     the caller's stream order (consumed at once, no synchronisation); repeated calls; a
     non-default caller stream; graph capture falls back to one stream."""
     from oracle import c_oracle
@@ -427,8 +427,13 @@ def test_side_stream_remainder(solver, golden):
         W, _, _ = solver.fista_solve(Y, hrf, 1.0, step, 40)
         s1 = W.abs().sum()                       # consumer on the caller's stream, right away
         Wq, _, _ = solver.fista_solve(Y, hrf, 1.0, step, 40, force="seq")
-        assert torch.equal(W, Wq), P
-        assert float(s1) == float(Wq.abs().sum())
+        # (the one-stream plan uses the same pieces up to 12 288 problems, other kernels beyond)
+        if P <= 12288:
+            assert torch.equal(W, Wq), P
+            assert float(s1) == float(Wq.abs().sum())
+        else:
+            assert float(((W - Wq).norm(dim=1) / Wq.norm(dim=1)).max()) < 1e-6
+            assert float(s1) == float(W.abs().sum())
         idx = np.concatenate([rng.choice(8192, 8, replace=False), 8192 + rng.choice(P - 8192, 8, replace=False)])
         Wo, _, _ = c_oracle.fista_batch(Y.cpu().numpy()[idx].astype(np.float64), hrf, 1.0, step, 40, threads=4)
         assert rel_rows(W.cpu().numpy()[idx], Wo) < 1e-5
