@@ -1,0 +1,29 @@
+"""Why does bench.py not see the side-stream gain?  Vary data and step."""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+from pybold_amd import solver, data
+from pybold_amd.hrf_model import spm_hrf
+from pybold_amd.linear import ConvAndLinear, DiscretInteg
+from pybold_amd.utils import spectral_radius_est
+hrf = spm_hrf(1.0, t_r=1.0, dur=30.)[0]
+P, N = 12500, 300
+dev = torch.device("cuda:0")
+np.random.seed(0)
+H = ConvAndLinear(DiscretInteg(), hrf, dim_in=N, dim_out=N)
+step_b = 1.0 / (0.9 * spectral_radius_est(H, (N,)))
+step_c = 1.0 / 723876.27
+Yr = torch.randn(P, N, device="cuda", dtype=torch.float32)
+Yb, _, _ = data.gen_rnd_bloc_bold_batch(P, dur=N / 60.0, tr=1.0, hrf=hrf, nb_events=5, avg_dur=12.0, std_dur=1.0, snr=1.0, seed=1000, device=dev)
+print("Yb", Yb.dtype, Yb.shape, Yb.stride(), "step_b", step_b, "step_c", step_c)
+for name, Y, step in (("randn/const", Yr, step_c), ("bold/const", Yb, step_c), ("randn/est", Yr, step_b), ("bold/est", Yb, step_b)):
+    for force in ("seq", None):
+        plan = solver.FistaPlan(Y, hrf, 1.0, step, 500, force=force)
+        for _ in range(3): plan.run()
+        torch.cuda.synchronize()
+        n = 20
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for k in range(n):
+            plan.run()
+        torch.cuda.synchronize(); b = (time.perf_counter() - t0) / n * 1e3
+        print("%-16s %-5s %.3f ms  nnz frac %.3f" % (name, force or "auto", b, float((plan.W != 0).double().mean())), flush=True)
