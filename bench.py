@@ -71,6 +71,11 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="target time of each cpu_baseline sample (0 = skip)")
     ap.add_argument("--master-port", type=int, default=0, help="self-launched ranks only")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="development aid: all N ranks share GPU 0 and synchronise over gloo (RCCL "
+                         "refuses two ranks on one device); rehearses launch, sharding, barrier and "
+                         "MAX-reduction of the N > 1 path on a one-GPU box. The line is marked "
+                         "\"rehearsal\": true and is not a measurement")
     return ap.parse_args()
 
 
@@ -90,7 +95,7 @@ def self_launch(args):
     `torch.cuda.device_count()` does not initialise it."""
     import torch
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and not (args.rehearse_on_one_gpu and have >= 1):
         sys.stderr.write("bench.py --gpus %d needs %d GPUs; this machine shows %d\n"
                          % (args.gpus, args.gpus, have))
         return 2
@@ -144,6 +149,8 @@ def run(args):
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     if local_rank >= torch.cuda.device_count():
         raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
@@ -153,7 +160,11 @@ def run(args):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    red_dev = torch.device("cpu") if args.rehearse_on_one_gpu else dev
 
     from pybold_amd import data, distributed, solver
     from pybold_amd.hrf_model import spm_hrf
@@ -212,7 +223,7 @@ def run(args):
         barrier()
         el = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            t = torch.tensor([el], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el, float(np.mean([a.elapsed_time(b) for a, b in ev]))
@@ -262,6 +273,7 @@ def run(args):
         "metric": "voxel-iterations/sec", "value": value, "unit": "voxel-iterations/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "untimed_spin_s": args.spin_seconds,
+        **({"rehearsal": True} if args.rehearse_on_one_gpu else {}),
         "ms_per_step": ms_step,
         "wall_clock_to_eps_ms": ms_step,       # one full solve meeting eps <= 1e-5, y resident in HBM
         "higher_is_better": True,
