@@ -197,7 +197,7 @@ class FistaPlan:
     graph capture: ``run()`` enqueues a memset of the iterate and ONE
     ``pb_fista_solve`` launch on the current stream and allocates nothing."""
 
-    def __init__(self, Y, hrf, lbda, step, n_iter, y_rep=1, force="fast"):
+    def __init__(self, Y, hrf, lbda, step, n_iter, y_rep=1, force="fast", W=None):
         self.lib = _lib.load()
         self.Y = _rows(Y, torch.float32, "Y")
         self.dev = self.Y.device
@@ -206,7 +206,11 @@ class FistaPlan:
         self.y_rep = int(y_rep)
         self.taps = _as_taps(hrf)
         self.taps_dev = torch.from_numpy(self.taps).to(self.dev)
-        self.W = torch.zeros((self.P, self.N), dtype=torch.float64, device=self.dev)
+        if W is None:
+            W = torch.zeros((self.P, self.N), dtype=torch.float64, device=self.dev)
+        elif tuple(W.shape) != (self.P, self.N) or W.stride(1) != 1:
+            raise ValueError("W must be (%d, %d) with unit stride along time" % (self.P, self.N))
+        self.W = _rows(W, torch.float64, "W")
         self.n_done = torch.empty((self.P,), dtype=torch.int32, device=self.dev)
         self.lbda_dev = None
         self.lbda = 0.0
@@ -234,6 +238,96 @@ class FistaPlan:
         self.W.zero_()
         self.launch()
         return self.W
+
+
+def round_size(n_scans, n_taps, dev=None):
+    """Problems in one full round of waves of the densest plain kernel form for this shape
+    (two waves on every SIMD of the device), or None when only the LDS kernel applies."""
+    n_main, main, tail = launch_plan(n_scans, n_taps, 1 << 22)
+    per_wave = {KERNEL_NAMES[2]: 8, KERNEL_NAMES[1]: 4, KERNEL_NAMES[3]: 1}.get(main if n_main else tail)
+    if per_wave is None:
+        return None
+    return torch.cuda.get_device_properties(device(dev)).multi_processor_count * 4 * 2 * per_wave
+
+
+class HostPipeline:
+    """Host buffers in, (optionally) host buffers out: ``y`` (float32, pinned host memory)
+    -> ``diff_z``, in chunks of ``chunk`` voxels on separate streams so that the H2D copy of
+    chunk c+1 and the D2H copy of chunk c-1 overlap the solve of chunk c.
+
+    ``out_dtype=None``: the result stays in HBM (float64 ``(V, N)``, ``self.W``);
+    ``torch.float32`` / ``torch.float64``: it is copied back into pinned host memory
+    (``self.out``) through two device slots of ``chunk`` voxels.  ``chunk`` defaults to one
+    full round of waves (:func:`round_size`: 16 384 voxels at N <= 304), which leaves the
+    solver's own cost unchanged but for the launch boundaries (measured at config-3 size:
+    17.25 ms in 7 chunks against 16.76 ms in one call) and one chunk copy exposed at each end.
+    Everything is allocated here; ``run`` allocates nothing."""
+
+    def __init__(self, n_voxels, n_scans, hrf, lbda, step, n_iter, chunk=None, out_dtype=torch.float32,
+                 dev=None, force=None):
+        self.dev = device(dev)
+        self.V, self.N = int(n_voxels), int(n_scans)
+        if chunk is None:
+            chunk = round_size(self.N, len(_as_taps(hrf)), self.dev) or 8192
+        self.chunk = max(1, min(int(chunk), max(self.V, 1)))
+        self.out_dtype = out_dtype
+        self.bounds = [(lo, min(lo + self.chunk, self.V)) for lo in range(0, self.V, self.chunk)]
+        self.s_in, self.s_cmp, self.s_out = (torch.cuda.Stream(self.dev) for _ in range(3))
+        lam = None if (np.ndim(lbda) == 0 and not torch.is_tensor(lbda)) else \
+            torch.as_tensor(lbda, dtype=torch.float64).ravel()
+        self.Yd = [torch.empty((self.chunk, self.N), dtype=torch.float32, device=self.dev) for _ in range(2)]
+        if out_dtype is None:
+            self.W = torch.empty((self.V, self.N), dtype=torch.float64, device=self.dev)
+            self.out = None
+        else:
+            self.W = None
+            self.Wd = [torch.empty((self.chunk, self.N), dtype=torch.float64, device=self.dev) for _ in range(2)]
+            self.Od = self.Wd if out_dtype == torch.float64 else [
+                torch.empty((self.chunk, self.N), dtype=out_dtype, device=self.dev) for _ in range(2)]
+            self.out = torch.empty((self.V, self.N), dtype=out_dtype).pin_memory()
+        self.plans = []
+        for c, (lo, hi) in enumerate(self.bounds):
+            b = c % 2
+            self.plans.append(FistaPlan(self.Yd[b][:hi - lo], hrf, lbda if lam is None else lam[lo:hi], step, n_iter,
+                                        force=force, W=self.W[lo:hi] if self.W is not None else self.Wd[b][:hi - lo]))
+        self.ev_in = [torch.cuda.Event() for _ in range(2)]
+        self.ev_cmp = [torch.cuda.Event() for _ in range(2)]
+        self.ev_out = [torch.cuda.Event() for _ in range(2)]
+
+    def run(self, Yh, sync=True):
+        """``Yh``: float32 host tensor ``(V, N)`` (pinned, or the copies are synchronous).
+        Returns ``self.out`` (pinned host) or ``self.W`` (HBM); with ``sync=False`` the work is
+        only enqueued and ordered before later work on the current stream."""
+        if tuple(Yh.shape) != (self.V, self.N) or Yh.dtype != torch.float32 or Yh.is_cuda:
+            raise ValueError("Yh must be a float32 host tensor of shape (%d, %d)" % (self.V, self.N))
+        cur = torch.cuda.current_stream(self.dev)
+        for s in (self.s_in, self.s_cmp, self.s_out):
+            s.wait_stream(cur)
+        for c, (lo, hi) in enumerate(self.bounds):
+            b, n = c % 2, hi - lo
+            with torch.cuda.stream(self.s_in):
+                if c >= 2:
+                    self.s_in.wait_event(self.ev_cmp[b])        # chunk c-2 no longer reads this slot
+                self.Yd[b][:n].copy_(Yh[lo:hi], non_blocking=True)
+                self.ev_in[b].record(self.s_in)
+            with torch.cuda.stream(self.s_cmp):
+                self.s_cmp.wait_event(self.ev_in[b])
+                if c >= 2 and self.out is not None:
+                    self.s_cmp.wait_event(self.ev_out[b])       # chunk c-2 has left this slot
+                self.plans[c].run()
+                if self.out is not None and self.Od is not self.Wd:
+                    self.Od[b][:n].copy_(self.Wd[b][:n])
+                self.ev_cmp[b].record(self.s_cmp)
+            if self.out is not None:
+                with torch.cuda.stream(self.s_out):
+                    self.s_out.wait_event(self.ev_cmp[b])
+                    self.out[lo:hi].copy_(self.Od[b][:n], non_blocking=True)
+                    self.ev_out[b].record(self.s_out)
+        for s in (self.s_in, self.s_cmp, self.s_out):
+            cur.wait_stream(s)
+        if sync:
+            cur.synchronize()
+        return self.out if self.out is not None else self.W
 
 
 def fista_outputs(W, hrf):
