@@ -409,6 +409,11 @@ def test_shared_taps_pair_kernel_at_scale(solver, golden):
         assert rel_rows(Wf.cpu().numpy()[idx], Wo) < 1e-5, force
 
 
+def orc_fista_one(y, hrf, lbda, step, n_iter, w0):
+    from oracle import pybold_oracle as orc
+    return orc.fista_batch(y[None], hrf, lbda, step, n_iter, W0=w0[None])[0]
+
+
 def test_side_stream_remainder(solver, golden):
     """8 192 < P < 16 384 problems: half a round of pair waves on the caller's stream with the
     remainder beside it on the library's side stream (fork/join by events).  Where the
@@ -437,6 +442,18 @@ def test_side_stream_remainder(solver, golden):
         idx = np.concatenate([rng.choice(8192, 8, replace=False), 8192 + rng.choice(P - 8192, 8, replace=False)])
         Wo, _, _ = c_oracle.fista_batch(Y.cpu().numpy()[idx].astype(np.float64), hrf, 1.0, step, 40, threads=4)
         assert rel_rows(W.cpu().numpy()[idx], Wo) < 1e-5
+    # shared y (y_rep), per-problem lambda and a warm start across the split: 600 voxels x 20
+    # lambdas = 12 000 problems, the pieces start at problem offsets inside a voxel's group
+    Yv = torch.from_numpy(rng.randn(600, 300).astype(np.float32)).cuda()
+    lam = np.tile(np.logspace(-2, 0, 20), 600)
+    W0 = torch.from_numpy(0.01 * rng.randn(12000, 300)).cuda()
+    W, _, n_done = solver.fista_solve(Yv, hrf, lam, step, 30, W0=W0, y_rep=20)
+    Wq, _, _ = solver.fista_solve(Yv, hrf, lam, step, 30, W0=W0, y_rep=20, force="seq")
+    assert torch.equal(W, Wq) and int(n_done.min()) == 30
+    idx = np.r_[0, 8191, 8192, 8193, 11999, rng.choice(12000, 8, replace=False)]
+    Wo = np.stack([orc_fista_one(Yv[i // 20].cpu().numpy().astype(np.float64), hrf, lam[i], step, 30,
+                                 W0[i].cpu().numpy()) for i in idx])
+    assert rel_rows(W.cpu().numpy()[idx], Wo) < 1e-5
     # back-to-back calls on a non-default stream, each result consumed in stream order
     Y = torch.from_numpy(rng.randn(10000, 300).astype(np.float32)).cuda()
     ref, _, _ = solver.fista_solve(Y, hrf, 1.0, step, 25, force="seq")
