@@ -285,40 +285,47 @@ bool stream_is_capturing(hipStream_t st) {
 
 struct Piece {
   int form, p0, p1;
-  bool side;                             // runs on the side stream, beside the first piece
+  bool side;                             // runs on the side stream ...
+  bool group;                            // ... as part of the concurrent group that closes the plan
 };
 
-// Plan of a plain solve as up to three pieces.  Sequential part: plan_plain.  If what remains
-// after the whole rounds lies between one and two half rounds of pair waves, it becomes half a
-// round of pair waves with the rest beside it.
+// Plan of a plain solve as up to four pieces.  Sequential part: plan_plain.  If what remains
+// after the whole rounds of pair waves lies between one and two half rounds, the whole rounds
+// go first (one launch) and the rest becomes a concurrent group: half a round of pair waves
+// with the remainder beside it on the side stream (forked after the whole rounds).
 int plan_pieces(int P, bool has_pair, bool has_wide, bool one_launch, bool one_stream, Piece* out) {
   int n = 0;
   const int half = (int)wave_slots() * 4;          // problems in half a round of pair waves
   const int round = 2 * half;
-  if (has_pair && !one_launch && !one_stream && P > half && P < round) {
-    const int rest = P - half;                     // < half
+  const int whole = (P / round) * round;
+  const int R = P - whole;                         // what the whole rounds leave
+  if (has_pair && !one_launch && !one_stream && R > half) {
+    const int rest = R - half;                     // < half
     const int quarter = half / 2;                  // single-row waves: one per SIMD
     const int wide_round = (int)wave_slots() / 2;  // one-problem waves: one per SIMD
+    const int g0 = whole, g1 = whole + half;
+    int m = 0;
+    Piece grp[3];
     if (has_wide && rest < 2 * wide_round) {       // at most two one-problem waves per SIMD
-      out[n++] = Piece{FORM_PAIR, 0, half, false};
-      out[n++] = Piece{FORM_WIDE, half, P, true};
-      return n;
+      grp[m++] = Piece{FORM_PAIR, g0, g1, false, true};
+      grp[m++] = Piece{FORM_WIDE, g1, P, true, true};
+    } else if (rest <= quarter) {                  // at most one single-row wave per SIMD
+      grp[m++] = Piece{FORM_PAIR, g0, g1, false, true};
+      grp[m++] = Piece{FORM_FAST1, g1, P, true, true};
+    } else if (has_wide && rest - quarter <= wide_round / 2) {
+      grp[m++] = Piece{FORM_PAIR, g0, g1, false, true};
+      grp[m++] = Piece{FORM_FAST1, g1, g1 + quarter, true, true};
+      grp[m++] = Piece{FORM_WIDE, g1 + quarter, P, true, true};
     }
-    if (rest <= quarter) {                         // at most one single-row wave per SIMD
-      out[n++] = Piece{FORM_PAIR, 0, half, false};
-      out[n++] = Piece{FORM_FAST1, half, P, true};
-      return n;
-    }
-    if (has_wide && rest - quarter <= wide_round / 2) {
-      out[n++] = Piece{FORM_PAIR, 0, half, false};
-      out[n++] = Piece{FORM_FAST1, half, half + quarter, true};
-      out[n++] = Piece{FORM_WIDE, half + quarter, P, true};
+    if (m > 0) {
+      if (whole > 0) out[n++] = Piece{FORM_PAIR, 0, whole, false, false};
+      for (int i = 0; i < m; ++i) out[n++] = grp[i];
       return n;
     }
   }
   const Plan pl = plan_plain(P, has_pair, has_wide, one_launch);
-  if (pl.n_main > 0) out[n++] = Piece{pl.main_form, 0, pl.n_main, false};
-  out[n++] = Piece{pl.tail_form, pl.n_main, P, false};
+  if (pl.n_main > 0) out[n++] = Piece{pl.main_form, 0, pl.n_main, false, false};
+  out[n++] = Piece{pl.tail_form, pl.n_main, P, false, false};
   return n;
 }
 
@@ -464,7 +471,7 @@ int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mod
     if (we && stop_mode == PB_STOP_WINDOW && (wind != 6 || we->S > 20)) we = nullptr;
     return we ? 3 : 0;
   }
-  Piece pc[3];
+  Piece pc[4];
   plan_pieces(P, fe->fn_pair != nullptr && stop_mode == PB_STOP_NONE, pick_wide_small(N, K) != nullptr,
               false, false, pc);
   return pc[0].form;                                    // the form that carries most problems
@@ -477,10 +484,13 @@ int pb_fista_plan(int N, int K, int P, int stop_mode, int wind, int* n_main, int
     const FastEntry* fe = pick_fast(N, K);
     if (fe && stop_mode == PB_STOP_WINDOW && (wind != 6 || fe->S > 20)) fe = nullptr;
     if (fe) {
-      Piece pc[3];
+      Piece pc[4];
       const int npc = plan_pieces(P, fe->fn_pair != nullptr && stop_mode == PB_STOP_NONE,
                                   pick_wide_small(N, K) != nullptr, false, false, pc);
-      if (npc > 1) { nm = pc[0].p1; mf = pc[0].form; tf = pc[1].form; }
+      // leading pieces of one form = the "main" part; the first other form = the tail
+      int i = 1;
+      while (i < npc && pc[i].form == pc[0].form) ++i;
+      if (i < npc) { nm = pc[i - 1].p1; mf = pc[0].form; tf = pc[i].form; }
       else { nm = 0; mf = 0; tf = pc[0].form; }
     } else {
       const WideEntry* we = pick_wide(N, K);
@@ -558,7 +568,7 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
     // stop rules; the one-problem-per-wave form has them all); a remainder that fits beside
     // half a round of pair waves runs on the side stream
     const bool pair_ok = fe->fn_pair != nullptr && stop_mode == PB_STOP_NONE;
-    Piece pc[3];
+    Piece pc[4];
     const bool one_stream = (flags & PB_FLAG_ONE_STREAM) != 0 || stream_is_capturing((hipStream_t)stream);
     const int npc = plan_pieces(P, pair_ok, pick_wide_small(N, K) != nullptr,
                                 (flags & PB_FLAG_ONE_LAUNCH) != 0, one_stream, pc);
@@ -581,14 +591,19 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
       return PB_OK;
     }
     hipStream_t user = (hipStream_t)stream;
-    if (hipEventRecord(ss->fork, user) != hipSuccess || hipStreamWaitEvent(ss->stream, ss->fork, 0) != hipSuccess)
-      return fail(PB_ERR_HIP, "pb_fista_solve: fork to the side stream failed");
     int rc_all = PB_OK;
+    bool forked = false;
     for (int i = 0; i < npc && rc_all == PB_OK; ++i) {
+      if (pc[i].group && !forked) {              // whole rounds are in the queue: the group starts here
+        if (hipEventRecord(ss->fork, user) != hipSuccess || hipStreamWaitEvent(ss->stream, ss->fork, 0) != hipSuccess)
+          return fail(PB_ERR_HIP, "pb_fista_solve: fork to the side stream failed");
+        forked = true;
+      }
       stream = pc[i].side ? (void*)ss->stream : (void*)user;      // `run` launches on `stream`
       rc_all = run(pc[i].form, pc[i].p0, pc[i].p1);
     }
     stream = (void*)user;
+    if (!forked) return rc_all;
     // join even after an error so that the caller's stream never runs ahead of the side stream
     if (hipEventRecord(ss->join, ss->stream) != hipSuccess || hipStreamWaitEvent(user, ss->join, 0) != hipSuccess)
       return fail(PB_ERR_HIP, "pb_fista_solve: join of the side stream failed");

@@ -442,6 +442,16 @@ def test_side_stream_remainder(solver, golden):
         idx = np.concatenate([rng.choice(8192, 8, replace=False), 8192 + rng.choice(P - 8192, 8, replace=False)])
         Wo, _, _ = c_oracle.fista_batch(Y.cpu().numpy()[idx].astype(np.float64), hrf, 1.0, step, 40, threads=4)
         assert rel_rows(W.cpu().numpy()[idx], Wo) < 1e-5
+    # whole rounds first, then the concurrent group closes the plan (same forms per problem as
+    # the one-stream plan: 24 576 on the pair kernel, 424 one per wave)
+    for P in (25000, 41500):
+        Y = torch.from_numpy(rng.randn(P, 300).astype(np.float32)).cuda()
+        n_main, main_k, tail_k = solver.launch_plan(300, 30, P)
+        assert n_main == (P // 8192) * 8192 and "two problems per row" in main_k and "one problem per wave" in tail_k
+        W, _, _ = solver.fista_solve(Y, hrf, 1.0, step, 30)
+        s1 = W.abs().sum()
+        Wq, _, _ = solver.fista_solve(Y, hrf, 1.0, step, 30, force="seq")
+        assert torch.equal(W, Wq) and float(s1) == float(Wq.abs().sum()), P
     # shared y (y_rep), per-problem lambda and a warm start across the split: 600 voxels x 20
     # lambdas = 12 000 problems, the pieces start at problem offsets inside a voxel's group
     Yv = torch.from_numpy(rng.randn(600, 300).astype(np.float32)).cuda()
