@@ -312,7 +312,10 @@ int plan_pieces(int P, bool has_pair, bool has_wide, bool one_launch, bool one_s
     } else if (rest <= quarter) {                  // at most one single-row wave per SIMD
       grp[m++] = Piece{FORM_PAIR, g0, g1, false, true};
       grp[m++] = Piece{FORM_FAST1, g1, P, true, true};
-    } else if (has_wide && rest - quarter <= wide_round / 2) {
+    } else if (has_wide && rest - quarter <= wide_round) {
+      // (the left-overs BEHIND the single-row waves, on the same side stream: 2.60-2.65 ms for
+      // 12 400 ... 13 312 problems.  On a stream of their own they start with the others and the
+      // result depends on where the dispatcher happens to put them: 2.46-2.78 ms, cf. tools/conc_probe4.py)
       grp[m++] = Piece{FORM_PAIR, g0, g1, false, true};
       grp[m++] = Piece{FORM_FAST1, g1, g1 + quarter, true, true};
       grp[m++] = Piece{FORM_WIDE, g1 + quarter, P, true, true};
