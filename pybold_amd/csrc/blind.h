@@ -190,13 +190,33 @@ __global__ __launch_bounds__(NE_THREADS) void normal_eq_reduce_kernel(const doub
 
 struct HrfModel {        // two-gamma SPM HRF, un-normalised (pybold/hrf_model.py:25-31)
   double a1, loc1, lg1, a2, loc2, lg2, ratio;
+  int n1, n2;            // a - 1 when that is a small non-negative integer (the default model:
+                         // 5 and 15), else -1
 };
 
+inline int hrf_int_power(double a) {
+  const double e = a - 1.0;
+  return (e >= 0.0 && e <= 64.0 && e == (double)(int)e) ? (int)e : -1;
+}
+
+// gamma density at v = x - loc: v^(a-1) exp(-v) / Gamma(a).  Integer a - 1 (uniform, a scalar
+// branch): the power by repeated squaring instead of exp(. log v) -- half the cost of the
+// density, which is nine tenths of the theta-fit's instructions -- and more accurate.
+__device__ __forceinline__ double gamma_pdf(double v, double a, double lg, int n) {
+  if (!(v > 0.0)) return 0.0;
+  if (n >= 0) {
+    double p = 1.0, b = v;
+    for (int e = n; e > 0; e >>= 1) {
+      if (e & 1) p *= b;
+      b *= b;
+    }
+    return p * exp(-v - lg);
+  }
+  return exp((a - 1.0) * log(v) - v - lg);
+}
+
 __device__ __forceinline__ double spm_hrf_value(const HrfModel& hm, double x) {
-  auto pdf = [](double v, double a, double lg) {
-    return v > 0.0 ? exp((a - 1.0) * log(v) - v - lg) : 0.0;
-  };
-  return pdf(x - hm.loc1, hm.a1, hm.lg1) - hm.ratio * pdf(x - hm.loc2, hm.a2, hm.lg2);
+  return gamma_pdf(x - hm.loc1, hm.a1, hm.lg1, hm.n1) - hm.ratio * gamma_pdf(x - hm.loc2, hm.a2, hm.lg2, hm.n2);
 }
 
 // argmin_theta F(theta) over [lo, hi] for M independent normal-equation sets, one
@@ -274,15 +294,26 @@ __global__ __launch_bounds__(256) void theta_fit_kernel(const double* ne_sets, i
     a = tl;
     c = tr;
   }
-  // cost and taps at the returned dilation (every lane prices it; one thread publishes)
-  const double best_f = price(best_t);
+  // cost and taps at the returned dilation: ONE candidate, thread k = tap / row k
+  double* h1 = G + ne;                         // [K]
+  double* v1 = h1 + K;                         // [K]
+  for (int k = threadIdx.x; k < K; k += 256) h1[k] = spm_hrf_value(hm, best_t * t[k]);
+  __syncthreads();
+  for (int m = threadIdx.x; m < K; m += 256) {
+    double row = 0.0;
+    for (int mp = 0; mp < K; ++mp) row = fma(G[m * K + mp], h1[mp], row);
+    v1[m] = h1[m] * (0.5 * row - b[m]);
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
+    double f = 0.0;
+    for (int m = 0; m < K; ++m) f += v1[m];    // fixed order
     theta[s] = best_t;
-    cost[s] = best_f;
+    cost[s] = 0.5 * yy + f;
   }
   if (taps) {
     double* trow = taps + (int64_t)s * ldt;
-    for (int k = threadIdx.x; k < K; k += 256) trow[k] = spm_hrf_value(hm, best_t * t[k]);
+    for (int k = threadIdx.x; k < K; k += 256) trow[k] = h1[k];
   }
 }
 
