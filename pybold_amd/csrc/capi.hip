@@ -67,9 +67,6 @@ namespace pb {
 #undef PB_FAST
 }  // namespace pb
 
-namespace {
-
-}  // namespace
 namespace pb {
 #define PB_WIDE(S, KT)                                                                            \
   extern template int launch_wide<S, KT>(const FistaArgs&, const double*, int, bool, int, hipStream_t); \
@@ -176,7 +173,8 @@ const FastEntry* pick_fast(int N, int K) {
 // A problem count that is not a whole number of rounds is therefore split: whole rounds on
 // the pair (or single-row) kernel, the remainder on whichever form finishes it first, as a
 // second launch on the same stream (the first launch ends with every SIMD draining at once,
-// so running the remainder after it costs what overlapping would).
+// so running the remainder after it costs what overlapping would) -- or, when the remainder
+// exceeds half a round of pair waves, as a concurrent group (plan_pieces below).
 constexpr double COST_FAST1 = 0.63, COST_WIDE = 0.19, COST_PARTIAL = 0.56;
 constexpr double COST_LAUNCH = 0.03, COST_LAUNCH_WIDE = 0.05;
 enum Form { FORM_GENERIC = 0, FORM_FAST1 = 1, FORM_PAIR = 2, FORM_WIDE = 3 };
@@ -249,8 +247,9 @@ Plan plan_plain(int P, bool has_pair, bool has_wide, bool one_launch) {
 // problems) or one-problem waves -- co-schedules one wave of each per SIMD: 12 288 problems in
 // 0.80 of a round instead of 0.92-1.0, 10 000 in 0.74.  The side stream forks from and joins
 // back into the caller's stream with events (no host synchronisation); it is created on first
-// use, one per device.  Not used while the caller's stream is being captured into a graph, nor
-// for remainders of multi-round launches (measured slower: it unbalances the last round).
+// use, one per device.  Not used while the caller's stream is being captured into a graph.  A
+// remainder is never started beside a multi-round launch (measured slower: it unbalances the
+// last round); after whole rounds the same group closes the plan (plan_pieces).
 struct SideStream {
   hipStream_t stream = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
