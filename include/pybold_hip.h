@@ -88,10 +88,11 @@ int pb_fista_plan(int N, int K, int P, int stop_mode, int wind, int* n_main, int
  *   deconv (fixed-lambda loop)   pybold/bold_signal.py:62-72
  *   _loops_deconv                pybold/bold_signal.py:259-276
  * for P independent problems, state resident on chip, in ONE launch -- or, for a plain
- * solve (no stop rule) whose problem count does not fill the machine evenly, in TWO launches
- * on the same stream: the whole rounds of waves on the densest kernel form and the
- * remainder on whichever form finishes it first (PB_FLAG_ONE_LAUNCH turns that off); a
- * remainder that fits beside half a round of waves runs concurrently on the side stream:
+ * solve (no stop rule) whose problem count does not fill the machine evenly, in up to four:
+ * the whole rounds of waves on the densest kernel form, then the remainder on whichever form
+ * finishes it first (PB_FLAG_ONE_LAUNCH turns that off).  A remainder above half a round of
+ * pair waves becomes half a round on `stream` with the rest beside it on the side stream
+ * (PB_FLAG_ONE_STREAM turns that off; pb_fista_plan reports the split):
  *
  *   u = w - step * H^T (H w - y)      H = toeplitz(taps) . cumsum
  *   p = soft(u, lbda_p * step)        pybold/linear.py:73-113, convolution.py:105-132
