@@ -204,3 +204,45 @@ def test_config4_shared_hrf_full_size():
     err = sample_vs_oracle(W0, Y4, idx, h20, 1.7, 1.0 / gram_frobenius(h20, 300), 100)
     print("config 4: first z-step, max rel err of 64 voxels vs C oracle %.2e" % err)
     assert err < 1e-5
+
+
+def test_four_million_problems_in_one_call(setup):
+    """Maximum sizes: 4.2 M problems in one call (200 k voxels x 21 lambdas; the iterate alone
+    is 10 GB) -- 64-bit row offsets, grids beyond 2^31 lanes, the ragged end of every piece of
+    the launch plan.  Rows solved in the big call equal the same rows solved in a small one
+    (bitwise where the small batch runs the same kernel form, 1e-6 otherwise) and a sample
+    matches the C oracle; more than 2^25 problems are refused, not truncated."""
+    solver, hrf, Y = setup
+    reps = 21
+    Yb = torch.cat([Y, -Y], dim=0)                                     # 200 000 voxels
+    P = Yb.shape[0] * reps
+    lam = torch.logspace(-2, 0, reps, dtype=torch.float64, device="cuda").repeat(Yb.shape[0])
+    n_iter = 6
+    W, _, n_done = solver.fista_solve(Yb, hrf, lam, 1.0 / LIP, n_iter, y_rep=reps)
+    assert W.shape == (P, N) and int(n_done.min()) == n_iter and bool(torch.isfinite(W).all())
+    n_main, _, _ = solver.launch_plan(N, len(hrf), P)
+    rng = np.random.RandomState(4)
+    rows = np.unique(np.r_[0, 1, n_main - 1, n_main, P - 2, P - 1, rng.randint(0, P, 40)])
+    rows = rows[(rows >= 0) & (rows < P)]
+    vox, k = rows // reps, rows % reps
+    Ys = Yb[torch.from_numpy(vox).cuda()]
+    lam_s = lam[torch.from_numpy(rows).cuda()]
+    Ws, _, _ = solver.fista_solve(Ys, hrf, lam_s, 1.0 / LIP, n_iter)
+    assert rel_rows_t(W[torch.from_numpy(rows).cuda()], Ws) < 1e-6
+    Wo, _, _ = c_oracle.fista_batch(Ys.cpu().numpy().astype(np.float64), hrf, lam_s.cpu().numpy(), 1.0 / LIP,
+                                    n_iter, threads=4)
+    assert rel_rows_t(W[torch.from_numpy(rows).cuda()].cpu(), torch.from_numpy(Wo)) < 1e-5
+    # odd symmetry across the two halves of the batch (same lambda index): bitwise
+    half = Y.shape[0] * reps
+    assert torch.equal(W[:1000 * reps], -W[half:half + 1000 * reps])
+    del W
+    # the guard, through the raw C ABI (no 80 GB iterate needed: it fires before any access)
+    from pybold_amd import _lib
+    lib = _lib.load()
+    taps = np.ascontiguousarray(hrf, dtype=np.float64)
+    w1 = torch.zeros((1, N), dtype=torch.float64, device="cuda")
+    betas = torch.zeros((1,), dtype=torch.float64, device="cuda")
+    rc = lib.pb_fista_solve(Yb.data_ptr(), N, (1 << 25) + 1, w1.data_ptr(), N, (1 << 25) + 1, N,
+                            taps.ctypes.data, None, taps.size, 1.0 / LIP, 1.0, None, betas.data_ptr(), 1,
+                            None, 0, 0, 0.0, 0, None, 0, None)
+    assert rc != 0 and b"2^25" in lib.pb_last_error()
