@@ -118,9 +118,14 @@ def bd_batch(Y, t_r, lbda=1.0, theta_0=None, z_0=None, hrf_dur=20.0, bounds=None
                                       inplace=not early_stopping)
         return Wn
 
-    def record(W, taps, eps):
-        X, Z = solver.fista_outputs_pp(W, taps)
-        r = ((X - Yd) ** 2).sum(dim=1)
+    def record(W, taps, eps, r=None):
+        """Cost bookkeeping of :337-342.  ``r`` given: the data term is already known (twice
+        the minimum the theta-fit returns, for the same ``W`` and the new taps) and no output
+        pass is needed; else ``x`` and ``z`` are formed and returned."""
+        X = Z = None
+        if r is None:
+            X, Z = solver.fista_outputs_pp(W, taps)
+            r = ((X - Yd) ** 2).sum(dim=1)
         g = W.abs().sum(dim=1)
         J.append((r + lbda * g) / j0 + eps)
         R.append(r / r0 + eps)
@@ -132,13 +137,14 @@ def bd_batch(Y, t_r, lbda=1.0, theta_0=None, z_0=None, hrf_dur=20.0, bounds=None
         all_active = (not early_stopping) or bool(active.all())
         W = Wn if all_active else torch.where(active[:, None], Wn, W)
         Z = solver.integ_op(W)
-        th_new, _, taps_new = fit_dilations(Z, Y, t_r, hrf_dur, bounds)
+        th_new, cost_new, taps_new = fit_dilations(Z, Y, t_r, hrf_dur, bounds)
         if all_active:
             theta, taps = th_new, taps_new
+            record(W, taps, 1.0e-30, r=2.0 * cost_new)
         else:
             theta = torch.where(active, th_new, theta)
             taps = torch.where(active[:, None], taps_new, taps)
-        record(W, taps, 1.0e-30)
+            record(W, taps, 1.0e-30)
         if verbose > 0:
             print("bd_batch outer %d: median theta %.4f, median J %.6f"
                   % (idx + 1, float(theta.median()), float(J[-1].median())))
