@@ -192,6 +192,7 @@ struct HrfModel {        // two-gamma SPM HRF, un-normalised (pybold/hrf_model.p
   double a1, loc1, lg1, a2, loc2, lg2, ratio;
   int n1, n2;            // a - 1 when that is a small non-negative integer (the default model:
                          // 5 and 15), else -1
+  double c1, c2;         // 1 / Gamma(a)
 };
 
 inline int hrf_int_power(double a) {
@@ -215,7 +216,22 @@ __device__ __forceinline__ double gamma_pdf(double v, double a, double lg, int n
   return exp((a - 1.0) * log(v) - v - lg);
 }
 
+__device__ __forceinline__ double ipow(double b, int n) {
+  double p = 1.0;
+  for (int e = n; e > 0; e >>= 1) {
+    if (e & 1) p *= b;
+    b *= b;
+  }
+  return p;
+}
+
 __device__ __forceinline__ double spm_hrf_value(const HrfModel& hm, double x) {
+  if (hm.n1 >= 0 && hm.n2 >= 0 && hm.loc1 == hm.loc2) {
+    // the default model: both densities at the same v with integer powers -- one exp
+    const double v = x - hm.loc1;
+    if (!(v > 0.0)) return 0.0;
+    return exp(-v) * (ipow(v, hm.n1) * hm.c1 - hm.ratio * hm.c2 * ipow(v, hm.n2));
+  }
   return gamma_pdf(x - hm.loc1, hm.a1, hm.lg1, hm.n1) - hm.ratio * gamma_pdf(x - hm.loc2, hm.a2, hm.lg2, hm.n2);
 }
 

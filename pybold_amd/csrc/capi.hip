@@ -868,7 +868,8 @@ int pb_theta_fit(const double* ne_dev, int64_t ldne, int M, int K, const double*
   if (!ne_dev || !t_dev || !theta_dev || !cost_dev)
     return fail(PB_ERR_INVALID, "pb_theta_fit: NULL pointer");
   pb::HrfModel hm{a_peak, loc_peak, lgamma(a_peak), a_under, loc_under, lgamma(a_under), ratio,
-                  pb::hrf_int_power(a_peak), pb::hrf_int_power(a_under)};
+                  pb::hrf_int_power(a_peak), pb::hrf_int_power(a_under), std::exp(-lgamma(a_peak)),
+                  std::exp(-lgamma(a_under))};
   hipLaunchKernelGGL(pb::theta_fit_kernel, dim3(M), dim3(256), (size_t)nd * sizeof(double),
                      (hipStream_t)stream, ne_dev, ldne, M, K, t_dev, hm, lo, hi, n_refine, theta_dev,
                      cost_dev, taps_dev, ldt);
