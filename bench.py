@@ -166,7 +166,7 @@ def run(args):
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     red_dev = torch.device("cpu") if args.rehearse_on_one_gpu else dev
 
-    from pybold_amd import data, distributed, solver
+    from pybold_amd import data, solver
     from pybold_amd.hrf_model import spm_hrf
     from pybold_amd.linear import ConvAndLinear, DiscretInteg
     from pybold_amd.utils import spectral_radius_est
