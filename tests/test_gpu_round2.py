@@ -528,3 +528,35 @@ def test_host_pipeline_matches_resident_solve():
     assert abs(float(tot) - float(ref.abs().sum())) < 1e-6 * float(ref.abs().sum())
     with pytest.raises(ValueError):
         pipe.run(Yh[:10])
+
+
+def test_c_abi_from_plain_c(solver, golden, tmp_path):
+    """examples/c_abi_demo (C99, linked against libpybold_hip.so and the HIP runtime only; built
+    by __graft_entry__.build()) runs pb_fista_solve without Python or PyTorch in the process:
+    its iterates equal those of the Python host side bit for bit."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "c_abi_demo")
+    if not os.path.exists(exe):
+        import __graft_entry__
+        __graft_entry__.build_c_demo()
+    g = golden("case1")
+    hrf, lip = np.ascontiguousarray(g["hrf"], dtype=np.float64), float(g["lipschitz"])
+    rng = np.random.RandomState(8)
+    V, N, n_iter = 1000, 300, 50
+    Y = rng.randn(V, N).astype(np.float32)
+    Y.tofile(tmp_path / "y.f32")
+    hrf.tofile(tmp_path / "taps.f64")
+    out = subprocess.run([exe, str(tmp_path / "y.f32"), str(V), str(N), str(tmp_path / "taps.f64"), str(len(hrf)),
+                          repr(1.0 / lip), "1.0", str(n_iter), str(tmp_path / "w.f64")],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "sum|diff_z|" in out.stdout
+    Wc = np.fromfile(tmp_path / "w.f64", dtype=np.float64).reshape(V, N)
+    W, _, _ = solver.fista_solve(torch.from_numpy(Y).cuda(), hrf, 1.0, 1.0 / lip, n_iter)
+    assert np.array_equal(Wc, W.cpu().numpy())
+    # error path: text from pb_last_error, non-zero exit code
+    bad = subprocess.run([exe, str(tmp_path / "y.f32"), str(V), str(N), str(tmp_path / "taps.f64"), str(len(hrf)),
+                          "-1.0", "1.0", str(n_iter), str(tmp_path / "w2.f64")], capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 1 and "step must be positive" in bad.stderr
