@@ -101,3 +101,13 @@ def test_missing_library_is_an_import_error(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(ImportError, match="no CPU"):
         _lib.load()
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/pybold_hip.h is what a cgo / JNI / ctypes binding reads: it must compile as C99
+    on its own (no HIP, no C++), with every prototype visible."""
+    import subprocess
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "pybold_hip.h"\nint (*keep)(void) = pb_version;\nint main(void) { return keep == (int (*)(void))0; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only",
+                           "-I" + os.path.join(ROOT, "include"), str(src)])
