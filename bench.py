@@ -215,9 +215,8 @@ def run(args):
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for k in range(steps):
-            p.W.zero_()
             ev[k][0].record()          # same stream the kernel is launched on
-            p.launch()
+            p.launch(cold=True)        # deconv's cold start (w = 0) without a memset: PB_FLAG_COLD_START
             ev[k][1].record()
         torch.cuda.synchronize(dev)
         barrier()

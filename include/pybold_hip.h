@@ -52,6 +52,8 @@ extern "C" {
 #define PB_FLAG_DIRECT_FIR 64u    /* pair form: direct K-tap FIRs (fista_pair_kernel) instead of the
                                      2-parallel fast FIRs (fista_pair_ffa_kernel) */
 #define PB_FLAG_ONE_STREAM 128u    /* never use the internal side stream (see pb_fista_solve) */
+#define PB_FLAG_COLD_START 256u   /* the iterate starts from 0 (what deconv does, bold_signal.py:57): w_dev
+                                     is output only -- no memset by the caller, no read by the kernel */
 #define PB_FLAG_ONE_LAUNCH 32u    /* never split a plain solve into a full-rounds launch and a
                                      remainder launch (see pb_fista_solve) */
 

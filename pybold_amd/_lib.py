@@ -19,6 +19,7 @@ PB_FLAG_FORCE_WIDE = 16
 PB_FLAG_ONE_LAUNCH = 32
 PB_FLAG_DIRECT_FIR = 64
 PB_FLAG_ONE_STREAM = 128
+PB_FLAG_COLD_START = 256
 PB_STOP_NONE = 0
 PB_STOP_LOOPS = 1
 PB_STOP_WINDOW = 2

@@ -533,6 +533,7 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
   a.step = step; a.lbda = lbda; a.tol = tol;
   a.y_rep = y_rep; a.P = P; a.N = N; a.n_iter = n_iter; a.stop_mode = stop_mode;
   a.taps_pp = nullptr; a.ldt = 0; a.step_vec = nullptr; a.step_shared = 0; a.K = K; a.p0 = 0;
+  a.cold = (flags & PB_FLAG_COLD_START) ? 1 : 0;
 
   const FastEntry* fe = (flags & PB_FLAG_FORCE_GENERIC) ? nullptr : pick_fast(N, K);
   // the register-resident window rule keeps wind-1 = 5 iterates in VGPRs: wind = 6
@@ -676,6 +677,7 @@ int pb_fista_solve_d(const double* y_dev, int64_t ldy, int y_rep, double* w_dev,
   a.step = step; a.lbda = lbda; a.tol = tol;
   a.y_rep = y_rep; a.P = P; a.N = N; a.n_iter = n_iter; a.stop_mode = stop_mode;
   a.taps_pp = nullptr; a.ldt = 0; a.step_vec = nullptr; a.step_shared = 0; a.K = K; a.p0 = 0;
+  a.cold = (flags & PB_FLAG_COLD_START) ? 1 : 0;
   if (ee) {
     if (ee->fn(a, taps_host, K, J_dev != nullptr, stop_mode, (hipStream_t)stream) != 0)
       return fail(PB_ERR_INVALID, "pb_fista_solve_d: launch rejected");
@@ -899,6 +901,7 @@ int pb_fista_solve_pp(const float* y_dev, int64_t ldy, double* w_dev, int64_t ld
   a.y_rep = 1; a.P = P; a.N = N; a.n_iter = n_iter; a.stop_mode = stop_mode;
   a.taps_pp = taps_dev; a.ldt = ldt; a.step_vec = step_dev; a.step_shared = (ldt == 0); a.K = K;
   a.p0 = 0;
+  a.cold = (flags & PB_FLAG_COLD_START) ? 1 : 0;
 
   const FastEntry* fe = (flags & PB_FLAG_FORCE_GENERIC) ? nullptr : pick_fast(N, K);
   if (fe) {

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void fista_exact_kernel(FistaArgs a, TapsD<KT>
     for (int j = 0; j < S; ++j) {
       const bool ok = base + j < a.N;
       y[j] = ok ? yrow[base + j] : 0.0;
-      w[j] = ok ? wrow[base + j] : 0.0;
+      w[j] = (ok && !a.cold) ? wrow[base + j] : 0.0;
       mk[j] = ok ? 1.0 : 0.0;
     }
   }

@@ -60,6 +60,7 @@ struct FistaArgs {
   int n_iter;
   int stop_mode;
   int K;                  // number of taps actually used (<= KT)
+  int cold;               // 1: the iterate starts from 0, a.w is written only
 };
 
 // Tap pairs as kernel arguments (read with scalar loads, kept in SGPRs).
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
     for (int j = 0; j < S; ++j) {
       const bool ok = live && (base + j < a.N);
       y[j] = ok ? yrow[base + j] : 0.0f;
-      w[j] = ok ? wrow[base + j] : 0.0;
+      w[j] = (ok && !a.cold) ? wrow[base + j] : 0.0;
     }
   }
   // 1.0 for the real samples of this lane, 0.0 for the padding behind sample N-1

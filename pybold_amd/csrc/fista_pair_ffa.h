@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
 #pragma unroll
       for (int k = 0; k < S; ++k) {
         const int i = k * 16 + sub;
-        stage_d[i] = (i < a.N) ? row[i] : 0.0;
+        stage_d[i] = (i < a.N && !a.cold) ? row[i] : 0.0;
       }
       lds_sync();
 #pragma unroll

@@ -391,7 +391,7 @@ __global__ __launch_bounds__(GEN_THREADS) void fista_generic_kernel(FistaArgs a_
   double* wrow = a_.w + (int64_t)p * a_.ldw;
   const double* tp = a_.taps_pp ? a_.taps_pp + (int64_t)p * a_.ldt : taps;
   const double stp = a_.step_vec ? a_.step_vec[a_.step_shared ? 0 : p] : a_.step;
-  for (int i = threadIdx.x; i < N; i += GEN_THREADS) w[i] = wrow[i];
+  for (int i = threadIdx.x; i < N; i += GEN_THREADS) w[i] = a_.cold ? 0.0 : wrow[i];
   for (int i = threadIdx.x; i < K; i += GEN_THREADS) k[i] = tp[i];
   __syncthreads();
   const double lb = a_.lbda_vec ? a_.lbda_vec[p] : a_.lbda;

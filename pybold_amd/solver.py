@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (PB_FLAG_DIRECT_FIR, PB_FLAG_ONE_STREAM, PB_FLAG_FORCE_FAST, PB_FLAG_FORCE_GENERIC, PB_FLAG_FORCE_PAIR, PB_FLAG_FORCE_WIDE,
+from ._lib import (PB_FLAG_COLD_START, PB_FLAG_DIRECT_FIR, PB_FLAG_ONE_STREAM, PB_FLAG_FORCE_FAST, PB_FLAG_FORCE_GENERIC, PB_FLAG_FORCE_PAIR, PB_FLAG_FORCE_WIDE,
                    PB_FLAG_NO_PAIR, PB_FLAG_ONE_LAUNCH, PB_STOP_LOOPS, PB_STOP_NONE, PB_STOP_WINDOW)
 
 _STOP = {None: PB_STOP_NONE, "none": PB_STOP_NONE, "loops": PB_STOP_LOOPS,
@@ -144,8 +144,10 @@ def fista_solve(Y, hrf, lbda, step, n_iter, W0=None, want_J=False, stop=None,
     P = V * int(y_rep)
     taps = _as_taps(hrf)
     taps_dev = torch.from_numpy(taps).to(dev)
-    if W0 is None:
-        W = torch.zeros((P, N), dtype=torch.float64, device=dev)
+    cold = 0
+    if W0 is None:                     # the kernels start from 0 themselves: no memset, no read
+        W = torch.empty((P, N), dtype=torch.float64, device=dev)
+        cold = PB_FLAG_COLD_START
     else:
         W = _rows(W0, torch.float64, "W0").clone()
         if W.shape != (P, N):
@@ -175,7 +177,7 @@ def fista_solve(Y, hrf, lbda, step, n_iter, W0=None, want_J=False, stop=None,
                 lbda_dev.data_ptr() if lbda_dev is not None else None,
                 betas.data_ptr(), int(n_iter),
                 J.data_ptr() if J is not None else None, _ld(J) if J is not None else 0,
-                _STOP[stop], float(tol), int(wind), n_done.data_ptr(), _FORCE[force],
+                _STOP[stop], float(tol), int(wind), n_done.data_ptr(), _FORCE[force] | cold,
                 _stream_ptr(dev))
         _lib.check(rc, "pb_fista_solve_d")
         return W, J, n_done
@@ -186,7 +188,7 @@ def fista_solve(Y, hrf, lbda, step, n_iter, W0=None, want_J=False, stop=None,
             lbda_dev.data_ptr() if lbda_dev is not None else None,
             betas.data_ptr(), int(n_iter),
             J.data_ptr() if J is not None else None, _ld(J) if J is not None else 0,
-            _STOP[stop], float(tol), int(wind), n_done.data_ptr(), _FORCE[force],
+            _STOP[stop], float(tol), int(wind), n_done.data_ptr(), _FORCE[force] | cold,
             _stream_ptr(dev))
     _lib.check(rc, "pb_fista_solve")
     return W, J, n_done
@@ -223,20 +225,20 @@ class FistaPlan:
         self.betas = _betas_on(self.dev, self.n_iter)
         self.flags = _FORCE[force]
 
-    def launch(self):
-        """Only the solver launch (the iterate continues from its current value)."""
+    def launch(self, cold=False):
+        """Only the solver launch: the iterate continues from its current value, or
+        (``cold``) starts from 0 without being read."""
         rc = self.lib.pb_fista_solve(
             self.Y.data_ptr(), _ld(self.Y), self.y_rep, self.W.data_ptr(), _ld(self.W), self.P,
             self.N, self.taps.ctypes.data, self.taps_dev.data_ptr(), self.taps.size, self.step,
             self.lbda, self.lbda_dev.data_ptr() if self.lbda_dev is not None else None,
             self.betas.data_ptr(), self.n_iter, None, 0, PB_STOP_NONE, 0.0, 0,
-            self.n_done.data_ptr(), self.flags, _stream_ptr(self.dev))
+            self.n_done.data_ptr(), self.flags | (PB_FLAG_COLD_START if cold else 0), _stream_ptr(self.dev))
         _lib.check(rc, "pb_fista_solve")
 
     def run(self):
-        """Cold start: zero the iterate, then solve."""
-        self.W.zero_()
-        self.launch()
+        """Cold start (what ``deconv`` does, pybold/bold_signal.py:57): solve from w = 0."""
+        self.launch(cold=True)
         return self.W
 
 
@@ -484,8 +486,10 @@ def fista_solve_pp(Y, taps, steps, lbda, n_iter, W0=None, stop=None, tol=0.0, fo
     steps = steps.to(device=dev, dtype=torch.float64).contiguous().ravel()
     if steps.numel() != (1 if shared else V):
         raise ValueError("steps must have one entry per voxel (one in all for a shared HRF)")
+    cold = 0
     if W0 is None:
-        W = torch.zeros((V, N), dtype=torch.float64, device=dev)
+        W = torch.empty((V, N), dtype=torch.float64, device=dev)
+        cold = PB_FLAG_COLD_START
     else:
         W = _rows(W0, torch.float64, "W0")
         if not inplace or W.data_ptr() != W0.data_ptr():
@@ -504,7 +508,7 @@ def fista_solve_pp(Y, taps, steps, lbda, n_iter, W0=None, stop=None, tol=0.0, fo
             Y.data_ptr(), _ld(Y), W.data_ptr(), _ld(W), V, N, taps.data_ptr(),
             0 if shared else _ld(taps), taps.shape[1], steps.data_ptr(), lbda_scalar,
             lbda_dev.data_ptr() if lbda_dev is not None else None, betas.data_ptr(), int(n_iter),
-            _STOP[stop], float(tol), n_done.data_ptr(), _FORCE[force], _stream_ptr(dev))
+            _STOP[stop], float(tol), n_done.data_ptr(), _FORCE[force] | cold, _stream_ptr(dev))
     _lib.check(rc, "pb_fista_solve_pp")
     return W, n_done
 

@@ -560,3 +560,39 @@ def test_c_abi_from_plain_c(solver, golden, tmp_path):
     bad = subprocess.run([exe, str(tmp_path / "y.f32"), str(V), str(N), str(tmp_path / "taps.f64"), str(len(hrf)),
                           "-1.0", "1.0", str(n_iter), str(tmp_path / "w2.f64")], capture_output=True, text=True, timeout=120)
     assert bad.returncode == 1 and "step must be positive" in bad.stderr
+
+
+@pytest.mark.parametrize("force", [None, "fast1", "fast2", "fast2d", "wide", "generic", "f64", "f64generic"])
+def test_cold_start_flag_equals_zero_warm_start(solver, golden, force):
+    """PB_FLAG_COLD_START (W0=None: the kernels start from w = 0 without reading w_dev, the
+    caller does not clear it) against an explicit all-zero warm start: bitwise, every kernel
+    form, cost trace and stop rule included; FistaPlan.run() on a buffer full of NaNs."""
+    g = golden("case1")
+    hrf, lip = g["hrf"], float(g["lipschitz"])
+    rng = np.random.RandomState(12)
+    V = 300 if force in ("generic", "f64generic") else 9000
+    Y = torch.from_numpy(rng.randn(V, 300).astype(np.float32)).cuda()
+    kw = dict(want_J=True, stop="window", tol=1e-3)
+    if force in ("f64", "f64generic"):
+        Y = Y.double()
+        f = None if force == "f64" else "generic"
+    else:
+        f = force
+    zeros = torch.zeros((V, 300), dtype=torch.float64, device="cuda")
+    for extra in ({}, kw):
+        if extra and f in ("fast2", "fast2d"):
+            continue                                       # the pair form has no stop rule
+        Wc, Jc, nc = solver.fista_solve(Y, hrf, 1.0, 1.0 / lip, 40, force=f, **extra)
+        Ww, Jw, nw = solver.fista_solve(Y, hrf, 1.0, 1.0 / lip, 40, W0=zeros, force=f, **extra)
+        assert torch.equal(Wc, Ww) and torch.equal(nc, nw)
+        if Jc is not None:
+            assert torch.equal(torch.nan_to_num(Jc), torch.nan_to_num(Jw))
+    if force not in ("f64", "f64generic"):
+        plan = solver.FistaPlan(Y, hrf, 1.0, 1.0 / lip, 40, force=f)
+        plan.W.fill_(float("nan"))
+        plan.run()
+        ref, _, _ = solver.fista_solve(Y, hrf, 1.0, 1.0 / lip, 40, W0=zeros, force=f)
+        assert torch.equal(plan.W, ref)
+        plan.launch()                                      # continues from the current iterate
+        ref2, _, _ = solver.fista_solve(Y, hrf, 1.0, 1.0 / lip, 40, W0=ref, force=f)
+        assert torch.equal(plan.W, ref2)
