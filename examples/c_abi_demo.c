@@ -54,10 +54,10 @@ int main(int argc, char** argv) {
   HIP_OK(hipMemcpy(y_dev, y, (size_t)V * N * sizeof(float), hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(taps_dev, taps, (size_t)K * sizeof(double), hipMemcpyHostToDevice));
   HIP_OK(hipMemcpy(betas_dev, betas, (size_t)n_iter * sizeof(double), hipMemcpyHostToDevice));
-  HIP_OK(hipMemset(w_dev, 0, (size_t)V * N * sizeof(double)));          /* cold start */
 
   const int rc = pb_fista_solve(y_dev, N, 1, w_dev, N, V, N, taps, taps_dev, K, step, lbda, NULL,
-                                betas_dev, n_iter, NULL, 0, PB_STOP_NONE, 0.0, 0, n_done_dev, 0u,
+                                betas_dev, n_iter, NULL, 0, PB_STOP_NONE, 0.0, 0, n_done_dev,
+                                PB_FLAG_COLD_START /* w_dev is output only */,
                                 NULL /* default stream */);
   if (rc != PB_OK) {
     fprintf(stderr, "pb_fista_solve failed (%d): %s\n", rc, pb_last_error());
