@@ -909,14 +909,19 @@ int pb_fista_solve_pp(const float* y_dev, int64_t ldy, double* w_dev, int64_t ld
     // dispatch model of plain solves would use it, the per-problem-taps kernel elsewhere
     if (ldt == 0 && stop_mode == PB_STOP_NONE && fe->fn_pair_dev && P >= 2 &&
         !(flags & (PB_FLAG_NO_PAIR | PB_FLAG_DIRECT_FIR))) {
+      // (the remainder of the whole rounds on the single-row or the one-problem-per-wave kernel,
+      // both reading the shared HRF through their per-problem-taps form)
+      const WideEntry* ws = pick_wide_small(N, K);
       Plan pl{0, FORM_GENERIC, FORM_PAIR};
-      if (!(flags & PB_FLAG_FORCE_PAIR)) pl = plan_plain(P, true, false, (flags & PB_FLAG_ONE_LAUNCH) != 0);
+      if (!(flags & PB_FLAG_FORCE_PAIR))
+        pl = plan_plain(P, true, ws != nullptr, (flags & PB_FLAG_ONE_LAUNCH) != 0);
       auto run = [&](int form, int p0, int p1) -> int {
         pb::FistaArgs b = a;
         b.p0 = p0;
         b.P = p1;
-        const int bad = (form == FORM_PAIR) ? fe->fn_pair_dev(b, (hipStream_t)stream)
-                                            : fe->fn_pp(b, stop_mode, (hipStream_t)stream);
+        const int bad = (form == FORM_PAIR)   ? fe->fn_pair_dev(b, (hipStream_t)stream)
+                        : (form == FORM_WIDE) ? ws->fn_pp(b, stop_mode, (hipStream_t)stream)
+                                              : fe->fn_pp(b, stop_mode, (hipStream_t)stream);
         if (bad) return fail(PB_ERR_INVALID, "pb_fista_solve_pp: launch rejected");
         return check_launch(form == FORM_PAIR ? "fista_pair_ffa_kernel(shared taps)" : "fista_fast_kernel(pp)");
       };
