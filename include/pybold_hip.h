@@ -65,6 +65,13 @@ extern "C" {
 /* Library version (major*10000 + minor*100 + patch). */
 int pb_version(void);
 
+/* Optional.  Creates the internal side stream of the current device now instead of at the
+ * first solve that uses it (see pb_fista_solve).  Worth calling before the application creates
+ * streams of its own: HIP multiplexes streams onto a few hardware queues in creation order, and
+ * a side stream created after half a dozen others was measured to overlap less with the caller's
+ * stream (2.52 ms instead of 2.38 ms for 12 500 problems).  Idempotent, thread-safe. */
+int pb_init(void);
+
 /* Text of the last error on the calling thread ("" if none). */
 const char* pb_last_error(void);
 

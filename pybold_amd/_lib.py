@@ -32,6 +32,7 @@ _ptr = ctypes.c_void_p
 # name -> (restype, argtypes); mirrors include/pybold_hip.h one to one
 SIGNATURES = {
     "pb_version": (_c_int, []),
+    "pb_init": (_c_int, []),
     "pb_last_error": (ctypes.c_char_p, []),
     "pb_fista_has_fast_path": (_c_int, [_c_int, _c_int]),
     "pb_fista_which_kernel": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int]),

@@ -263,7 +263,12 @@ SideStream* side_stream_locked() {      // call with g_side_mutex held
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   SideStream& ss = per_dev[dev];
   if (!ss.ok && ss.stream == nullptr) {
-    if (hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking) == hipSuccess &&
+    // Its own priority level: HIP multiplexes the streams of one priority onto a few hardware
+    // queues, and a side stream that lands on the caller's queue runs BEHIND the caller's
+    // kernel instead of beside it (seen after an application had created half a dozen streams)
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; (void)hipGetLastError(); }
+    if (hipStreamCreateWithPriority(&ss.stream, hipStreamNonBlocking, greatest) == hipSuccess &&
         hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) == hipSuccess &&
         hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess)
       ss.ok = true;
@@ -311,13 +316,16 @@ int plan_pieces(int P, bool has_pair, bool has_wide, bool one_launch, bool one_s
     } else if (rest <= quarter) {                  // at most one single-row wave per SIMD
       grp[m++] = Piece{FORM_PAIR, g0, g1, false, true};
       grp[m++] = Piece{FORM_FAST1, g1, P, true, true};
-    } else if (has_wide && rest - quarter <= wide_round) {
-      // (the left-overs BEHIND the single-row waves, on the same side stream: 2.60-2.65 ms for
-      // 12 400 ... 13 312 problems.  On a stream of their own they start with the others and the
-      // result depends on where the dispatcher happens to put them: 2.46-2.78 ms, cf. tools/conc_probe4.py)
+    } else if (has_wide && rest - quarter <= 2 * wide_round) {
+      // (both on the one side stream, in a fixed order.  On a stream of their own the left-overs
+      // land wherever the dispatcher happens to put them: 2.46-2.78 ms, tools/conc_probe4.py)
+      // The left-overs go FIRST on the side stream: they are latency-bound (0.37 ms whatever
+      // their number) and so are the pair waves while alone on their SIMDs, so the two overlap
+      // for free; behind the single-row waves they would run alone at the very end
+      // (tools/conc_probe5.py: 2.33 ms instead of 2.44 for 12 500 problems).
       grp[m++] = Piece{FORM_PAIR, g0, g1, false, true};
-      grp[m++] = Piece{FORM_FAST1, g1, g1 + quarter, true, true};
       grp[m++] = Piece{FORM_WIDE, g1 + quarter, P, true, true};
+      grp[m++] = Piece{FORM_FAST1, g1, g1 + quarter, true, true};
     }
     if (m > 0) {
       if (whole > 0) out[n++] = Piece{FORM_PAIR, 0, whole, false, false};
@@ -450,6 +458,13 @@ extern "C" {
 
 int pb_version(void) { return 100; }
 
+int pb_init(void) {
+  std::lock_guard<std::mutex> lock(g_side_mutex);
+  if (!side_stream_locked()) return fail(PB_ERR_HIP, "pb_init: no side stream (is a HIP device current?)");
+  g_err[0] = 0;
+  return PB_OK;
+}
+
 const char* pb_last_error(void) { return g_err; }
 
 int pb_fista_has_fast_path(int N, int K) {
@@ -490,10 +505,17 @@ int pb_fista_plan(int N, int K, int P, int stop_mode, int wind, int* n_main, int
       const int npc = plan_pieces(P, fe->fn_pair != nullptr && stop_mode == PB_STOP_NONE,
                                   pick_wide_small(N, K) != nullptr, false, false, pc);
       // leading pieces of one form = the "main" part; the first other form = the tail
+      // (of several: the one that carries most of the remaining problems)
       int i = 1;
       while (i < npc && pc[i].form == pc[0].form) ++i;
-      if (i < npc) { nm = pc[i - 1].p1; mf = pc[0].form; tf = pc[i].form; }
-      else { nm = 0; mf = 0; tf = pc[0].form; }
+      if (i < npc) {
+        nm = pc[i - 1].p1;
+        mf = pc[0].form;
+        int big = i;
+        for (int k = i + 1; k < npc; ++k)
+          if (pc[k].p1 - pc[k].p0 > pc[big].p1 - pc[big].p0) big = k;
+        tf = pc[big].form;
+      } else { nm = 0; mf = 0; tf = pc[0].form; }
     } else {
       const WideEntry* we = pick_wide(N, K);
       if (we && stop_mode == PB_STOP_WINDOW && (wind != 6 || we->S > 20)) we = nullptr;

@@ -61,7 +61,21 @@ def _betas_on(dev, n_iter):
     return cur
 
 
+_inited = set()
+
+
+def _ensure_init(dev):
+    """The first use of a device asks the library for its side stream (``pb_init``): created
+    before the application's own streams it overlaps best with the caller's
+    (include/pybold_hip.h)."""
+    if dev.index not in _inited:
+        _inited.add(dev.index)
+        with torch.cuda.device(dev):
+            _lib.load().pb_init()           # optional: a failure only postpones the creation
+
+
 def _stream_ptr(dev):
+    _ensure_init(dev)
     return torch.cuda.current_stream(dev).cuda_stream
 
 
@@ -268,9 +282,12 @@ class HostPipeline:
     def __init__(self, n_voxels, n_scans, hrf, lbda, step, n_iter, chunk=None, out_dtype=torch.float32,
                  dev=None, force=None):
         self.dev = device(dev)
+        _ensure_init(self.dev)                      # the library's side stream before ours
         self.V, self.N = int(n_voxels), int(n_scans)
         if chunk is None:
             chunk = round_size(self.N, len(_as_taps(hrf)), self.dev) or 8192
+            if self.V < 3 * chunk:                  # too few chunks to hide anything: measured slower
+                chunk = self.V                      # than copy, solve, copy on one stream
         self.chunk = max(1, min(int(chunk), max(self.V, 1)))
         self.out_dtype = out_dtype
         self.bounds = [(lo, min(lo + self.chunk, self.V)) for lo in range(0, self.V, self.chunk)]
@@ -303,6 +320,16 @@ class HostPipeline:
         if tuple(Yh.shape) != (self.V, self.N) or Yh.dtype != torch.float32 or Yh.is_cuda:
             raise ValueError("Yh must be a float32 host tensor of shape (%d, %d)" % (self.V, self.N))
         cur = torch.cuda.current_stream(self.dev)
+        if len(self.bounds) == 1:                   # one chunk: everything on the current stream
+            self.Yd[0][:self.V].copy_(Yh, non_blocking=True)
+            self.plans[0].run()
+            if self.out is not None:
+                if self.Od is not self.Wd:
+                    self.Od[0][:self.V].copy_(self.Wd[0][:self.V])
+                self.out.copy_(self.Od[0][:self.V], non_blocking=True)
+            if sync:
+                cur.synchronize()
+            return self.out if self.out is not None else self.W
         for s in (self.s_in, self.s_cmp, self.s_out):
             s.wait_stream(cur)
         for c, (lo, hi) in enumerate(self.bounds):

@@ -524,7 +524,8 @@ def test_host_pipeline_matches_resident_solve():
     # enqueue-only form is ordered before later work on the current stream
     assert solver.round_size(N, len(hrf)) == 16384
     pipe = solver.HostPipeline(V, N, hrf, lam, step, n_iter, out_dtype=None)
-    assert pipe.chunk == 16384
+    assert pipe.chunk == V                                   # under three rounds: one chunk, one stream
+    assert solver.HostPipeline(60000, N, hrf, 1.0, step, n_iter, out_dtype=None).chunk == 16384
     W = pipe.run(Yh, sync=False)
     tot = W.abs().sum()
     assert abs(float(tot) - float(ref.abs().sum())) < 1e-6 * float(ref.abs().sum())

@@ -151,12 +151,12 @@ def test_bench_job_layout_and_self_launch_guard():
 def test_launch_plan_of_a_plain_solve():
     """pb_fista_plan is a host-only query: whole rounds of pair waves (16 384 problems on 256
     CUs; the same default when no device is visible), half a round + a concurrent remainder
-    between 8 192 and 13 312 problems and after whole rounds, the cheapest single form below."""
+    between 8 192 and 14 336 problems and after whole rounds, the cheapest single form below."""
     from pybold_amd import solver
     pair, row, wave = (solver.KERNEL_NAMES[k] for k in (2, 1, 3))
     expect = {1: (0, None, wave), 1000: (0, None, wave), 4096: (0, None, row), 8192: (0, None, pair),
               10000: (8192, pair, wave), 12500: (8192, pair, row), 13312: (8192, pair, row),
-              14000: (0, None, pair), 16384: (0, None, pair), 25000: (24576, pair, wave),
+              14000: (8192, pair, row), 14400: (0, None, pair), 16384: (0, None, pair), 25000: (24576, pair, wave),
               29000: (24576, pair, row), 50000: (49152, pair, wave), 100000: (98304, pair, wave)}
     for P, want in expect.items():
         assert solver.launch_plan(300, 30, P) == want, P

@@ -18,6 +18,6 @@ def ms(V, force, reps=9, nit=500):
         ts.append(time.perf_counter() - t0)
     return float(np.median(ts)) * 1e3
 
-for P in (12400, 12500, 13312, 14000, 20000, 24576, 25000, 26000, 28672, 29000, 33000, 41000, 45056, 50000, 58000, 61440, 75000, 100000, 108000):
+for P in (12500, 13312, 13400, 13800, 14000, 14336, 14400, 15000, 16384, 29700, 30000, 30720):
     a, b = ms(P, "seq"), ms(P, None)
     print("P=%7d  one stream %7.3f ms  auto %7.3f ms  (%+.1f %%)   plan %s" % (P, a, b, (b / a - 1) * 100, solver.launch_plan(300, 30, P)), flush=True)
