@@ -333,6 +333,19 @@ int plan_pieces(int P, bool has_pair, bool has_wide, bool one_launch, bool one_s
       return n;
     }
   }
+  // Between a quarter and three eighths of a round (4 096 < R <= 6 144): one single-row wave per
+  // SIMD with up to two one-problem waves beside it, instead of pair waves alone on their SIMDs
+  // (tools/conc_probe7.py: 5 000 problems 1.14 ms against 1.31, 6 000 1.39 against 1.59).
+  if (has_pair && has_wide && !one_launch && !one_stream) {
+    const int quarter = half / 2, wide_round = (int)wave_slots() / 2;
+    // (behind whole rounds only with ONE left-over wave per SIMD: two measured no gain there)
+    if (R > quarter && R - quarter <= (whole > 0 ? 1 : 2) * wide_round) {
+      if (whole > 0) out[n++] = Piece{FORM_PAIR, 0, whole, false, false};
+      out[n++] = Piece{FORM_FAST1, whole, whole + quarter, false, true};
+      out[n++] = Piece{FORM_WIDE, whole + quarter, P, true, true};
+      return n;
+    }
+  }
   const Plan pl = plan_plain(P, has_pair, has_wide, one_launch);
   if (pl.n_main > 0) out[n++] = Piece{pl.main_form, 0, pl.n_main, false, false};
   out[n++] = Piece{pl.tail_form, pl.n_main, P, false, false};

@@ -444,6 +444,19 @@ def test_side_stream_remainder(solver, golden):
         idx = np.concatenate([rng.choice(8192, 8, replace=False), 8192 + rng.choice(P - 8192, 8, replace=False)])
         Wo, _, _ = c_oracle.fista_batch(Y.cpu().numpy()[idx].astype(np.float64), hrf, 1.0, step, 40, threads=4)
         assert rel_rows(W.cpu().numpy()[idx], Wo) < 1e-5
+    # a quarter to three eighths of a round (alone, or after whole rounds): single-row waves with
+    # one-problem waves beside them
+    for P in (4500, 6144, 21000):
+        Y = torch.from_numpy(rng.randn(P, 300).astype(np.float32)).cuda()
+        n_main, main_k, tail_k = solver.launch_plan(300, 30, P)
+        assert n_main == (16384 if P == 21000 else 4096) and ("one problem per wave" in tail_k or P == 21000)
+        W, _, _ = solver.fista_solve(Y, hrf, 1.0, step, 30)
+        s1 = W.abs().sum()
+        Wq, _, _ = solver.fista_solve(Y, hrf, 1.0, step, 30, force="seq")
+        assert float(((W - Wq).norm(dim=1) / Wq.norm(dim=1)).max()) < 1e-6 and float(s1) == float(W.abs().sum())
+        idx = np.r_[0, 4095, 4096, P - 1, rng.choice(P, 6, replace=False)]
+        Wo, _, _ = c_oracle.fista_batch(Y.cpu().numpy()[idx].astype(np.float64), hrf, 1.0, step, 30, threads=4)
+        assert rel_rows(W.cpu().numpy()[idx], Wo) < 1e-5
     # whole rounds first, then the concurrent group closes the plan (same forms per problem as
     # the one-stream plan: 24 576 on the pair kernel, 424 one per wave)
     for P in (25000, 41500):

@@ -154,7 +154,8 @@ def test_launch_plan_of_a_plain_solve():
     between 8 192 and 14 336 problems and after whole rounds, the cheapest single form below."""
     from pybold_amd import solver
     pair, row, wave = (solver.KERNEL_NAMES[k] for k in (2, 1, 3))
-    expect = {1: (0, None, wave), 1000: (0, None, wave), 4096: (0, None, row), 8192: (0, None, pair),
+    expect = {1: (0, None, wave), 1000: (0, None, wave), 4096: (0, None, row), 5000: (4096, row, wave),
+              6144: (4096, row, wave), 6200: (0, None, pair), 8192: (0, None, pair), 21000: (16384, pair, row),
               10000: (8192, pair, wave), 12500: (8192, pair, row), 13312: (8192, pair, row),
               14000: (8192, pair, row), 14400: (0, None, pair), 16384: (0, None, pair), 25000: (24576, pair, wave),
               29000: (24576, pair, row), 50000: (49152, pair, wave), 100000: (98304, pair, wave)}
