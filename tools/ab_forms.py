@@ -27,7 +27,7 @@ def ms(V, force, reps=7, nit=500):
 T = ms(16384, "fast2")
 print("pair round (16384 problems): %.3f ms" % T)
 print("%8s %18s %18s %18s %18s %18s %18s" % ("P", "fast1", "pair(ffa)", "pair(direct)", "wide", "auto 1 stream", "auto"))
-for P in (1, 64, 256, 512, 1024, 1696, 2048, 3072, 4096, 6000, 8192, 9000, 10000, 11000, 12288, 12500, 12800, 14000, 16384,
+for P in (1, 64, 256, 512, 1024, 1696, 2048, 3072, 4096, 5000, 6000, 8192, 9000, 10000, 11000, 12288, 12500, 12800, 14000, 16384,
           18000, 20480, 24576, 25000, 32768, 50000, 100000):
     row = "%8d" % P
     for force in ("fast1", "fast2", "fast2d", "wide", "seq", None):

@@ -18,6 +18,6 @@ def ms(V, force, reps=9, nit=500):
         ts.append(time.perf_counter() - t0)
     return float(np.median(ts)) * 1e3
 
-for P in (4500, 5000, 6000, 6144, 6200, 12500, 21000, 22000, 22528, 25000, 37500, 100000):
+for P in (4500, 5000, 6144, 9000, 10000, 12288, 12500, 13312, 14000, 14336, 20000, 21000, 24576, 25000, 29000, 41000, 50000, 58000, 75000, 100000):
     a, b = ms(P, "seq"), ms(P, None)
     print("P=%7d  one stream %7.3f ms  auto %7.3f ms  (%+.1f %%)   plan %s" % (P, a, b, (b / a - 1) * 100, solver.launch_plan(300, 30, P)), flush=True)
