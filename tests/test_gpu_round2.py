@@ -467,6 +467,17 @@ def test_side_stream_remainder(solver, golden):
         s1 = W.abs().sum()
         Wq, _, _ = solver.fista_solve(Y, hrf, 1.0, step, 30, force="seq")
         assert torch.equal(W, Wq) and float(s1) == float(Wq.abs().sum()), P
+    # the cost trace through the concurrent group (every piece writes its own rows of J)
+    Y = torch.from_numpy(rng.randn(12500, 300).astype(np.float32)).cuda()
+    W, J, _ = solver.fista_solve(Y, hrf, 1.0, step, 30, want_J=True)
+    Wq, Jq, _ = solver.fista_solve(Y, hrf, 1.0, step, 30, want_J=True, force="seq")
+    assert bool(torch.isfinite(J).all())
+    assert float(((W - Wq).norm(dim=1) / Wq.norm(dim=1)).max()) < 1e-6
+    assert float(((J - Jq).abs() / Jq.abs()).max()) < 1e-5
+    idx = np.r_[0, 8191, 8192, 12287, 12288, 12499]
+    Wo, Jo, _ = c_oracle.fista_batch(Y.cpu().numpy()[idx].astype(np.float64), hrf, 1.0, step, 30, want_J=True, threads=4)
+    assert rel_rows(W.cpu().numpy()[idx], Wo) < 1e-5
+    assert np.abs(J.cpu().numpy()[idx] / Jo - 1.0).max() < 1e-5
     # shared y (y_rep), per-problem lambda and a warm start across the split: 600 voxels x 20
     # lambdas = 12 000 problems, the pieces start at problem offsets inside a voxel's group
     Yv = torch.from_numpy(rng.randn(600, 300).astype(np.float32)).cuda()
