@@ -305,8 +305,10 @@ int pb_inf_norm(const double* x_dev, int64_t ldx, double* out_dev, int64_t ldo, 
  * pb_theta_fit       argmin over theta in [lo, hi] of the quadratic form for M sets
  *                    (ne_dev [M][ldne]) with h(theta) the un-normalised two-gamma SPM HRF
  *                    at the K sample times t_dev (parameters as pb_spm_hrf): section search
- *                    with 64 candidates per refinement (bracket / 31.5 each) closed by a
- *                    parabola vertex; replaces the reference's fmin_l_bfgs_b call
+ *                    -- one scan of 64 candidates over [lo, hi], then, per further level
+ *                    of n_refine, two scans of 16 candidates around the best one (bracket
+ *                    / 56 per level) -- closed by a parabola vertex (n_refine = 3: about
+ *                    1e-9 on theta); replaces the reference's fmin_l_bfgs_b call
  *                    (:329-333).  theta_dev [M], cost_dev [M] = F(theta*), taps_dev
  *                    [M][ldt] = h(theta*) (may be NULL).  Entirely on the device: the
  *                    next z-step can read taps_dev through pb_fista_solve_pp (ldt = 0).

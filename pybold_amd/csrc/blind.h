@@ -236,8 +236,9 @@ __device__ __forceinline__ double spm_hrf_value(const HrfModel& hm, double x) {
 }
 
 // argmin_theta F(theta) over [lo, hi] for M independent normal-equation sets, one
-// 256-thread workgroup per set: 64 candidate dilations per refinement (lane = candidate),
-// the K taps of each candidate and the K rows of the quadratic form dealt over the 4 waves.
+// 256-thread workgroup per set: a first scan of 64 candidate dilations (lane = candidate, the K
+// taps of each candidate and the K rows of the quadratic form dealt over the 4 waves), then
+// scans of 16 candidates around the best one (thread = candidate x one of 16 shares).
 // Section search, the bracket shrinks to the two grid cells around the best candidate (x31.5
 // per refinement); the last refinement ends with the vertex of the parabola through the best
 // candidate and its neighbours.  Every wave reduces the same 64 values in the same order, so
@@ -281,7 +282,8 @@ __global__ __launch_bounds__(256) void theta_fit_kernel(const double* ne_sets, i
   };
 
   double a = lo, c = hi, best_t = lo;
-  for (int r = 0; r < n_refine; ++r) {
+  {
+    // first scan: 64 candidates over the whole interval (lane = candidate)
     const double th = a + (c - a) * ((double)lane / 63.0);
     const double f = price(th);
     // argmin over the wave (first minimum wins: deterministic)
@@ -297,15 +299,48 @@ __global__ __launch_bounds__(256) void theta_fit_kernel(const double* ne_sets, i
     const double tl = __shfl(th, il, 64), tm = __shfl(th, im, 64), tr = __shfl(th, ir, 64);
     const double fl = __shfl(f, il, 64), fr = __shfl(f, ir, 64);
     best_t = tm;
-    if (r == n_refine - 1 && im > 0 && im < 63) {
+    if (n_refine == 1 && im > 0 && im < 63) {
+      const double den = fl - 2.0 * fm + fr;
+      if (den > 0.0) best_t = fmin(fmax(tm + 0.5 * (tm - tl) * (fl - fr) / den, tl), tr);
+    }
+    a = tl;
+    c = tr;
+  }
+  // every further level: two scans of 16 candidates over the two cells around the best one
+  // (bracket / 7.5 each, / 56 per level).  Thread = (candidate, 1 of 16 shares of the taps and
+  // rows): a sixteenth of the gamma densities per thread instead of a quarter.
+  const int cand = threadIdx.x >> 4, sh = threadIdx.x & 15;
+  double* h16 = G + ne;                        // [K][16]
+  for (int r = 0; r < 2 * (n_refine - 1); ++r) {
+    const double th = a + (c - a) * ((double)cand / 15.0);
+    for (int k = sh; k < K; k += 16) h16[k * 16 + cand] = spm_hrf_value(hm, th * t[k]);
+    __syncthreads();
+    double v = 0.0;
+    for (int m = sh; m < K; m += 16) {
+      double row = 0.0;
+      for (int mp = 0; mp < K; ++mp) row = fma(G[m * K + mp], h16[mp * 16 + cand], row);
+      v = fma(h16[m * 16 + cand], 0.5 * row - b[m], v);
+    }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);     // the 16 shares of one candidate
+    if (sh == 0) part[cand] = 0.5 * yy + v;
+    __syncthreads();
+    int im = 0;
+    double fm = part[0];
+    for (int q = 1; q < 16; ++q) {
+      const double fq = part[q];
+      if (fq < fm) { fm = fq; im = q; }
+    }
+    const int il = im > 0 ? im - 1 : 0, ir = im < 15 ? im + 1 : 15;
+    const double step16 = (c - a) / 15.0;
+    const double tl = a + step16 * il, tm = a + step16 * im, tr = a + step16 * ir;
+    const double fl = part[il], fr = part[ir];
+    __syncthreads();                           // h16 / part are rewritten by the next scan
+    best_t = tm;
+    if (r == 2 * (n_refine - 1) - 1 && im > 0 && im < 15) {
       // vertex of the parabola through (tl, fl), (tm, fm), (tr, fr); equal spacing
       const double den = fl - 2.0 * fm + fr;
-      if (den > 0.0) {
-        const double hstep = tm - tl;
-        double tv = tm + 0.5 * hstep * (fl - fr) / den;
-        tv = fmin(fmax(tv, tl), tr);
-        best_t = tv;
-      }
+      if (den > 0.0) best_t = fmin(fmax(tm + 0.5 * step16 * (fl - fr) / den, tl), tr);
     }
     a = tl;
     c = tr;
