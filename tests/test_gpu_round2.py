@@ -281,6 +281,11 @@ def test_theta_fit_matches_direct_minimiser_and_lbfgsb(solver):
         assert float(costs[v]) <= float(f_l) * (1 + 1e-9)
         assert float(costs[v]) == pytest.approx(orc.hrf_fit_err(float(thetas[v]), Z[v], Y[v], T_R, HRF_DUR),
                                                 rel=1e-8)
+    # accuracy levels: one scan of 64 candidates (spacing 0.02) + parabola, then / 56 per level
+    for n_refine, tol in ((1, 2e-3), (2, 2e-6), (4, 2e-7)):
+        th_n, f_n, _ = solver.theta_fit(ne, T_R, HRF_DUR, (0.6, 1.9), n_refine=n_refine)
+        assert float(th_n[0]) == pytest.approx(th_ref, abs=tol), n_refine
+        assert float(f_n[0]) >= f_ref * (1 - 1e-9)
     # minimiser on a bound
     th_b, _, _ = solver.theta_fit(ne, T_R, HRF_DUR, (1.2, 1.9))
     assert float(th_b[0]) == pytest.approx(1.2, abs=1e-12)
