@@ -106,72 +106,175 @@ __global__ __launch_bounds__(NE_THREADS) void normal_eq_kernel(const double* z, 
 // Sum over the voxels of the block: part[blockIdx.x][ne_len] (a second kernel adds the blocks
 // in a fixed order: deterministic).  Summed over voxels, the running sums become
 //   G[m][m'] = BULK_d + sum_{j' <= j} P_d[j'],   P_d[j'] = sum_v z_v[jb+j'] z_v[jb+j'+d]
-// so nothing in the voxel loop depends on the previous step: every lane accumulates its
-// bulk terms in a register and its share of the tail products P in LDS (own entries only),
-// and the prefix sums over j' are taken once per block at the end.
-// LDS: z[N] y[N] P[K*K].
+// so nothing in the voxel loop depends on the previous step.
+//
+// The bulk sums are register-blocked: a thread owns NE_LB consecutive lags of one kind
+// (autocorrelation of z, or cross-correlation of z with y) and one slice of the sample axis;
+// per block of NE_JB samples it reads NE_JB + (NE_JB + NE_LB - 1) values from LDS for
+// NE_JB x NE_LB multiply-adds (0.36 reads per FMA; one lag per lane costs 2 and made the
+// kernel LDS-bound: 0.26 ms for 50 k voxels, 4x the time of its HBM traffic).  Accumulators
+// live in registers across the whole voxel loop; slices are folded once, in a fixed order.
+// The tail products P (last K samples: one running sum per truncation point) and yy are dealt
+// over the threads entry by entry.
+// LDS: z[N + pad] y[N + K + pad] P[K*K] red[256 * NE_LB].
+constexpr int NE_LB = 8, NE_JB = 8;
+
+// LDS index of sample i: one pad every NE_JB samples, so that lanes whose blocks start NE_JB
+// samples apart read 9 doubles apart (2-way bank conflicts instead of 16-way)
+__host__ __device__ inline int ne_sk(int i) { return i + (i >> 3); }
+
+__host__ __device__ inline int ne_sum_lds_doubles(int N, int K) {
+  return ne_sk(N + NE_LB + NE_JB) + 1 + ne_sk(N + K + NE_LB + NE_JB) + 1 + K * K + 2 * NE_LB * 16 + 2 * K + 16;
+}
+
 template <typename TY>
 __global__ __launch_bounds__(NE_THREADS) void normal_eq_sum_kernel(const double* z, int64_t ldz,
                                                                    const TY* y, int64_t ldy, int V,
-                                                                   int N, int K, int sub_log2,
-                                                                   double* part_out) {
+                                                                   int N, int K, double* part_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int SUB = 1 << sub_log2;
   const int ne = ne_len(K);
-  const int role = threadIdx.x >> sub_log2;
-  const int sub = threadIdx.x & (SUB - 1);
-  const bool worker = role < 2 * K + 1;
+  static_assert(NE_JB == 8 && NE_LB == 8, "ne_sk() pads every 8 samples");
+  const int nz = N + NE_LB + NE_JB, ny = N + K + NE_LB + NE_JB;      // logical lengths
   double* lz = reinterpret_cast<double*>(smem);
-  double* ly = lz + N;
-  double* P = ly + N;
-  for (int e = threadIdx.x; e < K * K; e += NE_THREADS) P[e] = 0.0;
+  double* ly = lz + ne_sk(nz) + 1;
+  double* P = ly + ne_sk(ny) + 1;
+  double* red = P + K * K;                     // [roles <= 32][NE_LB]
+  double* bulk = red + 2 * NE_LB * 16;         // [2K]: autocorrelation lags, then cross lags
+  double* red8 = bulk + 2 * K;                 // block_sum scratch
+  const int t = threadIdx.x;
+  for (int e = t; e < K * K; e += NE_THREADS) P[e] = 0.0;
+  for (int i = t; i <= ne_sk(nz); i += NE_THREADS) lz[i] = 0.0;      // padding stays zero
+  for (int i = t; i <= ne_sk(ny); i += NE_THREADS) ly[i] = 0.0;
   const int jb = N > K ? N - K : 0;
-  const int d = role;                          // autocorrelation roles
-  const int tail = (worker && role < K && N - d > jb) ? N - d - jb : 0;   // truncation points of lag d
-  double acc = 0.0;
+  // roles: lag blocks of the two kinds; slices: threads that share a role
+  const int nlb = (K + NE_LB - 1) / NE_LB;
+  int slices = 1;                              // threads per role: a power of two (shuffle fold)
+  while (2 * slices * 2 * nlb <= NE_THREADS) slices *= 2;
+  const int role = t / slices, slice = t % slices;
+  const bool worker = role < 2 * nlb;
+  const bool cross = role >= nlb;
+  const int d0 = (cross ? role - nlb : role) * NE_LB;
+  const int jrange = cross ? N : jb;           // autocorrelation: bulk part only
+  const double* src = cross ? ly : lz;
+  double acc[NE_LB];
+#pragma unroll
+  for (int l = 0; l < NE_LB; ++l) acc[l] = 0.0;
+  double yy = 0.0;
+  // this thread's tail entries (d, jj), fixed for the whole launch: LDS offsets, -1 = none
+  constexpr int NE_TE = 4;                     // up to 4 * 256 entries: K <= 32; larger K loop below
+  int te_a[NE_TE], te_b[NE_TE];
+#pragma unroll
+  for (int q = 0; q < NE_TE; ++q) {
+    const int e = t + q * NE_THREADS;
+    const int d = e / K, jj = e - d * K;
+    const bool ok = e < K * K && jb + jj + d < N;
+    te_a[q] = ok ? ne_sk(jb + jj) : -1;
+    te_b[q] = ok ? ne_sk(jb + jj + d) : 0;
+  }
+  // samples of this thread for the voxel being staged (N <= 4 * 256: registers, prefetched
+  // while the previous voxel is being processed; longer series are loaded in place)
+  constexpr int NE_PF = 4;
+  const bool prefetch = N <= NE_PF * NE_THREADS;
+  double pz[NE_PF];
+  TY py[NE_PF];
+  auto fetch = [&](int v) {
+    const double* zr = z + (int64_t)v * ldz;
+    const TY* yr = y + (int64_t)v * ldy;
+#pragma unroll
+    for (int q = 0; q < NE_PF; ++q) {
+      const int i = t + q * NE_THREADS;
+      if (i < N) { pz[q] = zr[i]; py[q] = yr[i]; }
+    }
+  };
+  if (prefetch && (int)blockIdx.x < V) fetch(blockIdx.x);
   for (int v = blockIdx.x; v < V; v += gridDim.x) {
-    __syncthreads();
-    {
+    __syncthreads();                           // previous voxel fully consumed
+    if (prefetch) {
+#pragma unroll
+      for (int q = 0; q < NE_PF; ++q) {
+        const int i = t + q * NE_THREADS;
+        if (i < N) { lz[ne_sk(i)] = pz[q]; ly[ne_sk(i)] = (double)py[q]; }
+      }
+      if (v + (int)gridDim.x < V) fetch(v + gridDim.x);            // in flight during the sums below
+    } else {
       const double* zr = z + (int64_t)v * ldz;
       const TY* yr = y + (int64_t)v * ldy;
-      for (int i = threadIdx.x; i < N; i += NE_THREADS) {
-        lz[i] = zr[i];
-        ly[i] = (double)yr[i];
+      for (int i = t; i < N; i += NE_THREADS) {
+        lz[ne_sk(i)] = zr[i];
+        ly[ne_sk(i)] = (double)yr[i];
       }
     }
     __syncthreads();
     if (worker) {
-      if (role < K) {
-        for (int j = sub; j < jb; j += SUB) acc = fma(lz[j], lz[j + d], acc);
-        for (int jj = sub; jj < tail; jj += SUB)
-          P[d * K + jj] = fma(lz[jb + jj], lz[jb + jj + d], P[d * K + jj]);
-      } else if (role < 2 * K) {
-        const int m = role - K;
-        for (int j = sub; j < N - m; j += SUB) acc = fma(lz[j], ly[j + m], acc);
-      } else {
-        for (int i = sub; i < N; i += SUB) acc = fma(ly[i], ly[i], acc);
+      for (int j0 = slice * NE_JB; j0 < jrange; j0 += slices * NE_JB) {
+        double a[NE_JB], b[NE_JB + NE_LB - 1];
+        const double* pa = lz + ne_sk(j0);
+        const double* pb = src + ne_sk(j0 + d0);                   // j0, d0: multiples of 8
+#pragma unroll
+        for (int q = 0; q < NE_JB; ++q) a[q] = (j0 + q < jrange) ? pa[q] : 0.0;
+#pragma unroll
+        for (int q = 0; q < NE_JB + NE_LB - 1; ++q) b[q] = pb[q + (q >> 3)];
+#pragma unroll
+        for (int q = 0; q < NE_JB; ++q)
+#pragma unroll
+          for (int l = 0; l < NE_LB; ++l) acc[l] = fma(a[q], b[q + l], acc[l]);
       }
+    }
+    // tail products: entry (d, jj), jj < number of truncation points of lag d
+#pragma unroll
+    for (int q = 0; q < NE_TE; ++q)
+      if (te_a[q] >= 0) P[t + q * NE_THREADS] = fma(lz[te_a[q]], lz[te_b[q]], P[t + q * NE_THREADS]);
+    for (int e = t + NE_TE * NE_THREADS; e < K * K; e += NE_THREADS) {
+      const int d = e / K, jj = e - d * K;
+      if (jb + jj + d < N) P[e] = fma(lz[ne_sk(jb + jj)], lz[ne_sk(jb + jj + d)], P[e]);
+    }
+    for (int i = t; i < N; i += NE_THREADS) yy = fma(ly[ne_sk(i)], ly[ne_sk(i)], yy);
+  }
+  // fold the slices of every role (adjacent lanes; fixed order), then one value per lag
+  for (int o = slices >> 1; o >= 1; o >>= 1) {
+    if (o < 64) {
+#pragma unroll
+      for (int l = 0; l < NE_LB; ++l) acc[l] += __shfl_xor(acc[l], o, 64);
     }
   }
-  for (int o = SUB >> 1; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);     // fixed order
-  double* part = part_out + (int64_t)blockIdx.x * ne;
-  for (int e = threadIdx.x; e < ne; e += NE_THREADS) part[e] = 0.0;          // entries with no sample
   __syncthreads();
-  if (worker && sub == 0) {
-    if (role < K) {
-      double r = acc;
-      for (int jj = 0; jj < tail; ++jj) {
-        r += P[d * K + jj];
-        const int mp = N - 1 - (jb + jj);
-        const int m = mp - d;
-        part[m * K + mp] = r;
-        part[mp * K + m] = r;
-      }
-    } else if (role < 2 * K) {
-      part[K * K + (role - K)] = acc;
-    } else {
-      part[K * K + K] = acc;
+  // (slices > 64: a role spans several waves -- only for K <= 8; their leaders are folded below)
+  const int per_wave = slices < 64 ? slices : 64;
+  if (worker && (t % per_wave) == 0) {
+    const int part_i = (slices > 64) ? (t % slices) / 64 : 0;
+    if (part_i < 2) {
+#pragma unroll
+      for (int l = 0; l < NE_LB; ++l) red[((part_i * 16 + role) * NE_LB) + l] = acc[l];
     }
+  }
+  __syncthreads();
+  for (int e = t; e < 2 * K; e += NE_THREADS) {
+    const bool cr = e >= K;
+    const int lag = cr ? e - K : e;
+    const int r = (cr ? nlb : 0) + lag / NE_LB, l = lag % NE_LB;
+    double sum = red[(r * NE_LB) + l];
+    if (slices > 64) sum += red[((16 + r) * NE_LB) + l];
+    bulk[e] = sum;
+  }
+  yy = block_sum(yy, red8);                    // (syncs inside: bulk[] is visible afterwards)
+  double* part = part_out + (int64_t)blockIdx.x * ne;
+  for (int e = t; e < ne; e += NE_THREADS) part[e] = 0.0;            // entries with no sample
+  __syncthreads();
+  if (t < K) {
+    const int d = t;
+    const int tail = (N - d > jb) ? N - d - jb : 0;
+    double r = bulk[d];
+    for (int jj = 0; jj < tail; ++jj) {
+      r += P[d * K + jj];
+      const int mp = N - 1 - (jb + jj);
+      const int m = mp - d;
+      part[m * K + mp] = r;
+      part[mp * K + m] = r;
+    }
+  } else if (t < 2 * K) {
+    part[K * K + (t - K)] = bulk[t];
+  } else if (t == 2 * K) {
+    part[K * K + K] = yy;
   }
 }
 

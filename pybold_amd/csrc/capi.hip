@@ -436,7 +436,7 @@ int normal_eq_impl(const double* z_dev, int64_t ldz, const TY* y_dev, int64_t ld
   const int ne = pb::ne_len(K);
   int sub_log2 = 0;                            // lanes per role: 4 for K <= 31, 2 for K <= 63
   while ((2 * K + 1) << (sub_log2 + 1) <= pb::NE_THREADS && sub_log2 < 2) ++sub_log2;
-  const int64_t nd = 2 * (int64_t)N + (per_voxel ? 0 : (int64_t)K * K);
+  const int64_t nd = per_voxel ? 2 * (int64_t)N : (int64_t)pb::ne_sum_lds_doubles(N, K);
   if (nd > LDS_DOUBLES_MAX) return fail(PB_ERR_INVALID, "%s: N=%d K=%d exceeds LDS", name, N, K);
   const size_t lds = (size_t)nd * sizeof(double);
   if (per_voxel) {
@@ -456,8 +456,9 @@ int normal_eq_impl(const double* z_dev, int64_t ldz, const TY* y_dev, int64_t ld
     if (blocks < 1 || !work_dev)
       return fail(PB_ERR_INVALID, "%s: work buffer must hold at least %d doubles", name, ne);
     if (!z_dev || !y_dev) return fail(PB_ERR_INVALID, "%s: NULL pointer", name);
-    hipLaunchKernelGGL((pb::normal_eq_sum_kernel<TY>), dim3(blocks), dim3(pb::NE_THREADS), lds,
-                       (hipStream_t)stream, z_dev, ldz, y_dev, ldy, V, N, K, sub_log2, work_dev);
+    hipLaunchKernelGGL((pb::normal_eq_sum_kernel<TY>), dim3(blocks), dim3(pb::NE_THREADS),
+                       (size_t)pb::ne_sum_lds_doubles(N, K) * sizeof(double), (hipStream_t)stream, z_dev,
+                       ldz, y_dev, ldy, V, N, K, work_dev);
   } else {
     blocks = 0;
   }
