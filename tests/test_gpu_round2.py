@@ -628,3 +628,20 @@ def test_cold_start_flag_equals_zero_warm_start(solver, golden, force):
         plan.launch()                                      # continues from the current iterate
         ref2, _, _ = solver.fista_solve(Y, hrf, 1.0, 1.0 / lip, 40, W0=ref, force=f)
         assert torch.equal(plan.W, ref2)
+
+
+@pytest.mark.parametrize("n,K", [(1200, 5), (37, 1), (600, 64), (300, 127), (9, 9), (2000, 33), (1025, 8), (64, 17)])
+def test_normal_equations_any_tap_count(solver, n, K):
+    """Shapes that move the thread layout of normal_eq_sum_kernel: K <= 8 (a role spans two
+    waves), K = 127 (32 roles of 8 threads), series longer than the prefetch registers hold,
+    series shorter than the HRF."""
+    rng = np.random.RandomState(n + K)
+    V = 7
+    Z = np.cumsum((rng.rand(V, n) < 0.1) * rng.randn(V, n), axis=1)
+    Y = rng.randn(V, n)
+    G, b, yy = orc.hrf_normal_eq(Z, Y, K)
+    ref = np.concatenate([G.ravel(), b, [yy]])
+    ne = solver.hrf_normal_eq(dev64(Z), dev64(Y), K).cpu().numpy()
+    np.testing.assert_allclose(ne, ref, rtol=1e-11, atol=1e-12 * np.abs(ref).max())
+    pv = solver.hrf_normal_eq(dev64(Z), dev64(Y), K, per_voxel=True).cpu().numpy()
+    np.testing.assert_allclose(pv.sum(axis=0), ref, rtol=1e-10, atol=1e-11 * np.abs(ref).max())
