@@ -308,7 +308,10 @@ def run(args):
                              "2-parallel fast FIRs execute 3/4 of those multiply-adds. State never "
                              "leaves the chip during a solve, so the SURVEY-8d algorithmic-byte "
                              "rate (12*N B per voxel-iteration / kernel time) exceeds the HBM peak; "
-                             "measured HBM traffic = one read of y, w and one write of w per launch."},
+                             "measured HBM traffic = one read of y and one write of w per launch. The peak assumes "
+                             "2.4 GHz; while this kernel runs the package sits at its power limit (1.27-1.29 kW) "
+                             "and the shader clock at 2.07-2.19 GHz (profiles/r2_clock_and_power_during_solve.txt, "
+                             "r2_pmc_sq_valu_utilisation.json): frac = 0.86-0.9 of the peak at the sustained clock."},
     }
 
     if world > 1 and args.scaling == "strong":
