@@ -852,6 +852,11 @@ int pb_gram_frobenius(const double* taps_dev, int64_t ldt, int P, int K, int N, 
   if ((int64_t)N + 8 > LDS_DOUBLES_MAX) return fail(PB_ERR_INVALID, "pb_gram_frobenius: exceeds LDS");
   if (P == 0) return PB_OK;
   if (!taps_dev || !out_dev) return fail(PB_ERR_INVALID, "pb_gram_frobenius: NULL pointer");
+  if (K <= N && K <= 1024) {                     // the FIR form: O(K^2 + N) per HRF
+    hipLaunchKernelGGL(pb::gram_frobenius_fir_kernel, dim3(P), dim3(64), (size_t)3 * K * sizeof(double),
+                       (hipStream_t)stream, taps_dev, ldt, K, N, out_dev);
+    return check_launch("gram_frobenius_fir_kernel");
+  }
   const size_t lds = (size_t)(N + 8) * sizeof(double);
   hipLaunchKernelGGL(pb::gram_frobenius_kernel, dim3(P), dim3(pb::GEN_THREADS), lds,
                      (hipStream_t)stream, taps_dev, ldt, K < N ? K : N, N, out_dev);

@@ -199,6 +199,65 @@ __global__ __launch_bounds__(GEN_THREADS) void gram_frobenius_kernel(const doubl
   if (threadIdx.x == 0) out[blockIdx.x] = sqrt(tot);
 }
 
+// The same constant in O(K^2 + N) instead of O(N^2 / 2) per HRF, for K <= N.  The kernel of A,
+// c = cumsum(h), is constant from t = K-1 on (c[t] = S = sum h), so for T >= K-2
+//   R_d(T) = alpha_d + (T - (K-2)) S^2,   alpha_d = R_d(K-2) = sum_{t<=K-2} c[t] c[min(t+d, K-1)]
+// and sum_T R_d(T)^2 over that range is a quadratic-polynomial sum in closed form; only the
+// first K-2 partial sums of the K-1 diagonals with d <= K-2 are accumulated term by term
+// (for d >= K-1 they are S * prefix(c), shared by all those diagonals).  One wave per HRF.
+// LDS: c[K] C[K] E[K].
+__global__ __launch_bounds__(64) void gram_frobenius_fir_kernel(const double* taps, int64_t ldt, int K,
+                                                               int N, double* out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* c = reinterpret_cast<double*>(smem);   // c[t], t < K (c[K-1] = S)
+  double* C = c + K;                             // C[T] = sum_{t<=T} c[t]
+  double* E = C + K;                             // E[T] = sum_{T'<=T} (S C[T'])^2
+  const double* h = taps + (int64_t)blockIdx.x * ldt;
+  const int lane = threadIdx.x;
+  if (lane == 0) {
+    double run = 0.0;
+    for (int t = 0; t < K; ++t) { run += h[t]; c[t] = run; }
+    const double S0 = run;
+    double cs = 0.0, es = 0.0;
+    for (int t = 0; t < K; ++t) {
+      cs += c[t];
+      C[t] = cs;
+      es = fma(S0 * cs, S0 * cs, es);
+      E[t] = es;
+    }
+  }
+  __syncthreads();
+  const double S = c[K - 1], S2 = S * S;
+  double part = 0.0;
+  for (int d = lane; d < N; d += 64) {
+    const int Tmax = N - 1 - d;                  // valid T: 0 .. Tmax
+    double direct = 0.0, alpha = 0.0;
+    if (d <= K - 2) {
+      double r = 0.0;
+      for (int t = 0; t <= K - 2; ++t) {
+        const int td = t + d < K - 1 ? t + d : K - 1;
+        r = fma(c[t], c[td], r);
+        if (t <= K - 3 && t <= Tmax) direct = fma(r, r, direct);
+      }
+      alpha = r;
+    } else {
+      const int last = (K - 3 < Tmax ? K - 3 : Tmax);
+      direct = last >= 0 ? E[last] : 0.0;
+      alpha = K >= 2 ? S * C[K - 2] : 0.0;
+    }
+    double tot = direct;
+    if (Tmax >= K - 2) {
+      const double M = (double)(Tmax - (K - 2));
+      const double s1 = 0.5 * M * (M + 1.0), s2 = M * (M + 1.0) * (2.0 * M + 1.0) / 6.0;
+      tot += (M + 1.0) * alpha * alpha + 2.0 * alpha * S2 * s1 + S2 * S2 * s2;
+    }
+    part += (d == 0 ? 1.0 : 2.0) * tot;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o, 64);
+  if (lane == 0) out[blockIdx.x] = sqrt(part);
+}
+
 // cost[c][v] = 0.5 || y_v - taps * z_v ||^2 ; grid = (V, n_hrf).  taps index:
 // shared candidates taps[c][K] (per_voxel = 0) or one HRF per (candidate, voxel)
 // taps[c][v][K] (per_voxel = 1).

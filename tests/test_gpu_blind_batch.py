@@ -40,6 +40,14 @@ def test_gram_frobenius_kernel(golden):
         L = solver.gram_frobenius_batch(d64(H), n).cpu().numpy()
         ref = np.array([orc.gram_lipschitz(h, n) for h in H])
         np.testing.assert_allclose(L, ref, rtol=1e-12)
+    # the FIR closed form on the corners of its case analysis (K = 1, 2; K = N, K = N - 1; long
+    # series; more taps than scans: the HRF is truncated to the series)
+    rng = np.random.RandomState(5)
+    for K, n in ((1, 5), (2, 2), (2, 9), (3, 50), (30, 30), (30, 31), (30, 32), (48, 2432), (127, 128), (40, 12)):
+        Hr = rng.randn(6, K)
+        L = solver.gram_frobenius_batch(d64(Hr), n).cpu().numpy()
+        ref = np.array([orc.gram_lipschitz(h, n) for h in Hr])
+        np.testing.assert_allclose(L, ref, rtol=1e-11, err_msg=str((K, n)))
 
 
 def test_per_voxel_cost_and_outputs():
