@@ -972,6 +972,16 @@ int pb_fista_solve_pp(const float* y_dev, int64_t ldy, double* w_dev, int64_t ld
       }
       return run(pl.tail_form, pl.n_main, P);
     }
+    // one HRF per problem: single-row form, or one problem per wave where that finishes first
+    // (small batches are latency-bound: 0.37 ms against 0.93 ms per 500 iterations up to 2 048)
+    if (!(flags & (PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_ONE_LAUNCH))) {
+      const WideEntry* ws = pick_wide_small(N, K);
+      if (ws && best_form(P, false, true) == FORM_WIDE) {
+        if (ws->fn_pp(a, stop_mode, (hipStream_t)stream) != 0)
+          return fail(PB_ERR_INVALID, "pb_fista_solve_pp: launch rejected");
+        return check_launch("fista_fast_kernel(wide, pp)");
+      }
+    }
     if (fe->fn_pp(a, stop_mode, (hipStream_t)stream) != 0)
       return fail(PB_ERR_INVALID, "pb_fista_solve_pp: launch rejected");
     return check_launch("fista_fast_kernel(pp)");

@@ -300,9 +300,12 @@ def test_shared_taps_solver_equals_host_taps_solver(solver, golden):
     h = g["h"]
     from pybold_amd.utils import gram_frobenius
     step = 1.0 / gram_frobenius(h, Y.shape[1])
-    Wp, _ = solver.fista_solve_pp(dev32(Y), dev64(np.tile(h, (37, 1))), dev64(np.full(37, step)), 1.7, 50)
+    Wp, _ = solver.fista_solve_pp(dev32(Y), dev64(np.tile(h, (37, 1))), dev64(np.full(37, step)), 1.7, 50,
+                                  force="fast1")
     W1, _ = solver.fista_solve_pp(dev32(Y), dev64(h), dev64([step]), 1.7, 50, force="fast1")
     assert torch.equal(W1, Wp)                     # the same kernel form: bitwise
+    Wd, _ = solver.fista_solve_pp(dev32(Y), dev64(np.tile(h, (37, 1))), dev64(np.full(37, step)), 1.7, 50)
+    assert rel_rows(Wd.cpu().numpy(), Wp.cpu().numpy()) < 1e-6    # library dispatch: one problem per wave here
     Ws, _ = solver.fista_solve_pp(dev32(Y), dev64(h), dev64([step]), 1.7, 50)   # library dispatch (one per wave here)
     assert rel_rows(Ws.cpu().numpy(), Wp.cpu().numpy()) < 1e-6
     ref = orc.fista_batch(Y.astype(np.float32).astype(np.float64), h, 1.7, step, 50)
