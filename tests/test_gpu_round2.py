@@ -648,3 +648,39 @@ def test_normal_equations_any_tap_count(solver, n, K):
     np.testing.assert_allclose(ne, ref, rtol=1e-11, atol=1e-12 * np.abs(ref).max())
     pv = solver.hrf_normal_eq(dev64(Z), dev64(Y), K, per_voxel=True).cpu().numpy()
     np.testing.assert_allclose(pv.sum(axis=0), ref, rtol=1e-10, atol=1e-11 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("force", [None, "fast1", "fast2", "wide", "generic", "f64"])
+def test_padded_rows_and_views(solver, golden, force):
+    """Leading dimensions larger than the series (row views of wider buffers, the layout an
+    allocator with padded pitches hands over): y float32 / float64 with ld > N, per-problem
+    lambda as a strided view, warm start from a view -- same results as contiguous copies,
+    nothing written outside the N columns."""
+    g = golden("case1")
+    hrf, lip = g["hrf"], float(g["lipschitz"])
+    rng = np.random.RandomState(21)
+    V, N, pad = 523, 300, 21
+    f64 = force == "f64"
+    dt = torch.float64 if f64 else torch.float32
+    buf = torch.from_numpy(rng.randn(V, N + pad)).to(dt).cuda()
+    Yv = buf[:, 3:3 + N]                                            # stride(0) = N + pad, offset 3
+    assert Yv.stride(0) == N + pad and not Yv.is_contiguous()
+    lam_buf = torch.from_numpy(0.2 + rng.rand(V, 2)).cuda()
+    lam = lam_buf[:, 1]                                             # strided 1-D view
+    W0buf = torch.from_numpy(0.01 * rng.randn(V, N + 5)).cuda()
+    W0 = W0buf[:, :N]
+    f = None if f64 else force
+    Wv, Jv, _ = solver.fista_solve(Yv, hrf, lam, 1.0 / lip, 35, W0=W0, want_J=True, force=f)
+    Wc, Jc, _ = solver.fista_solve(Yv.contiguous(), hrf, lam.contiguous(), 1.0 / lip, 35, W0=W0.contiguous(),
+                                   want_J=True, force=f)
+    assert torch.equal(Wv, Wc) and torch.equal(Jv, Jc)
+    assert torch.equal(W0buf[:, :N], W0) and torch.equal(buf[:, 3:3 + N], Yv)     # inputs untouched
+    ref = orc.fista_batch(Yv.cpu().numpy().astype(np.float64), hrf, lam.cpu().numpy(), 1.0 / lip, 35,
+                          W0=W0.cpu().numpy())
+    assert rel_rows(Wv.cpu().numpy(), ref) < (1e-10 if f64 else 1e-5)
+    # outputs / stats / operators on views
+    X, Z = solver.fista_outputs(Wv, hrf)
+    np.testing.assert_allclose(Z.cpu().numpy(), np.cumsum(Wv.cpu().numpy(), axis=1), rtol=1e-12, atol=1e-12)
+    lm_v = solver.lambda_max(Yv, hrf)
+    lm_c = solver.lambda_max(Yv.contiguous(), hrf)
+    assert torch.equal(lm_v, lm_c)
