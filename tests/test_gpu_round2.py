@@ -684,3 +684,36 @@ def test_padded_rows_and_views(solver, golden, force):
     lm_v = solver.lambda_max(Yv, hrf)
     lm_c = solver.lambda_max(Yv.contiguous(), hrf)
     assert torch.equal(lm_v, lm_c)
+
+
+def test_two_host_threads_share_the_side_stream(solver, golden):
+    """Two host threads, each on a stream of its own, solving batches that use the library's
+    (one per device) side stream: the fork/join is serialised inside the library, every result
+    equals the one-stream result of the same input."""
+    import threading
+    g = golden("case1")
+    hrf, lip = g["hrf"], float(g["lipschitz"])
+    gens = [torch.Generator(device="cuda").manual_seed(s) for s in (1, 2)]
+    Ys = [torch.randn(10000 + 1250 * i, 300, device="cuda", generator=gens[i]) for i in range(2)]
+    refs = [solver.fista_solve(Y, hrf, 1.0, 1.0 / lip, 20, force="seq")[0] for Y in Ys]
+    torch.cuda.synchronize()
+    errs = [[], []]
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(8):
+                    W, _, _ = solver.fista_solve(Ys[i], hrf, 1.0, 1.0 / lip, 20)
+                    errs[i].append(float((W - refs[i]).abs().max() / refs[i].abs().max()))
+            st.synchronize()
+        except Exception as e:                                   # surfaced below
+            errs[i].append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for i in range(2):
+        assert len(errs[i]) == 8 and all(isinstance(e, float) and e < 1e-6 for e in errs[i]), errs[i]
