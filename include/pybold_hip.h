@@ -54,6 +54,10 @@ extern "C" {
 #define PB_FLAG_ONE_STREAM 128u    /* never use the internal side stream (see pb_fista_solve) */
 #define PB_FLAG_COLD_START 256u   /* the iterate starts from 0 (what deconv does, bold_signal.py:57): w_dev
                                      is output only -- no memset by the caller, no read by the kernel */
+#define PB_FLAG_NO_CERT 512u       /* PB_STOP_WINDOW: always evaluate the rule in full (fista_fast_kernel), never
+                                     the no-fire certificate of the pair form + re-solve (see pb_fista_solve) */
+#define PB_FLAG_CERT_NO_RESOLVE 2048u /* diagnostic: certificate launch only; uncleared problems keep n_done = -1 */
+#define PB_FLAG_FORCE_CERT 1024u   /* PB_STOP_WINDOW, wind = 6: certificate path whatever tol * n_iter is */
 #define PB_FLAG_ONE_LAUNCH 32u    /* never split a plain solve into a full-rounds launch and a
                                      remainder launch (see pb_fista_solve) */
 
@@ -126,6 +130,16 @@ int pb_fista_plan(int N, int K, int P, int stop_mode, int wind, int* n_main, int
  *            (PB_STOP_*); n_done_dev int32 [P] receives the number of
  *            iterations executed.  PB_STOP_NONE ignores tol/wind; n_done_dev
  *            may be NULL.
+ *            PB_STOP_WINDOW with wind = 6 (the reference default), n_done_dev given and
+ *            tol * n_iter < 0.5 (the rule is not expected to fire: its criterion decays like
+ *            ~0.9/k): the problems run on the two-problems-per-row form, which PROVES per
+ *            iteration that the rule does not fire (a lower bound of its numerator from one
+ *            tracked sample per lane, an upper bound of its denominator from norms of the
+ *            iterate); problems it cannot clear come out with n_done = -1, iterate untouched,
+ *            and are re-solved at once, exactly, by a second launch of the single-row form --
+ *            results are those of the full rule either way.  PB_FLAG_NO_CERT / _FORCE_CERT
+ *            override the choice.  Other wind values, or series above 16*20 scans, evaluate the
+ *            rule in full (single-row form; LDS kernel beyond its limits).
  */
 int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep,
                    double* w_dev, int64_t ldw, int P, int N,

@@ -43,6 +43,7 @@ typedef int (*fast_launch_fn)(const pb::FistaArgs&, const double* taps, int K, b
                               int stop, hipStream_t);
 typedef int (*fast_launch_pp_fn)(const pb::FistaArgs&, int stop, hipStream_t);
 typedef int (*pair_launch_fn)(const pb::FistaArgs&, const double* taps, int K, bool with_j, hipStream_t);
+typedef int (*pair_cert_fn)(const pb::FistaArgs&, const double* taps, int K, hipStream_t);
 
 struct FastEntry {
   int S, KT;
@@ -51,6 +52,7 @@ struct FastEntry {
   pair_launch_fn fn_pair;     // two-problems-per-row kernel (S <= 20, KT <= 32 only), else nullptr
   pair_launch_fn fn_pair_ffa; // the same with 2-parallel fast FIRs (fista_pair_ffa.h)
   int (*fn_pair_dev)(const pb::FistaArgs&, hipStream_t);   // ... reading ONE shared HRF from device memory
+  pair_cert_fn fn_pair_cert;  // ... carrying the window rule (wind = 6) as a no-fire certificate
 };
 
 }  // namespace
@@ -62,7 +64,8 @@ namespace pb {
   extern template int launch_fast_pp<S, KT>(const FistaArgs&, int, hipStream_t);            \
   extern template int launch_pair<S, KT>(const FistaArgs&, const double*, int, bool, hipStream_t); \
   extern template int launch_pair_ffa<S, KT>(const FistaArgs&, const double*, int, bool, hipStream_t); \
-  extern template int launch_pair_ffa_dev<S, KT>(const FistaArgs&, hipStream_t);
+  extern template int launch_pair_ffa_dev<S, KT>(const FistaArgs&, hipStream_t);                  \
+  extern template int launch_pair_ffa_cert<S, KT>(const FistaArgs&, const double*, int, hipStream_t);
 #include "fast_table.inc"
 #undef PB_FAST
 }  // namespace pb
@@ -142,9 +145,13 @@ template <int S, int KT>
 constexpr int (*pair_dev_or_null())(const pb::FistaArgs&, hipStream_t) {
   if constexpr (S <= 20 && KT <= 32) return &pb::launch_pair_ffa_dev<S, KT>; else return nullptr;
 }
+template <int S, int KT>
+constexpr pair_cert_fn pair_cert_or_null() {
+  if constexpr (S <= 20 && KT <= 32) return &pb::launch_pair_ffa_cert<S, KT>; else return nullptr;
+}
 #define PB_FAST(S, KT)                                                                             \
   {S, KT, &pb::launch_fast<S, KT>, &pb::launch_fast_pp<S, KT>, pair_or_null<S, KT>(),             \
-   pair_ffa_or_null<S, KT>(), pair_dev_or_null<S, KT>()},
+   pair_ffa_or_null<S, KT>(), pair_dev_or_null<S, KT>(), pair_cert_or_null<S, KT>()},
 const FastEntry kFast[] = {
 #include "fast_table.inc"
 };
@@ -492,6 +499,14 @@ static const WideEntry* pick_wide_small(int N, int K) {
   return (we && we->S <= 8) ? we : nullptr;
 }
 
+// the pair form carries plain solves and, as a no-fire certificate with an exact re-solve of what
+// it cannot clear, the window rule at the reference's wind = 6 (the queries assume the tolerance
+// is small enough for that path: tol * n_iter < 0.5, see pb_fista_solve)
+static bool pair_carries(const FastEntry* fe, int stop_mode, int wind) {
+  if (stop_mode == PB_STOP_NONE) return fe->fn_pair != nullptr;
+  return stop_mode == PB_STOP_WINDOW && wind == 6 && fe->fn_pair_cert != nullptr;
+}
+
 int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mode, int wind) {
   (void)with_cost_trace;
   if (N < 1 || K < 1 || P < 1) return 0;
@@ -503,8 +518,7 @@ int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mod
     return we ? 3 : 0;
   }
   Piece pc[4];
-  plan_pieces(P, fe->fn_pair != nullptr && stop_mode == PB_STOP_NONE, pick_wide_small(N, K) != nullptr,
-              false, false, pc);
+  plan_pieces(P, pair_carries(fe, stop_mode, wind), pick_wide_small(N, K) != nullptr, false, false, pc);
   return pc[0].form;                                    // the form that carries most problems
 }
 
@@ -516,7 +530,7 @@ int pb_fista_plan(int N, int K, int P, int stop_mode, int wind, int* n_main, int
     if (fe && stop_mode == PB_STOP_WINDOW && (wind != 6 || fe->S > 20)) fe = nullptr;
     if (fe) {
       Piece pc[4];
-      const int npc = plan_pieces(P, fe->fn_pair != nullptr && stop_mode == PB_STOP_NONE,
+      const int npc = plan_pieces(P, pair_carries(fe, stop_mode, wind),
                                   pick_wide_small(N, K) != nullptr, false, false, pc);
       // leading pieces of one form = the "main" part; the first other form = the tail
       // (of several: the one that carries most of the remaining problems)
@@ -576,11 +590,23 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
   // (the reference default) on entries small enough to hold them; else LDS kernel
   if (fe && stop_mode == PB_STOP_WINDOW && (wind != 6 || fe->S > 20)) fe = nullptr;
   if (fe && (flags & PB_FLAG_FORCE_WIDE)) fe = nullptr;
+  // Window rule on the pair form: a per-iteration no-fire certificate (fista_pair_ffa.h), then an
+  // exact re-solve of the problems it could not clear (n_done = -1) on the single-row form.  Worth
+  // it when the rule is not expected to fire: the criterion decays like ~0.9/k on this problem
+  // class, so it cannot pass below tol before k ~ 0.9/tol.
+  const bool cert = fe && stop_mode == PB_STOP_WINDOW && wind == 6 && fe->fn_pair_cert && n_done_dev &&
+                    P >= 2 && !(flags & (PB_FLAG_NO_PAIR | PB_FLAG_NO_CERT | PB_FLAG_DIRECT_FIR)) &&
+                    ((flags & PB_FLAG_FORCE_CERT) || tol * (double)n_iter < 0.5);
   if (fe) {
     auto run = [&](int form, int p0, int p1) -> int {
       pb::FistaArgs b = a;
       b.p0 = p0;
       b.P = p1;
+      if (form == FORM_PAIR && cert) {
+        if (fe->fn_pair_cert(b, taps_host, K, (hipStream_t)stream) != 0)
+          return fail(PB_ERR_INVALID, "pb_fista_solve: certificate kernel rejected the launch");
+        return check_launch("fista_pair_ffa_kernel(cert)");
+      }
       if (form == FORM_PAIR) {
         const pair_launch_fn fn = (fe->fn_pair_ffa && !(flags & PB_FLAG_DIRECT_FIR)) ? fe->fn_pair_ffa
                                                                                       : fe->fn_pair;
@@ -598,27 +624,50 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
         return fail(PB_ERR_INVALID, "pb_fista_solve: no register-resident form for this stop rule");
       return check_launch("fista_fast_kernel");
     };
+    // flagged problems of the pair pieces [q0, q1): exact window rule, on `stream` (after the join)
+    auto resolve = [&](int q0, int q1) -> int {
+      if (flags & PB_FLAG_CERT_NO_RESOLVE) return PB_OK;
+      pb::FistaArgs b = a;
+      b.p0 = q0;
+      b.P = q1;
+      b.only_flagged = 1;
+      if (fe->fn(b, taps_host, K, J_dev != nullptr, PB_STOP_WINDOW, (hipStream_t)stream) != 0)
+        return fail(PB_ERR_INVALID, "pb_fista_solve: no single-row form for the re-solve");
+      return check_launch("fista_fast_kernel(re-solve)");
+    };
     if (flags & PB_FLAG_NO_PAIR) return run(FORM_FAST1, 0, P);
     if (flags & PB_FLAG_FORCE_PAIR) {
+      if (cert) {
+        const int rc = run(FORM_PAIR, 0, P);
+        return rc != PB_OK ? rc : resolve(0, P);
+      }
       if (!fe->fn_pair || P < 2 || stop_mode != PB_STOP_NONE) return run(FORM_FAST1, 0, P);
       return run(FORM_PAIR, 0, P);
     }
     // whole rounds on the densest form, the remainder on the cheapest (the pair form has no
     // stop rules; the one-problem-per-wave form has them all); a remainder that fits beside
     // half a round of pair waves runs on the side stream
-    const bool pair_ok = fe->fn_pair != nullptr && stop_mode == PB_STOP_NONE;
+    const bool pair_ok = (fe->fn_pair != nullptr && stop_mode == PB_STOP_NONE) || cert;
     Piece pc[4];
     const bool one_stream = (flags & PB_FLAG_ONE_STREAM) != 0 || stream_is_capturing((hipStream_t)stream);
     const int npc = plan_pieces(P, pair_ok, pick_wide_small(N, K) != nullptr,
                                 (flags & PB_FLAG_ONE_LAUNCH) != 0, one_stream, pc);
     bool any_side = false;
-    for (int i = 0; i < npc; ++i) any_side |= pc[i].side;
+    int q0 = P, q1 = 0;                          // range covered by the pair pieces (contiguous)
+    for (int i = 0; i < npc; ++i) {
+      any_side |= pc[i].side;
+      if (pc[i].form == FORM_PAIR) {
+        q0 = pc[i].p0 < q0 ? pc[i].p0 : q0;
+        q1 = pc[i].p1 > q1 ? pc[i].p1 : q1;
+      }
+    }
+    auto finish = [&](int rc) -> int { return (rc == PB_OK && cert && q1 > q0) ? resolve(q0, q1) : rc; };
     if (!any_side) {
       for (int i = 0; i < npc; ++i) {
         const int rc = run(pc[i].form, pc[i].p0, pc[i].p1);
         if (rc != PB_OK) return rc;
       }
-      return PB_OK;
+      return finish(PB_OK);
     }
     std::lock_guard<std::mutex> lock(g_side_mutex);
     SideStream* ss = side_stream_locked();
@@ -627,7 +676,7 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
         const int rc = run(pc[i].form, pc[i].p0, pc[i].p1);
         if (rc != PB_OK) return rc;
       }
-      return PB_OK;
+      return finish(PB_OK);
     }
     hipStream_t user = (hipStream_t)stream;
     int rc_all = PB_OK;
@@ -642,11 +691,11 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
       rc_all = run(pc[i].form, pc[i].p0, pc[i].p1);
     }
     stream = (void*)user;
-    if (!forked) return rc_all;
+    if (!forked) return finish(rc_all);
     // join even after an error so that the caller's stream never runs ahead of the side stream
     if (hipEventRecord(ss->join, ss->stream) != hipSuccess || hipStreamWaitEvent(user, ss->join, 0) != hipSuccess)
       return fail(PB_ERR_HIP, "pb_fista_solve: join of the side stream failed");
-    return rc_all;
+    return finish(rc_all);
   }
   // long series: one problem per wave (window rule: wind = 6 and S <= 20, as above)
   if (!(flags & PB_FLAG_FORCE_GENERIC)) {

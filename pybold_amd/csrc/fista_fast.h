@@ -61,6 +61,8 @@ struct FistaArgs {
   int stop_mode;
   int K;                  // number of taps actually used (<= KT)
   int cold;               // 1: the iterate starts from 0, a.w is written only
+  int only_flagged = 0;   // 1: solve only the problems with n_done[p] < 0 (left by the certificate
+                          //    form of the pair kernel, fista_pair_ffa.h), skip the others
 };
 
 // Tap pairs as kernel arguments (read with scalar loads, kept in SGPRs).
@@ -111,9 +113,17 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int sub = threadIdx.x & (LPV - 1);  // lane within the problem's segment
   const int prob = (int)(gid / LPV) + a.p0;
-  const bool live = prob < a.P;
+  bool live = prob < a.P;
   const int p = live ? prob : a.P - 1;
   const int base = sub * S;
+  if constexpr (STOP == 2) {
+    // re-solve pass behind the certificate kernel: only flagged problems; a wave none of whose
+    // rows is flagged leaves at once (no barrier anywhere in this kernel)
+    if (a.only_flagged) {
+      live = live && a.n_done[p] < 0;
+      if (__builtin_amdgcn_ballot_w64(live) == 0) return;
+    }
+  }
 
   // ---- load the problem: y strip (fp32), w strip (fp64) -------------------
   float y[S];

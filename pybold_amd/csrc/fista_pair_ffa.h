@@ -30,6 +30,9 @@
 
 namespace pb {
 
+constexpr int PAIR_LJ = 12;          // floats of per-row scratch behind the staging regions
+constexpr int PAIR_LC = 16;          // CERT: floats of per-lane scratch behind that
+
 // taps as (h0[k], h1[k]) pairs and the sums hs[k] = h0[k] + h1[k] packed two per SGPR pair
 template <int KT>
 struct TapsFFA {
@@ -55,8 +58,29 @@ inline TapsFFA<KT> make_taps_ffa(const double* taps, int K) {
 // every problem, a.step_vec[0]) instead of the kernel arguments -- the shared-HRF blind step,
 // whose taps come out of pb_theta_fit without passing through the host.  Uniform loads: the
 // taps still end up in SGPRs.
-template <int S, int KT, bool WITH_J = false, bool SKIP0 = false, bool WB_LDS = false, bool TAPS_DEV = false>
+//
+// CERT: the deconv window rule (wind = 6, pybold/bold_signal.py:82-95) as a per-iteration
+// NO-FIRE CERTIFICATE.  The rule stops when  ||3(new - old)|| / (||3 new|| + 3e-10) < tol  with
+//   3 (new - old) = delta_{k-3} + 2 delta_{k-2} + 3 delta_{k-1} + 2 delta_k + e,   3 new = u_{k-1} + u_k + w_{k+1}
+// (delta_i = u_i - u_{i-1}, e = w_{k+1} - u_k; fista_fast.h).  Its full evaluation needs the last
+// four increments of EVERY sample (no room for them at this density); a proof that it does NOT
+// fire needs much less:
+//   numerator   >= the same combination on ONE tracked sample per lane (16 of the 16 S samples:
+//                  its increment history lives in 5 registers per problem), less its rounding;
+//   denominator <= ||w_k|| + 2 ||w_{k+1}|| + 4 th sqrt(N)      since u_i = w_{i+1} + (1+beta_i) d_i
+//                  with |d_i| <= th elementwise; the two norms come out of the cumsum pass.
+// Squared and split with Cauchy-Schwarz weights p = (0.3133, 0.6467, 0.04) (2 % loose when the two
+// norms agree), the test becomes ONE row sum per problem and iteration of lane partials:
+//   sum_lanes [ v_lane^2 - tol^2 (||w_k||^2_lane / p1 + 4 ||w_{k+1}||^2_lane / p2) ]  >=  tol^2 c0^2 / p3.
+// A problem whose certificate fails at some iteration (the rule may or may not have fired) is
+// FLAGGED: its iterate is not stored and n_done[p] = -1; the caller re-solves the flagged
+// problems exactly on fista_fast_kernel<..., STOP = 2> (capi.hip).  On the reference's default
+// tol = 1e-6 the criterion stays ~0.9/k and the bound is ~4x below it: nothing is flagged.
+// Implies the rotated loop of WITH_J; the cost trace itself is written only if a.J != nullptr.
+template <int S, int KT, bool WITH_J = false, bool SKIP0 = false, bool WB_LDS = false, bool TAPS_DEV = false,
+          bool CERT = false>
 __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, TapsFFA<KT> taps_arg) {
+  static_assert(!CERT || WITH_J, "the certificate runs in the rotated (cost trace) loop");
   constexpr int H = KT - 1;
   constexpr int D = (H + S - 1) / S;
   constexpr int KE = (KT + 1) / 2;          // taps per phase
@@ -86,8 +110,9 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
   constexpr size_t R2 = WB_LDS ? sizeof(double) : sizeof(float);
   float* stage_f = reinterpret_cast<float*>(pair_smem + (size_t)16 * S * 16 * sizeof(f2)) +
                    (WB_LDS ? 2 : 1) * rslot;
+  // per row: [0,1] lambda, [2,3] ||w||_1, CERT: [10,11] tol^2 c0^2 / p3
   float* lj = reinterpret_cast<float*>(pair_smem + (size_t)16 * S * 16 * (sizeof(f2) + R2)) +
-              (threadIdx.x >> 4) * 4;
+              (threadIdx.x >> 4) * PAIR_LJ;
   auto lds_sync = [] {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -166,10 +191,32 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
     lj[0] = (float)lbA;
     lj[1] = (float)lbB;
   }
+  // CERT: c0 = 4 th sqrt(16 S) >= 4 th sqrt(N), rounded up, + the rule's 3e-10 floor
+  constexpr float CP1 = 0.3133f, CP2 = 0.6467f, CP3 = 0.04f;
+  const float cert_t2 = ((float)a.tol * 1.001f) * ((float)a.tol * 1.001f);
+  if constexpr (CERT) {
+    const float cert_sq = 16.0f * 1.0001f * __builtin_sqrtf((float)S);
+    const float c0A = (float)thA * cert_sq + 3.1e-10f, c0B = (float)thB * cert_sq + 3.1e-10f;
+    lj[10] = cert_t2 * c0A * c0A * (1.0001f / CP3);
+    lj[11] = cert_t2 * c0B * c0B * (1.0001f / CP3);
+  }
+  int cert_it = -1;                         // iteration whose certificate the next forward pass closes
   // samples that can be padding in SOME lane: j >= jpad (uniform); sample j of this lane is
   // real iff j < jlim = N - base, i.e. mask = saturate(jlim - j) as a float
   const int jpad = (a.N - 15 * S > 0) ? a.N - 15 * S : 0;
   const float jlimf = (float)(a.N - base);
+  // CERT state, per lane, in LDS behind the per-row scratch (slot-major: conflict-free b32
+  // accesses; each lane touches only its own words): [0..7] ring of the tracked sample's last
+  // four increments (float32, slot = 2 (k mod 4) + problem), [8..11] its u_{k-1} (float64 halves),
+  // [12,13] v^2 of this lane, [14,15] this lane's part of ||w_k||^2
+  constexpr int JT = S / 2;
+  float* lc = reinterpret_cast<float*>(pair_smem + (size_t)16 * S * 16 * (sizeof(f2) + R2)) + 16 * PAIR_LJ +
+              threadIdx.x;
+  if constexpr (CERT) {
+#pragma unroll
+    for (int q = 0; q < PAIR_LC; ++q) lc[q * 256] = 0.0f;
+  }
+  bool flagA = false, flagB = false;
 
   auto tap0 = [&](auto kc) -> f2 { return taps.pr[decltype(kc)::value].xx; };
   auto tap1 = [&](auto kc) -> f2 { return taps.pr[decltype(kc)::value].yy; };
@@ -191,16 +238,36 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
       }
       z[0] = f2{(float)wA[0], (float)wb[0]};
       if constexpr (WITH_J) {
+        // CERT: the lane partials and the limit are read here, a cumsum away from their use
+        f2 c_vsq, c_wp, c_lim;
+        if constexpr (CERT) {
+          c_vsq = f2{lc[12 * 256], lc[13 * 256]};
+          c_wp = f2{lc[14 * 256], lc[15 * 256]};
+          c_lim = f2{lj[10], lj[11]};
+          asm volatile("" : "+v"(c_vsq), "+v"(c_wp), "+v"(c_lim));     // issued here, not sunk to the use
+        }
         float l1a = fabsf(z[0].x), l1b = fabsf(z[0].y);
+        f2 sq = z[0] * z[0];
 #pragma unroll
         for (int j = 1; j < S; ++j) {
           const f2 wj = f2{(float)wA[j], (float)wb[j]};
           z[j] = z[j - 1] + wj;
           l1a += fabsf(wj.x);
           l1b += fabsf(wj.y);
+          if constexpr (CERT) sq = __builtin_elementwise_fma(wj, wj, sq);
         }
         lj[2] = row_allsum(l1a);
         lj[3] = row_allsum(l1b);
+        if constexpr (CERT) {
+          // close the certificate of iteration cert_it (the rule is first tested at wind + 1 = 7)
+          const f2 t = c_vsq - cert_t2 * ((1.0001f / CP1) * c_wp + (4.0001f / CP2) * sq);
+          const float tA = row_allsum(t.x), tB = row_allsum(t.y);
+          const bool chk = cert_it >= 7;
+          flagA = flagA | (chk & !(tA >= c_lim.x));   // NaN-safe: anything unclear is flagged
+          flagB = flagB | (chk & !(tB >= c_lim.y));
+          lc[14 * 256] = sq.x;
+          lc[15 * 256] = sq.y;
+        }
       } else {
 #pragma unroll
         for (int j = 1; j < S; ++j) z[j] = z[j - 1] + f2{(float)wA[j], (float)wb[j]};
@@ -375,6 +442,20 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
     // ---- gradient step, prox, momentum (float64), per problem ------------------
     const double nb1 = -(1.0 + beta);
     {
+      // CERT: the tracked sample's history is read here, the float64 update away from its use
+      f2 c_d1, c_d2, c_d3;
+      unsigned c_u[4];
+      if constexpr (CERT) {
+        const float* r1 = lc + ((cert_it + 3) & 3) * 512;
+        const float* r2 = lc + ((cert_it + 2) & 3) * 512;
+        const float* r3 = lc + ((cert_it + 1) & 3) * 512;
+        c_d1 = f2{r1[0], r1[256]};
+        c_d2 = f2{r2[0], r2[256]};
+        c_d3 = f2{r3[0], r3[256]};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c_u[q] = __builtin_bit_cast(unsigned, lc[(8 + q) * 256]);
+        asm volatile("" : "+v"(c_d1), "+v"(c_d2), "+v"(c_d3), "+v"(c_u[0]), "+v"(c_u[1]), "+v"(c_u[2]), "+v"(c_u[3]));
+      }
       double uA[S], uB[S], dA[S], dB[S];
 #pragma unroll
       for (int j = 0; j < S; ++j) {
@@ -395,10 +476,44 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
         dA[j] = fmin(dA[j], thA);
         dB[j] = fmin(dB[j], thB);
       }
+      double wnB_t = 0.0;
 #pragma unroll
       for (int j = 0; j < S; ++j) {
         wA[j] = fma(nb1, dA[j], uA[j]);
-        if constexpr (WB_LDS) lw[j * 16] = fma(nb1, dB[j], uB[j]); else wBr[j] = fma(nb1, dB[j], uB[j]);
+        const double wnB = fma(nb1, dB[j], uB[j]);
+        if constexpr (WB_LDS) lw[j * 16] = wnB; else wBr[j] = wnB;
+        if (CERT && j == JT) wnB_t = wnB;
+      }
+      if constexpr (CERT) {
+        // the window combination on the tracked sample of this lane, both problems (float32 from
+        // float64 differences; its rounding, and that of the stored increments, is below 2^-21 M)
+        auto st_d = [&](int q, double v) {
+          const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+          lc[q * 256] = __builtin_bit_cast(float, (unsigned)b);
+          lc[(q + 1) * 256] = __builtin_bit_cast(float, (unsigned)(b >> 32));
+        };
+        float* r0 = lc + (cert_it & 3) * 512;
+        const f2 d1 = c_d1, d2 = c_d2, d3 = c_d3;
+        const double upA = __builtin_bit_cast(double, ((unsigned long long)c_u[1] << 32) | c_u[0]);
+        const double upB = __builtin_bit_cast(double, ((unsigned long long)c_u[3] << 32) | c_u[2]);
+        const f2 dk = f2{(float)(uA[JT] - upA), (float)(uB[JT] - upB)};
+        const f2 e = f2{(float)(wA[JT] - uA[JT]), (float)(wnB_t - uB[JT])};
+        const f2 two = f2{2.f, 2.f}, three = f2{3.f, 3.f};
+        f2 v = __builtin_elementwise_fma(two, dk, e);
+        v = __builtin_elementwise_fma(three, d1, v);
+        v = __builtin_elementwise_fma(two, d2, v) + d3;
+        f2 m = __builtin_elementwise_fma(two, __builtin_elementwise_abs(dk), __builtin_elementwise_abs(e));
+        m = __builtin_elementwise_fma(three, __builtin_elementwise_abs(d1), m);
+        m = __builtin_elementwise_fma(two, __builtin_elementwise_abs(d2), m) + __builtin_elementwise_abs(d3);
+        f2 vs = __builtin_elementwise_fma(f2{-0x1p-21f, -0x1p-21f}, m, __builtin_elementwise_abs(v));
+        vs = __builtin_elementwise_max(vs, f2{0.f, 0.f});
+        vs = vs * vs;
+        lc[12 * 256] = vs.x;
+        lc[13 * 256] = vs.y;
+        r0[0] = dk.x;
+        r0[256] = dk.y;
+        st_d(8, uA[JT]);
+        st_d(10, uB[JT]);
       }
     }
   };
@@ -415,6 +530,7 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
     forward(r);
     for (int it = 0; it < a.n_iter; ++it) {
       const double beta = a.betas[it];
+      cert_it = it;
       backward(r, beta);
       forward(r);
       f2 sq = r[0] * r[0];
@@ -422,9 +538,11 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
       for (int j = 1; j < S; ++j) sq = __builtin_elementwise_fma(r[j], r[j], sq);
       const float cA = fmaf(0.5f, row_allsum(sq.x), lj[0] * lj[2]);
       const float cB = fmaf(0.5f, row_allsum(sq.y), lj[1] * lj[3]);
-      if (sub == 0) {
-        if (liveA) a.J[(int64_t)pA * a.ldj + it] = cA;
-        if (liveB) a.J[(int64_t)pB * a.ldj + it] = cB;
+      // (a flagged problem stops tracing: it was flagged no later than the iteration its rule
+      // fires at, so the re-solve rewrites everything written here and nothing beyond its stop)
+      if (sub == 0 && (!CERT || a.J != nullptr)) {
+        if (liveA && !flagA) a.J[(int64_t)pA * a.ldj + it] = cA;
+        if (liveB && !flagB) a.J[(int64_t)pB * a.ldj + it] = cB;
       }
     }
   }
@@ -448,11 +566,11 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
       }
     }
   };
-  store_w(wA, a.w + (int64_t)pA * a.ldw, liveA);
-  store_w(wBf, a.w + (int64_t)pB * a.ldw, liveB);
+  store_w(wA, a.w + (int64_t)pA * a.ldw, liveA && !flagA);
+  store_w(wBf, a.w + (int64_t)pB * a.ldw, liveB && !flagB);
   if (a.n_done && sub == 0) {
-    if (liveA) a.n_done[pA] = a.n_iter;
-    if (liveB) a.n_done[pB] = a.n_iter;
+    if (liveA) a.n_done[pA] = flagA ? -1 : a.n_iter;
+    if (liveB) a.n_done[pB] = flagB ? -1 : a.n_iter;
   }
 }
 
@@ -462,8 +580,22 @@ int launch_pair_ffa_dev(const FistaArgs& a, hipStream_t st) {
   const TapsFFA<KT> none{};
   const int64_t rows = ((int64_t)(a.P - a.p0) + 1) / 2;
   const dim3 grid((unsigned)((rows * 16 + 255) / 256)), block(256);
-  const size_t lds = (size_t)16 * S * 16 * (sizeof(f2) + sizeof(float)) + 16 * 4 * sizeof(float);
+  const size_t lds = (size_t)16 * S * 16 * (sizeof(f2) + sizeof(float)) + 16 * PAIR_LJ * sizeof(float);
   hipLaunchKernelGGL((fista_pair_ffa_kernel<S, KT, false, false, false, true>), grid, block, lds, st, a, none);
+  return 0;
+}
+
+// window rule (wind = 6) as a no-fire certificate; flagged problems come back with n_done = -1
+template <int S, int KT>
+int launch_pair_ffa_cert(const FistaArgs& a, const double* taps, int K, hipStream_t st) {
+  if (!a.n_done) return 1;
+  const auto tf = make_taps_ffa<KT>(taps, K);
+  const int64_t rows = ((int64_t)(a.P - a.p0) + 1) / 2;
+  const dim3 grid((unsigned)((rows * 16 + 255) / 256)), block(256);
+  const size_t lds = (size_t)16 * S * 16 * (sizeof(f2) + sizeof(float)) + (16 * PAIR_LJ + 256 * PAIR_LC) * sizeof(float);
+  const bool skip0 = KT > 1 && tf.pr[0].x == 0.0f;
+  if (skip0) hipLaunchKernelGGL((fista_pair_ffa_kernel<S, KT, true, true, false, false, true>), grid, block, lds, st, a, tf);
+  else hipLaunchKernelGGL((fista_pair_ffa_kernel<S, KT, true, false, false, false, true>), grid, block, lds, st, a, tf);
   return 0;
 }
 
@@ -472,7 +604,7 @@ int launch_pair_ffa(const FistaArgs& a, const double* taps, int K, bool with_j, 
   const auto tf = make_taps_ffa<KT>(taps, K);
   const int64_t rows = ((int64_t)(a.P - a.p0) + 1) / 2;
   const dim3 grid((unsigned)((rows * 16 + 255) / 256)), block(256);
-  const size_t lds = (size_t)16 * S * 16 * (sizeof(f2) + sizeof(float)) + 16 * 4 * sizeof(float);
+  const size_t lds = (size_t)16 * S * 16 * (sizeof(f2) + sizeof(float)) + 16 * PAIR_LJ * sizeof(float);
   const bool skip0 = KT > 1 && tf.pr[0].x == 0.0f;      // leading tap exactly zero
   if (with_j && skip0) hipLaunchKernelGGL((fista_pair_ffa_kernel<S, KT, true, true>), grid, block, lds, st, a, tf);
   else if (with_j) hipLaunchKernelGGL((fista_pair_ffa_kernel<S, KT, true, false>), grid, block, lds, st, a, tf);

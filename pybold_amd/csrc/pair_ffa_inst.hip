@@ -8,5 +8,6 @@ namespace pb {
 #if PB_S <= 20 && PB_KT <= 32
 template int launch_pair_ffa<PB_S, PB_KT>(const FistaArgs&, const double*, int, bool, hipStream_t);
 template int launch_pair_ffa_dev<PB_S, PB_KT>(const FistaArgs&, hipStream_t);
+template int launch_pair_ffa_cert<PB_S, PB_KT>(const FistaArgs&, const double*, int, hipStream_t);
 #endif
 }

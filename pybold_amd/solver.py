@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (PB_FLAG_COLD_START, PB_FLAG_DIRECT_FIR, PB_FLAG_ONE_STREAM, PB_FLAG_FORCE_FAST, PB_FLAG_FORCE_GENERIC, PB_FLAG_FORCE_PAIR, PB_FLAG_FORCE_WIDE,
+from ._lib import (PB_FLAG_COLD_START, PB_FLAG_NO_CERT, PB_FLAG_FORCE_CERT, PB_FLAG_DIRECT_FIR, PB_FLAG_ONE_STREAM, PB_FLAG_FORCE_FAST, PB_FLAG_FORCE_GENERIC, PB_FLAG_FORCE_PAIR, PB_FLAG_FORCE_WIDE,
                    PB_FLAG_NO_PAIR, PB_FLAG_ONE_LAUNCH, PB_STOP_LOOPS, PB_STOP_NONE, PB_STOP_WINDOW)
 
 _STOP = {None: PB_STOP_NONE, "none": PB_STOP_NONE, "loops": PB_STOP_LOOPS,
@@ -25,7 +25,12 @@ _FORCE = {None: 0, "generic": PB_FLAG_FORCE_GENERIC, "fast": PB_FLAG_FORCE_FAST,
           "fast2d": PB_FLAG_FORCE_FAST | PB_FLAG_FORCE_PAIR | PB_FLAG_ONE_LAUNCH | PB_FLAG_DIRECT_FIR,
           "direct": PB_FLAG_DIRECT_FIR,
           "wide": PB_FLAG_FORCE_FAST | PB_FLAG_FORCE_WIDE | PB_FLAG_ONE_LAUNCH,
-          "one": PB_FLAG_ONE_LAUNCH, "seq": PB_FLAG_ONE_STREAM}
+          "one": PB_FLAG_ONE_LAUNCH, "seq": PB_FLAG_ONE_STREAM,
+          # window rule: "cert" = no-fire certificate on the pair form + exact re-solve whatever
+          # tol * n_iter is; "nocert" = always the full rule (single-row form)
+          "cert": PB_FLAG_FORCE_CERT, "cert2": PB_FLAG_FORCE_CERT | PB_FLAG_FORCE_PAIR | PB_FLAG_ONE_LAUNCH,
+          "certonly": PB_FLAG_FORCE_CERT | PB_FLAG_FORCE_PAIR | PB_FLAG_ONE_LAUNCH | _lib.PB_FLAG_CERT_NO_RESOLVE,
+          "nocert": PB_FLAG_NO_CERT}
 
 
 def device(dev=None):

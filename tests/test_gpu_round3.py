@@ -1,0 +1,161 @@
+"""GPU tests of the round-3 additions, all through the C ABI: the deconv window rule carried on
+the two-problems-per-row kernel as a no-fire certificate with an exact re-solve of the problems
+it cannot clear (pybold/bold_signal.py:82-95; include/pybold_hip.h, pb_fista_solve)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pybold_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+EPS = 1.0e-5
+
+
+def rel_rows(a, b):
+    a, b = np.atleast_2d(a), np.atleast_2d(b)
+    return (np.linalg.norm(a - b, axis=1) / (np.linalg.norm(b, axis=1) + 1e-300)).max()
+
+
+def dev32(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def dev64(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+
+
+@pytest.fixture(scope="module")
+def solver():
+    from pybold_amd import solver
+    assert torch.cuda.is_available()
+    return solver
+
+
+def synthetic(n_vox, seed, n=300):
+    from pybold_amd import data
+    from pybold_amd.hrf_model import spm_hrf
+    hrf = spm_hrf(1.0, t_r=1.0, dur=30.0)[0]
+    Y, _, _ = data.gen_rnd_bloc_bold_batch(n_vox, dur=n / 60.0, tr=1.0, hrf=hrf, nb_events=5, avg_dur=12.0,
+                                           std_dur=1.0, snr=1.0, seed=seed, device=torch.device("cuda"))
+    return Y, hrf
+
+
+def oracle_window(Yh, hrf, lbda, lip, n_iter, tol, w0=None):
+    out = [orc.deconv_fixed_lbda(Yh[v], hrf, lbda, nb_iter=n_iter, tol=tol, lipschitz=lip, dense=False,
+                                 w0=None if w0 is None else w0[v]) for v in range(len(Yh))]
+    return np.stack([o[2] for o in out]), np.array([o[4] for o in out]), [o[3] for o in out]
+
+
+@pytest.mark.parametrize("force", ["cert", "cert2"])
+def test_certificate_half_fire_half_never(solver, golden, force):
+    """A batch where about half of the voxels meet the window rule before n_iter and the others
+    never do, forced through the certificate path: stop iterations, iterates and cost traces
+    equal the float64 oracle's; the rows whose rule never fires are bit-identical to the plain
+    solve of the same kernel form (the certificate only watches)."""
+    g = golden("early_stop")
+    hrf, lip = g["hrf"], float(g["lipschitz"])
+    Y, _ = synthetic(37, seed=5)                      # odd count: a lone problem in the last row
+    Y[3] = 0.0                                        # y = 0: criterion 0/0 -> fires at the first test
+    Y[20] = torch.from_numpy(g["y"]).float().cuda()   # golden series: fires at 191 for tol = 0.01
+    tol = 0.01
+    Yh = Y.cpu().numpy().astype(np.float64)
+    _, n_fire, _ = oracle_window(Yh, hrf, 1.0, lip, 400, tol)      # where each voxel's rule fires
+    assert n_fire[20] == 191 and n_fire[3] == 8
+    n_iter = int(np.median(n_fire))                                # about half fire before n_iter
+    Wr, nr, Jr = oracle_window(Yh, hrf, 1.0, lip, n_iter, tol)
+    fired = n_fire < n_iter
+    assert 8 <= fired.sum() <= 29, fired.sum()                     # a real mix
+    assert (nr == np.minimum(n_fire, n_iter)).all()
+    W, J, nd = solver.fista_solve(Y, hrf, 1.0, 1.0 / lip, n_iter, want_J=True, stop="window", tol=tol,
+                                  wind=6, force=force)
+    nd = nd.cpu().numpy()
+    assert (nd == nr).all(), np.flatnonzero(nd != nr)
+    Wn, Jn = W.cpu().numpy(), J.cpu().numpy()
+    live = np.linalg.norm(Wr, axis=1) > 0
+    assert rel_rows(Wn[live], Wr[live]) < EPS
+    assert np.abs(Wn[~live]).max() == 0.0
+    for v in range(len(Yh)):
+        assert np.isfinite(Jn[v, :nd[v]]).all() and np.isnan(Jn[v, nd[v]:]).all(), v
+        if live[v]:
+            # the oracle's trace is normalised by J[0] like the reference's (bold_signal.py:97)
+            np.testing.assert_allclose(Jn[v, :nd[v]] / Jn[v, 0], Jr[v], rtol=5e-5)
+    # the never-firing rows against the plain solve (so close to firing, some of them were flagged
+    # and re-solved on the single-row form, whose direct FIRs round differently: not bitwise here;
+    # test_default_tolerance_runs_on_the_pair_form holds the bitwise claim)
+    Wp, Jp, _ = solver.fista_solve(Y, hrf, 1.0, 1.0 / lip, n_iter, want_J=True, force="fast2")
+    keep = np.flatnonzero(~fired)
+    assert rel_rows(Wn[keep], Wp.cpu().numpy()[keep]) < 1e-6
+
+
+def test_certificate_warm_start_and_per_problem_lambda(solver, golden):
+    """Flagged problems restart from the caller's warm start (the certificate kernel leaves
+    their iterate untouched), with y_rep > 1 and one lambda per problem."""
+    g = golden("early_stop")
+    hrf, lip = g["hrf"], float(g["lipschitz"])
+    Y, _ = synthetic(6, seed=11)
+    y_rep = 3
+    lbda = np.tile(np.array([0.3, 1.0, 3.0]), 6)
+    rng = np.random.RandomState(3)
+    W0 = 0.01 * rng.randn(18, 300)
+    tol = 0.012
+    Yh = np.repeat(Y.cpu().numpy().astype(np.float64), y_rep, axis=0)
+    n_fire = np.array([orc.deconv_fixed_lbda(Yh[p], hrf, lbda[p], nb_iter=400, tol=tol, lipschitz=lip, dense=False,
+                                             w0=W0[p])[4] for p in range(18)])
+    n_iter = int(np.median(n_fire))
+    out = [orc.deconv_fixed_lbda(Yh[p], hrf, lbda[p], nb_iter=n_iter, tol=tol, lipschitz=lip, dense=False,
+                                 w0=W0[p]) for p in range(18)]
+    Wr, nr = np.stack([o[2] for o in out]), np.array([o[4] for o in out])
+    assert 4 <= (n_fire < n_iter).sum() <= 14
+    W, J, nd = solver.fista_solve(Y, hrf, lbda, 1.0 / lip, n_iter, W0=dev64(W0), want_J=True, stop="window",
+                                  tol=tol, wind=6, y_rep=y_rep, force="cert")
+    assert (nd.cpu().numpy() == nr).all()
+    assert rel_rows(W.cpu().numpy(), Wr) < EPS
+
+
+def test_default_tolerance_runs_on_the_pair_form(solver, golden):
+    """The reference defaults (tol = 1e-6, wind = 6, 1000 iterations): the library picks the
+    certificate path by itself, nothing fires, and the result is bit-identical to the plain
+    solve with cost trace; n_done = n_iter everywhere.  Larger batch: several pieces (whole
+    rounds on the pair form, a remainder on other forms)."""
+    g = golden("early_stop")
+    hrf, lip = g["hrf"], float(g["lipschitz"])
+    assert "two problems per row" in solver.which_kernel(300, 30, 20000, stop="window", wind=6)
+    Y, _ = synthetic(20000, seed=2)
+    n_iter = 300
+    W, J, nd = solver.fista_solve(Y, hrf, 1.0, 1.0 / lip, n_iter, want_J=True, stop="window", tol=1e-6, wind=6)
+    assert int(nd.min()) == n_iter and int(nd.max()) == n_iter
+    Wp, Jp, _ = solver.fista_solve(Y, hrf, 1.0, 1.0 / lip, n_iter, want_J=True)
+    assert torch.equal(W, Wp) and torch.equal(J, Jp)
+    # and against the full rule evaluated on the single-row form
+    Wn, Jn, ndn = solver.fista_solve(Y[:4096], hrf, 1.0, 1.0 / lip, n_iter, want_J=True, stop="window",
+                                     tol=1e-6, wind=6, force="nocert")
+    assert int(ndn.min()) == n_iter
+    assert rel_rows(W[:4096].cpu().numpy(), Wn.cpu().numpy()) < 1e-6
+    # the golden default run (1000 iterations, the rule never fires): pinned to the reference
+    Wg, _, ndg = solver.fista_solve(dev32(np.stack([g["y"]] * 4)), hrf, 1.0, 1.0 / lip, 1000, want_J=True,
+                                    stop="window", tol=1e-6, wind=6)
+    assert (ndg.cpu().numpy() == int(g["n_default"])).all()
+    assert rel_rows(Wg.cpu().numpy(), np.stack([g["dz_default"]] * 4)) < EPS
+
+
+def test_certificate_is_tight_enough_to_be_useful(solver, golden):
+    """At tol = 1e-4 with 1000 iterations (criterion ~ 9e-4 at the end) the certificate must
+    still clear every problem of a realistic batch: same result as the full rule, and -- the
+    point -- no slower path taken silently (n_done = n_iter for all is necessary for that)."""
+    g = golden("early_stop")
+    hrf, lip = g["hrf"], float(g["lipschitz"])
+    Y, _ = synthetic(512, seed=7)
+    W, _, nd = solver.fista_solve(Y, hrf, 1.0, 1.0 / lip, 1000, want_J=True, stop="window", tol=1e-4, wind=6,
+                                  force="cert2")
+    Wn, _, ndn = solver.fista_solve(Y, hrf, 1.0, 1.0 / lip, 1000, want_J=True, stop="window", tol=1e-4, wind=6,
+                                    force="nocert")
+    assert (nd == ndn).all() and int(nd.min()) == 1000
+    assert rel_rows(W.cpu().numpy(), Wn.cpu().numpy()) < 1e-6
+    # diagnostic form without the re-solve: flagged problems keep n_done = -1
+    _, _, ndc = solver.fista_solve(Y, hrf, 1.0, 1.0 / lip, 1000, want_J=True, stop="window", tol=1e-4, wind=6,
+                                   force="certonly")
+    assert int((ndc < 0).sum()) == 0
+    _, _, ndc = solver.fista_solve(Y, hrf, 1.0, 1.0 / lip, 1000, want_J=True, stop="window", tol=2e-3, wind=6,
+                                   force="certonly")
+    assert int((ndc < 0).sum()) == 512               # the rule does fire here (~0.9/k): everything is flagged

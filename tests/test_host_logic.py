@@ -161,7 +161,9 @@ def test_launch_plan_of_a_plain_solve():
               29000: (24576, pair, row), 50000: (49152, pair, wave), 100000: (98304, pair, wave)}
     for P, want in expect.items():
         assert solver.launch_plan(300, 30, P) == want, P
-    # stop rules never use the pair form; shapes outside the tables go to the LDS kernel
-    n_main, main, tail = solver.launch_plan(300, 30, 100000, stop="window")
+    # the window rule at the reference's wind = 6 rides the pair form (no-fire certificate +
+    # re-solve); the _loops_deconv rule does not; shapes outside the tables go to the LDS kernel
+    assert solver.launch_plan(300, 30, 100000, stop="window") == (98304, pair, wave)
+    n_main, main, tail = solver.launch_plan(300, 30, 100000, stop="loops")
     assert main in (None, row) and tail in (row, wave)
     assert solver.launch_plan(5000, 30, 100) == (0, None, solver.KERNEL_NAMES[0])
