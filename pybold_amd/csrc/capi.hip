@@ -44,6 +44,7 @@ typedef int (*fast_launch_fn)(const pb::FistaArgs&, const double* taps, int K, b
 typedef int (*fast_launch_pp_fn)(const pb::FistaArgs&, int stop, hipStream_t);
 typedef int (*pair_launch_fn)(const pb::FistaArgs&, const double* taps, int K, bool with_j, hipStream_t);
 typedef int (*pair_cert_fn)(const pb::FistaArgs&, const double* taps, int K, hipStream_t);
+typedef int (*pair_split_fn)(const pb::FistaArgs&, const double* taps, int K, bool with_j, bool cert, hipStream_t);
 
 struct FastEntry {
   int S, KT;
@@ -53,6 +54,7 @@ struct FastEntry {
   pair_launch_fn fn_pair_ffa; // the same with 2-parallel fast FIRs (fista_pair_ffa.h)
   int (*fn_pair_dev)(const pb::FistaArgs&, hipStream_t);   // ... reading ONE shared HRF from device memory
   pair_cert_fn fn_pair_cert;  // ... carrying the window rule (wind = 6) as a no-fire certificate
+  pair_split_fn fn_pair_split; // ... ONE series of 16 S < N <= 32 S scans per row (its halves in the two slots)
 };
 
 }  // namespace
@@ -65,7 +67,8 @@ namespace pb {
   extern template int launch_pair<S, KT>(const FistaArgs&, const double*, int, bool, hipStream_t); \
   extern template int launch_pair_ffa<S, KT>(const FistaArgs&, const double*, int, bool, hipStream_t); \
   extern template int launch_pair_ffa_dev<S, KT>(const FistaArgs&, hipStream_t);                  \
-  extern template int launch_pair_ffa_cert<S, KT>(const FistaArgs&, const double*, int, hipStream_t);
+  extern template int launch_pair_ffa_cert<S, KT>(const FistaArgs&, const double*, int, hipStream_t); \
+  extern template int launch_pair_ffa_split<S, KT>(const FistaArgs&, const double*, int, bool, bool, hipStream_t);
 #include "fast_table.inc"
 #undef PB_FAST
 }  // namespace pb
@@ -149,9 +152,14 @@ template <int S, int KT>
 constexpr pair_cert_fn pair_cert_or_null() {
   if constexpr (S <= 20 && KT <= 32) return &pb::launch_pair_ffa_cert<S, KT>; else return nullptr;
 }
+template <int S, int KT>
+constexpr pair_split_fn pair_split_or_null() {
+  if constexpr (S <= 20 && KT <= 32) return &pb::launch_pair_ffa_split<S, KT>; else return nullptr;
+}
 #define PB_FAST(S, KT)                                                                             \
   {S, KT, &pb::launch_fast<S, KT>, &pb::launch_fast_pp<S, KT>, pair_or_null<S, KT>(),             \
-   pair_ffa_or_null<S, KT>(), pair_dev_or_null<S, KT>(), pair_cert_or_null<S, KT>()},
+   pair_ffa_or_null<S, KT>(), pair_dev_or_null<S, KT>(), pair_cert_or_null<S, KT>(),              \
+   pair_split_or_null<S, KT>()},
 const FastEntry kFast[] = {
 #include "fast_table.inc"
 };
@@ -166,6 +174,20 @@ const FastEntry* pick_fast(int N, int K) {
   }
   return best;
 }
+
+// series of 16 S < N <= 32 S scans: the pair form with the series' two halves in the slots of a row
+const FastEntry* pick_split(int N, int K) {
+  const FastEntry* best = nullptr;
+  const FastEntry* whole = pick_fast(N, K);
+  if (whole && whole->fn_pair_ffa) return nullptr;      // the series fits a slot: two PROBLEMS per row
+  for (const FastEntry& e : kFast) {
+    if (!e.fn_pair_split || e.KT < K || N <= 16 * e.S || N > 32 * e.S) continue;
+    if (!best || (int64_t)e.S * e.KT < (int64_t)best->S * best->KT) best = &e;
+  }
+  return best;
+}
+// below this many series the one-problem-per-wave / single-row forms finish first (latency-bound)
+constexpr int SPLIT_MIN_P = 1024;
 
 // ---- dispatch of a plain solve (no stop rule) over the register-resident forms --------
 // All forms keep two waves per SIMD and are VALU-issue bound, so a launch costs "rounds":
@@ -510,6 +532,9 @@ static bool pair_carries(const FastEntry* fe, int stop_mode, int wind) {
 int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mode, int wind) {
   (void)with_cost_trace;
   if (N < 1 || K < 1 || P < 1) return 0;
+  if (const FastEntry* se = pick_split(N, K))
+    if (P >= SPLIT_MIN_P && pair_carries(se, stop_mode, wind) && (stop_mode == PB_STOP_NONE || pick_wide(N, K)))
+      return FORM_PAIR;
   const FastEntry* fe = pick_fast(N, K);
   if (fe && stop_mode == PB_STOP_WINDOW && (wind != 6 || fe->S > 20)) fe = nullptr;
   if (!fe) {
@@ -525,7 +550,10 @@ int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mod
 int pb_fista_plan(int N, int K, int P, int stop_mode, int wind, int* n_main, int* main_form,
                   int* tail_form) {
   int nm = 0, mf = 0, tf = 0;
-  if (N >= 1 && K >= 1 && P >= 1) {
+  const FastEntry* se = (N >= 1 && K >= 1 && P >= SPLIT_MIN_P) ? pick_split(N, K) : nullptr;
+  if (se && pair_carries(se, stop_mode, wind) && (stop_mode == PB_STOP_NONE || pick_wide(N, K))) {
+    tf = FORM_PAIR;                                     // one launch of the split pair form
+  } else if (N >= 1 && K >= 1 && P >= 1) {
     const FastEntry* fe = pick_fast(N, K);
     if (fe && stop_mode == PB_STOP_WINDOW && (wind != 6 || fe->S > 20)) fe = nullptr;
     if (fe) {
@@ -585,6 +613,28 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
   a.taps_pp = nullptr; a.ldt = 0; a.step_vec = nullptr; a.step_shared = 0; a.K = K; a.p0 = 0;
   a.cold = (flags & PB_FLAG_COLD_START) ? 1 : 0;
 
+  // series of 16 S < N <= 32 S scans (the reference's 600-scan demo): the pair form with the two
+  // halves of ONE series in the slots of a row, in one launch; the window rule as a certificate,
+  // re-solved on the one-problem-per-wave form
+  if (!(flags & (PB_FLAG_FORCE_GENERIC | PB_FLAG_NO_PAIR | PB_FLAG_FORCE_WIDE | PB_FLAG_DIRECT_FIR))) {
+    const FastEntry* se = pick_split(N, K);
+    const WideEntry* wre = se ? pick_wide(N, K) : nullptr;
+    const bool scert = se && stop_mode == PB_STOP_WINDOW && wind == 6 && n_done_dev && wre && wre->S <= 20 &&
+                       !(flags & PB_FLAG_NO_CERT) && ((flags & PB_FLAG_FORCE_CERT) || tol * (double)n_iter < 0.5);
+    if (se && (P >= SPLIT_MIN_P || (flags & PB_FLAG_FORCE_PAIR)) && (stop_mode == PB_STOP_NONE || scert)) {
+      if (se->fn_pair_split(a, taps_host, K, J_dev != nullptr, scert, (hipStream_t)stream) != 0)
+        return fail(PB_ERR_INVALID, "pb_fista_solve: split pair kernel rejected the launch");
+      int rc = check_launch("fista_pair_ffa_kernel(split)");
+      if (rc == PB_OK && scert && !(flags & PB_FLAG_CERT_NO_RESOLVE)) {
+        pb::FistaArgs b = a;
+        b.only_flagged = 1;
+        if (wre->fn(b, taps_host, K, J_dev != nullptr, PB_STOP_WINDOW, (hipStream_t)stream) != 0)
+          return fail(PB_ERR_INVALID, "pb_fista_solve: no one-problem-per-wave form for the re-solve");
+        rc = check_launch("fista_fast_kernel(wide, re-solve)");
+      }
+      return rc;
+    }
+  }
   const FastEntry* fe = (flags & PB_FLAG_FORCE_GENERIC) ? nullptr : pick_fast(N, K);
   // the register-resident window rule keeps wind-1 = 5 iterates in VGPRs: wind = 6
   // (the reference default) on entries small enough to hold them; else LDS kernel

@@ -31,6 +31,13 @@ __device__ __forceinline__ float dpp_zero(float v) {
       float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
 
+// the same move, but lanes whose source lies outside the row keep `old` (bound_ctrl off)
+template <int CTRL>
+__device__ __forceinline__ float dpp_keep(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
+                                                               __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+
 // value of lane (i - n) of the same 16-lane row, 0 if that lane is outside it
 template <int n>
 __device__ __forceinline__ float row_from_below(float v) {

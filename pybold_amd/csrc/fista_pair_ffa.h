@@ -77,10 +77,19 @@ inline TapsFFA<KT> make_taps_ffa(const double* taps, int K) {
 // problems exactly on fista_fast_kernel<..., STOP = 2> (capi.hip).  On the reference's default
 // tol = 1e-6 the criterion stays ~0.9/k and the bound is ~4x below it: nothing is flagged.
 // Implies the rotated loop of WITH_J; the cost trace itself is written only if a.J != nullptr.
+//
+// SPLIT: ONE series of 16 S < N <= 32 S scans per row, its first 16 S samples in slot A and the rest
+// in slot B of every float2 -- the pair arithmetic unchanged, at the same density per sample
+// (the reference's shipped demo is 600 scans, examples/synth_data/deconv.py:46).  What changes is
+// where the two halves meet: slot B's halo below comes from slot A's last lanes (a row rotation
+// of A merged into the zero-filled shift of B: DPP with bound_ctrl off keeps `old` in the lanes
+// whose source is outside the row), slot A's halo above from slot B's first lanes, the prefix
+// scan of B starts from A's total and the suffix scan of A from B's.
 template <int S, int KT, bool WITH_J = false, bool SKIP0 = false, bool WB_LDS = false, bool TAPS_DEV = false,
-          bool CERT = false>
+          bool CERT = false, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, TapsFFA<KT> taps_arg) {
   static_assert(!CERT || WITH_J, "the certificate runs in the rotated (cost trace) loop");
+  static_assert(!SPLIT || !WB_LDS, "SPLIT keeps both halves in registers");
   constexpr int H = KT - 1;
   constexpr int D = (H + S - 1) / S;
   constexpr int KE = (KT + 1) / 2;          // taps per phase
@@ -96,8 +105,10 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
   const int sub = threadIdx.x & 15;
   const int row = gid >> 4;
   const int base = sub * S;
-  const int pA0 = 2 * row + a.p0, pB0 = 2 * row + 1 + a.p0;
+  const int pA0 = SPLIT ? row + a.p0 : 2 * row + a.p0, pB0 = SPLIT ? pA0 : pA0 + 1;
   const bool liveA = pA0 < a.P, liveB = pB0 < a.P;
+  // samples of the series held by slot A / slot B, and where slot B starts in the row
+  const int nA = SPLIT ? 16 * S : a.N, nB = SPLIT ? a.N - 16 * S : a.N, oB = SPLIT ? 16 * S : 0;
   const int pA = liveA ? pA0 : a.P - 1;
   const int pB = liveB ? pB0 : a.P - 1;
 
@@ -123,15 +134,15 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
   double wBr[WB_LDS ? 1 : S];               // problem B's iterate: registers, or parked in LDS
   {
     const float* yA = a.y + (int64_t)(pA / a.y_rep) * a.ldy;
-    const float* yB = a.y + (int64_t)(pB / a.y_rep) * a.ldy;
+    const float* yB = a.y + (int64_t)(pB / a.y_rep) * a.ldy + oB;
     const double* rA = a.w + (int64_t)pA * a.ldw;
-    const double* rB = a.w + (int64_t)pB * a.ldw;
+    const double* rB = a.w + (int64_t)pB * a.ldw + oB;
     // coalesced read -> LDS (natural order) -> strips (see fista_pair.h)
-    auto load_w = [&](const double* row, double* strip) {
+    auto load_w = [&](const double* row, double* strip, int nv) {
 #pragma unroll
       for (int k = 0; k < S; ++k) {
         const int i = k * 16 + sub;
-        stage_d[i] = (i < a.N && !a.cold) ? row[i] : 0.0;
+        stage_d[i] = (i < nv && !a.cold) ? row[i] : 0.0;
       }
       lds_sync();
 #pragma unroll
@@ -139,22 +150,22 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
       lds_sync();
     };
     double wB[S];
-    load_w(rA, wA);
-    load_w(rB, wB);
+    load_w(rA, wA, nA);
+    load_w(rB, wB, nB);
     float ya[S], yb[S];
-    auto load_y = [&](const float* row, float* strip) {
+    auto load_y = [&](const float* row, float* strip, int nv) {
 #pragma unroll
       for (int k = 0; k < S; ++k) {
         const int i = k * 16 + sub;
-        stage_f[i] = (i < a.N) ? row[i] : 0.0f;
+        stage_f[i] = (i < nv) ? row[i] : 0.0f;
       }
       lds_sync();
 #pragma unroll
       for (int j = 0; j < S; ++j) strip[j] = stage_f[base + j];
       lds_sync();
     };
-    load_y(yA, ya);
-    load_y(yB, yb);
+    load_y(yA, ya, nA);
+    load_y(yB, yb, nB);
     // y as the initial values of the forward accumulator chains: the output at an even
     // window position starts its A chain from -y_j, the one at an odd position its C chain
     // from -(y_j + y_{j-1}) (y_{j-1} only if that even position is an output of this lane)
@@ -195,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
   constexpr float CP1 = 0.3133f, CP2 = 0.6467f, CP3 = 0.04f;
   const float cert_t2 = ((float)a.tol * 1.001f) * ((float)a.tol * 1.001f);
   if constexpr (CERT) {
-    const float cert_sq = 16.0f * 1.0001f * __builtin_sqrtf((float)S);
+    const float cert_sq = 16.0f * 1.0001f * __builtin_sqrtf((float)(SPLIT ? 2 * S : S));
     const float c0A = (float)thA * cert_sq + 3.1e-10f, c0B = (float)thB * cert_sq + 3.1e-10f;
     lj[10] = cert_t2 * c0A * c0A * (1.0001f / CP3);
     lj[11] = cert_t2 * c0B * c0B * (1.0001f / CP3);
@@ -203,8 +214,8 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
   int cert_it = -1;                         // iteration whose certificate the next forward pass closes
   // samples that can be padding in SOME lane: j >= jpad (uniform); sample j of this lane is
   // real iff j < jlim = N - base, i.e. mask = saturate(jlim - j) as a float
-  const int jpad = (a.N - 15 * S > 0) ? a.N - 15 * S : 0;
-  const float jlimf = (float)(a.N - base);
+  const int jpad = (nB - 15 * S > 0) ? nB - 15 * S : 0;
+  const float jlimf = (float)(nB - base);
   // CERT state, per lane, in LDS behind the per-row scratch (slot-major: conflict-free b32
   // accesses; each lane touches only its own words): [0..7] ring of the tracked sample's last
   // four increments (float32, slot = 2 (k mod 4) + problem), [8..11] its u_{k-1} (float64 halves),
@@ -263,8 +274,13 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
           const f2 t = c_vsq - cert_t2 * ((1.0001f / CP1) * c_wp + (4.0001f / CP2) * sq);
           const float tA = row_allsum(t.x), tB = row_allsum(t.y);
           const bool chk = cert_it >= 7;
-          flagA = flagA | (chk & !(tA >= c_lim.x));   // NaN-safe: anything unclear is flagged
-          flagB = flagB | (chk & !(tB >= c_lim.y));
+          if constexpr (SPLIT) {
+            flagA = flagA | (chk & !(tA + tB >= c_lim.x));
+            flagB = flagA;
+          } else {
+            flagA = flagA | (chk & !(tA >= c_lim.x));   // NaN-safe: anything unclear is flagged
+            flagB = flagB | (chk & !(tB >= c_lim.y));
+          }
           lc[14 * 256] = sq.x;
           lc[15 * 256] = sq.y;
         }
@@ -274,8 +290,9 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
       }
     }
     {
-      const f2 off = f2{row_from_below<1>(row_prefix_incl(z[S - 1].x)),
-                        row_from_below<1>(row_prefix_incl(z[S - 1].y))};
+      f2 off = f2{row_from_below<1>(row_prefix_incl(z[S - 1].x)),
+                  row_from_below<1>(row_prefix_incl(z[S - 1].y))};
+      if constexpr (SPLIT) off.y += row_allsum(z[S - 1].x);      // slot B continues slot A's sum
 #pragma unroll
       for (int j = 0; j < S; ++j) z[j] += off;
     }
@@ -291,7 +308,11 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
       static_for<0, S>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         constexpr int e = H - d * S + j;
-        if constexpr (e >= 0) Z[e] = dpp_zero2<DPP_ROW_SHR + d>(z[j]);
+        if constexpr (e >= 0) {
+          if constexpr (SPLIT) Z[e] = f2{dpp_zero<DPP_ROW_SHR + d>(z[j].x),
+                                        dpp_keep<DPP_ROW_SHR + d>(dpp_zero<DPP_ROW_ROR + d>(z[j].x), z[j].y)};
+          else Z[e] = dpp_zero2<DPP_ROW_SHR + d>(z[j]);
+        }
       });
     });
 
@@ -362,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
       if (j >= jp) {
         asm volatile("");
         const float m = __builtin_amdgcn_fmed3f(jl - (float)j, 0.0f, 1.0f);
-        r[j] = r[j] * f2{m, m};
+        r[j] = r[j] * f2{SPLIT ? 1.0f : m, m};
       }
     });
   };
@@ -380,7 +401,11 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
       static_for<0, S>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
         constexpr int e = d * S + j;
-        if constexpr (e < S + H) R[e] = dpp_zero2<DPP_ROW_SHL + d>(r[j]);
+        if constexpr (e < S + H) {
+          if constexpr (SPLIT) R[e] = f2{dpp_keep<DPP_ROW_SHL + d>(dpp_zero<DPP_ROW_ROR + (16 - d)>(r[j].y), r[j].x),
+                                        dpp_zero<DPP_ROW_SHL + d>(r[j].y)};
+          else R[e] = dpp_zero2<DPP_ROW_SHL + d>(r[j]);
+        }
       });
     });
     // g(2n) = A'[n] + C'[n], g(2n+1) = B'[n] + C'[n]
@@ -433,8 +458,9 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
 #pragma unroll
     for (int j = S - 2; j >= 0; --j) g[j] += g[j + 1];
     {
-      const f2 off = f2{row_from_above<1>(row_suffix_incl(g[0].x)),
-                        row_from_above<1>(row_suffix_incl(g[0].y))};
+      f2 off = f2{row_from_above<1>(row_suffix_incl(g[0].x)),
+                  row_from_above<1>(row_suffix_incl(g[0].y))};
+      if constexpr (SPLIT) off.x += row_allsum(g[0].y);          // slot A's suffix continues into slot B
 #pragma unroll
       for (int j = 0; j < S; ++j) g[j] += off;
     }
@@ -541,8 +567,12 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
       // (a flagged problem stops tracing: it was flagged no later than the iteration its rule
       // fires at, so the re-solve rewrites everything written here and nothing beyond its stop)
       if (sub == 0 && (!CERT || a.J != nullptr)) {
-        if (liveA && !flagA) a.J[(int64_t)pA * a.ldj + it] = cA;
-        if (liveB && !flagB) a.J[(int64_t)pB * a.ldj + it] = cB;
+        if constexpr (SPLIT) {
+          if (liveA && !flagA) a.J[(int64_t)pA * a.ldj + it] = cA + cB;
+        } else {
+          if (liveA && !flagA) a.J[(int64_t)pA * a.ldj + it] = cA;
+          if (liveB && !flagB) a.J[(int64_t)pB * a.ldj + it] = cB;
+        }
       }
     }
   }
@@ -553,7 +583,7 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
   for (int j = 0; j < S; ++j) {
     if constexpr (WB_LDS) wBf[j] = lw[j * 16]; else wBf[j] = wBr[j];
   }
-  auto store_w = [&](const double* strip, double* row, bool live) {
+  auto store_w = [&](const double* strip, double* row, bool live, int nv) {
     lds_sync();
 #pragma unroll
     for (int j = 0; j < S; ++j) stage_d[base + j] = strip[j];
@@ -562,15 +592,15 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
 #pragma unroll
       for (int k = 0; k < S; ++k) {
         const int i = k * 16 + sub;
-        if (i < a.N) row[i] = stage_d[i];
+        if (i < nv) row[i] = stage_d[i];
       }
     }
   };
-  store_w(wA, a.w + (int64_t)pA * a.ldw, liveA && !flagA);
-  store_w(wBf, a.w + (int64_t)pB * a.ldw, liveB && !flagB);
+  store_w(wA, a.w + (int64_t)pA * a.ldw, liveA && !flagA, nA);
+  store_w(wBf, a.w + (int64_t)pB * a.ldw + oB, liveB && !flagB, nB);
   if (a.n_done && sub == 0) {
     if (liveA) a.n_done[pA] = flagA ? -1 : a.n_iter;
-    if (liveB) a.n_done[pB] = flagB ? -1 : a.n_iter;
+    if (liveB && !SPLIT) a.n_done[pB] = flagB ? -1 : a.n_iter;
   }
 }
 
@@ -582,6 +612,29 @@ int launch_pair_ffa_dev(const FistaArgs& a, hipStream_t st) {
   const dim3 grid((unsigned)((rows * 16 + 255) / 256)), block(256);
   const size_t lds = (size_t)16 * S * 16 * (sizeof(f2) + sizeof(float)) + 16 * PAIR_LJ * sizeof(float);
   hipLaunchKernelGGL((fista_pair_ffa_kernel<S, KT, false, false, false, true>), grid, block, lds, st, a, none);
+  return 0;
+}
+
+// one series of 16 S < N <= 32 S scans per row (SPLIT): plain, cost trace, certificate
+template <int S, int KT>
+int launch_pair_ffa_split(const FistaArgs& a, const double* taps, int K, bool with_j, bool cert, hipStream_t st) {
+  if (a.N <= 16 * S || a.N > 32 * S || (cert && !a.n_done)) return 1;
+  const auto tf = make_taps_ffa<KT>(taps, K);
+  const int64_t rows = (int64_t)(a.P - a.p0);
+  const dim3 grid((unsigned)((rows * 16 + 255) / 256)), block(256);
+  const size_t lds = (size_t)16 * S * 16 * (sizeof(f2) + sizeof(float)) +
+                     (16 * PAIR_LJ + (cert ? 256 * PAIR_LC : 0)) * sizeof(float);
+  const bool skip0 = KT > 1 && tf.pr[0].x == 0.0f;
+  if (cert) {
+    if (skip0) hipLaunchKernelGGL((fista_pair_ffa_kernel<S, KT, true, true, false, false, true, true>), grid, block, lds, st, a, tf);
+    else hipLaunchKernelGGL((fista_pair_ffa_kernel<S, KT, true, false, false, false, true, true>), grid, block, lds, st, a, tf);
+  } else if (with_j) {
+    if (skip0) hipLaunchKernelGGL((fista_pair_ffa_kernel<S, KT, true, true, false, false, false, true>), grid, block, lds, st, a, tf);
+    else hipLaunchKernelGGL((fista_pair_ffa_kernel<S, KT, true, false, false, false, false, true>), grid, block, lds, st, a, tf);
+  } else {
+    if (skip0) hipLaunchKernelGGL((fista_pair_ffa_kernel<S, KT, false, true, false, false, false, true>), grid, block, lds, st, a, tf);
+    else hipLaunchKernelGGL((fista_pair_ffa_kernel<S, KT, false, false, false, false, false, true>), grid, block, lds, st, a, tf);
+  }
   return 0;
 }
 

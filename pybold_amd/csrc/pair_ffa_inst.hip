@@ -9,5 +9,6 @@ namespace pb {
 template int launch_pair_ffa<PB_S, PB_KT>(const FistaArgs&, const double*, int, bool, hipStream_t);
 template int launch_pair_ffa_dev<PB_S, PB_KT>(const FistaArgs&, hipStream_t);
 template int launch_pair_ffa_cert<PB_S, PB_KT>(const FistaArgs&, const double*, int, hipStream_t);
+template int launch_pair_ffa_split<PB_S, PB_KT>(const FistaArgs&, const double*, int, bool, bool, hipStream_t);
 #endif
 }

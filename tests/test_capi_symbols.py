@@ -67,7 +67,10 @@ def test_version_and_dispatch_table(lib):
     assert lib.pb_fista_which_kernel(300, 30, 8192, 1, 2, 6) == 2        # the deconv default call: pair form
     assert lib.pb_fista_which_kernel(300, 30, 8192, 1, 1, 6) == 1        # _loops_deconv rule: single-row kernel
     assert lib.pb_fista_which_kernel(300, 30, 3, 1, 2, 6) == 3           # ... or one problem per wave
-    assert lib.pb_fista_which_kernel(600, 30, 100000, 0, 0, 6) == 1      # S = 38: no pair form
+    assert lib.pb_fista_which_kernel(600, 30, 100000, 0, 0, 6) == 2      # 600 scans: the halves of a series in the two slots of a row
+    assert lib.pb_fista_which_kernel(600, 30, 100000, 1, 2, 6) == 2      # ... with the window rule as a certificate
+    assert lib.pb_fista_which_kernel(600, 30, 500, 0, 0, 6) in (1, 3)    # few long series: latency-bound forms
+    assert lib.pb_fista_which_kernel(640, 30, 100000, 0, 0, 6) == 3      # beyond 32 x 19 scans: one problem per wave
     assert lib.pb_fista_which_kernel(5000, 30, 10, 0, 0, 6) == 0
 
 

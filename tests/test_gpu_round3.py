@@ -159,3 +159,63 @@ def test_certificate_is_tight_enough_to_be_useful(solver, golden):
     _, _, ndc = solver.fista_solve(Y, hrf, 1.0, 1.0 / lip, 1000, want_J=True, stop="window", tol=2e-3, wind=6,
                                    force="certonly")
     assert int((ndc < 0).sum()) == 512               # the rule does fire here (~0.9/k): everything is flagged
+
+
+# ---- series of 16 S < N <= 32 S scans: the two halves of ONE series in the slots of a row ----------
+def long_problem(n_vox, n, k_taps, seed):
+    rng = np.random.RandomState(seed)
+    hrf = orc.spm_hrf(1.0, 1.0, float(k_taps), False)[0][:k_taps]
+    Z = np.zeros((n_vox, n))
+    for v in range(n_vox):
+        for _ in range(6):
+            o = rng.randint(0, n - 40)
+            Z[v, o:o + rng.randint(8, 30)] += rng.choice([-1.0, 1.0])
+    Y = orc.causal_conv(hrf, Z) + 0.3 * rng.randn(n_vox, n)
+    lip = orc.gram_lipschitz(hrf, n)
+    return Y, hrf, lip
+
+
+@pytest.mark.parametrize("n,k", [(600, 30), (608, 30), (305, 30), (400, 27), (480, 30), (520, 32), (330, 16)])
+def test_split_pair_form_matches_oracle(solver, n, k):
+    """N in (16 S, 32 S]: plain solve, cost trace and the iterate against the float64 oracle;
+    the kernel is the pair form (asked for by force='fast2'; the library picks it from 1 024
+    series on)."""
+    Y, hrf, lip = long_problem(9, n, k, seed=n)
+    assert len(hrf) == k
+    n_iter = 300
+    Wr = orc.fista_batch(Y.astype(np.float32).astype(np.float64), hrf, 0.7, 1.0 / lip, n_iter)
+    W, J, nd = solver.fista_solve(dev32(Y), hrf, 0.7, 1.0 / lip, n_iter, want_J=True, force="fast2")
+    assert "two problems per row" in solver.which_kernel(n, k, 5000)
+    assert rel_rows(W.cpu().numpy(), Wr) < EPS
+    Xr, Zr = orc.fista_outputs(Wr, hrf)
+    Jr = 0.5 * np.sum(np.square(Xr - Y.astype(np.float32)), axis=1) + 0.7 * np.abs(Wr).sum(axis=1)
+    np.testing.assert_allclose(J.cpu().numpy()[:, -1], Jr, rtol=2e-5)
+    # without the cost trace: same iterate (another instantiation: not bitwise), any batch position
+    W2, _, _ = solver.fista_solve(dev32(np.concatenate([Y[4:], Y[:4]])), hrf, 0.7, 1.0 / lip, n_iter, force="fast2")
+    assert rel_rows(W2.cpu().numpy(), np.concatenate([Wr[4:], Wr[:4]])) < EPS
+    W3, _, _ = solver.fista_solve(dev32(Y), hrf, 0.7, 1.0 / lip, n_iter, force="fast2")
+    assert torch.equal(W3[4:], W2[:5]) and torch.equal(W3[:4], W2[5:])
+
+
+def test_split_pair_form_window_rule(solver):
+    """600-scan series with the window rule through the certificate path: stop iterations and
+    iterates of the oracle, about half of the series firing before n_iter."""
+    Y, hrf, lip = long_problem(12, 600, 30, seed=1)
+    Y32 = Y.astype(np.float32).astype(np.float64)
+    tol = 0.01
+    n_fire = np.array([orc.deconv_fixed_lbda(Y32[v], hrf, 0.7, nb_iter=500, tol=tol, lipschitz=lip, dense=False)[4]
+                       for v in range(12)])
+    n_iter = int(np.median(n_fire))
+    out = [orc.deconv_fixed_lbda(Y32[v], hrf, 0.7, nb_iter=n_iter, tol=tol, lipschitz=lip, dense=False)
+           for v in range(12)]
+    Wr, nr = np.stack([o[2] for o in out]), np.array([o[4] for o in out])
+    assert 3 <= (n_fire < n_iter).sum() <= 9
+    W, J, nd = solver.fista_solve(dev32(Y), hrf, 0.7, 1.0 / lip, n_iter, want_J=True, stop="window", tol=tol,
+                                  wind=6, force="cert2")
+    assert (nd.cpu().numpy() == nr).all()
+    assert rel_rows(W.cpu().numpy(), Wr) < EPS
+    # default tolerance on a full-size batch: nothing fires, same result as the plain solve
+    Yb = dev32(np.tile(Y, (200, 1)))
+    Wd, _, ndd = solver.fista_solve(Yb, hrf, 0.7, 1.0 / lip, 200, want_J=True, stop="window", tol=1e-6, wind=6)
+    Wp, _, _ = solver.fista_solve(Yb, hrf, 0.7, 1.0 / lip, 200, want_J=True)
+    assert int(ndd.min()) == 200 and torch.equal(Wd, Wp)
