@@ -18,6 +18,12 @@ axis of the north_star's ">= 6x at 8 GPUs".  The only collectives are the timing
 the MAX-reduction of the elapsed time.  `--scaling weak` (or the `weak_scaling` key of the
 default line for N > 1) gives every rank its own 100k voxels instead.
 
+`--config {2,3,4,5}` picks the BASELINE.json configuration (default 3; the default command is
+unchanged): 2 = 10k voxels (L1 deconv), 3 = 100k voxels, 4 = semi-blind deconvolution with ONE
+shared HRF dilation (50k voxels, 20 outer x 100 inner iterations + the closing z-step, one
+all-reduce of K^2+K+2 float64 per outer iteration), 5 = regularisation path (50k voxels x 20
+lambdas = 10^6 problems sharing each voxel's series).  One JSON line each, same blocks.
+
 Prints ONE JSON line (rank 0): metric = voxel-iterations/s (whole job), plus `roofline`
 (dominant kernel against the fp32 vector-ALU peak that binds it; the HBM-algorithmic figure
 of SURVEY.md 8d and the measured HBM traffic as context) and `cpu_baseline` (the reference's
@@ -39,6 +45,16 @@ VALU_FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector), needs 
 BYTES_PER_VOXEL_ITER_PER_SCAN = 12   # read w, read y, write w in fp32
 
 
+CONFIG_VOXELS = {2: 10000, 3: 100000, 4: 50000, 5: 50000}
+N_LAMBDA = 20                        # config 5: lambdas per voxel
+
+
+def executed_flops_per_voxel_iter(n, k):
+    """What the pair kernel with 2-parallel fast FIRs executes: three half-length sub-filters
+    per FIR instead of four (3/4 of the multiply-adds), same scans and update."""
+    return 3.0 * n * k + 12.0 * n
+
+
 def flops_per_voxel_iter(n, k):
     """Algorithmic flops of one iteration: two K-tap FIRs 4NK, two scans 2N,
     update/prox/momentum ~10N."""
@@ -50,8 +66,14 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--voxels", type=int, default=100000,
-                    help="voxels of the whole job (strong scaling) / per GPU (--scaling weak)")
+    ap.add_argument("--config", type=int, choices=[2, 3, 4, 5], default=3,
+                    help="BASELINE.json configuration (see the module docstring)")
+    ap.add_argument("--voxels", type=int, default=None,
+                    help="voxels of the whole job (strong scaling) / per GPU (--scaling weak); "
+                         "default: the configuration's own count (10k / 100k / 50k / 50k)")
+    ap.add_argument("--busy-seconds", type=float, default=6.0,
+                    help="N = 1: untimed back-to-back solves after the timed region (sustained rate; also "
+                         "keeps the GPU visibly busy between the two CPU legs)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: shard --voxels over the ranks (strong, default) or give every "
                          "rank --voxels of its own (weak)")
@@ -116,6 +138,8 @@ def self_launch(args):
 
 def main():
     args = parse()
+    if args.voxels is None:
+        args.voxels = CONFIG_VOXELS[args.config]
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
     # Everything but the final JSON line goes to stderr, including what native
@@ -139,6 +163,7 @@ def run(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    cfg = args.config
 
     # CPU legs first (rank 0, one GPU): their worker processes are started before this
     # process initialises the GPU
@@ -172,11 +197,75 @@ def run(args):
     from pybold_amd.linear import ConvAndLinear, DiscretInteg
     from pybold_amd.utils import spectral_radius_est
 
+    lo, hi, V_total = job_layout(args.voxels, args.scaling, world, rank)
+    V = hi - lo                                                 # this rank's voxels
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def timed_local(fn, steps, warmup, spin_s=0.0):
+        """This rank only (no collective): `warmup` untimed calls, then `steps` calls bracketed by
+        events on the launch stream.  Returns (elapsed s by the host clock, mean ms by events)."""
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < spin_s:
+            fn()
+            torch.cuda.synchronize(dev)
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize(dev)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for k in range(steps):
+            ev[k][0].record()          # same stream the kernel is launched on
+            fn()
+            ev[k][1].record()
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0, float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    def timed(fn, steps, warmup, spin_s=0.0):
+        """The contract's timed region, on EVERY rank: `warmup` untimed steps, then exactly `steps`
+        steps between barrier + synchronize on both sides; MAX over ranks.  `spin_s` > 0 first
+        keeps the device busy with the same (untimed) step for that long: a step of a 12 500-voxel
+        shard lasts 2.7 ms, and three warm-up steps end before the GPU has left its idle clocks
+        (measured: 2.80 ms/step after 3 warm-up steps, 2.63 after 30 or more)."""
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < spin_s:
+            fn()
+            torch.cuda.synchronize(dev)
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize(dev)
+        barrier()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for k in range(steps):
+            ev[k][0].record()
+            fn()
+            ev[k][1].record()
+        torch.cuda.synchronize(dev)
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    if cfg == 4:
+        out = run_config4(args, world, rank, dev, dist, V, V_total, lo, timed, timed_local, barrier)
+        if rank == 0 and world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline_block(cpu_dense, None, args.iters)
+        if dist is not None:
+            dist.destroy_process_group()
+        return json.dumps(out) if rank == 0 else None
+
     N, n_iter = args.scans, args.iters
     tr = 1.0
     hrf = spm_hrf(1.0, t_r=tr, dur=30.0)[0]                    # canonical HRF, K = 30
-    lo, hi, V_total = job_layout(args.voxels, args.scaling, world, rank)
-    V = hi - lo                                                 # this rank's voxels
+    K = len(hrf)
+    y_rep = N_LAMBDA if cfg == 5 else 1
 
     def make_batch(n_vox, seed):
         Y, _, _ = data.gen_rnd_bloc_bold_batch(n_vox, dur=N * tr / 60.0, tr=tr, hrf=hrf, nb_events=5,
@@ -188,87 +277,66 @@ def run(args):
     lipschitz = 0.9 * spectral_radius_est(H, (N,))              # pybold/bold_signal.py:52
     step = 1.0 / lipschitz
     force = None if args.kernel == "auto" else args.kernel
-    plan = solver.FistaPlan(Y, hrf, args.lbda, step, n_iter, force=force)
-    kernel_name = (solver.which_kernel(N, len(hrf), max(V, 1)) if args.kernel in ("auto", "seq") else
+    if cfg == 5:      # lambda_v,i = logspace(-2, 0, 20)_i * ||H^T y_v||_inf, one problem per (voxel, lambda)
+        lam = (solver.lambda_max(Y, hrf)[:, None] *
+               torch.logspace(-2.0, 0.0, N_LAMBDA, dtype=torch.float64, device=dev)[None, :]).reshape(-1)
+    else:
+        lam = args.lbda
+    P = V * y_rep                                               # problems of this rank
+    plan = solver.FistaPlan(Y, hrf, lam, step, n_iter, y_rep=y_rep, force=force)
+    kernel_name = (solver.which_kernel(N, K, max(P, 1)) if args.kernel in ("auto", "seq") else
                    {"fast1": solver.KERNEL_NAMES[1], "generic": solver.KERNEL_NAMES[0]}[args.kernel])
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    def one_step():
+        plan.launch(cold=True)     # deconv's cold start (w = 0) without a memset: PB_FLAG_COLD_START
 
-    def timed(p, steps, warmup, spin_s=0.0):
-        """`warmup` untimed steps, then exactly `steps` steps between barrier +
-        synchronize on both sides; MAX over ranks.  Returns (elapsed s, mean kernel ms).
-        `spin_s` > 0 first keeps the device busy with the same (untimed) step for that
-        long: a step of a 12 500-voxel shard lasts 2.7 ms, and three warm-up steps end
-        before the GPU has left its idle clocks (measured: 2.80 ms/step after 3 warm-up
-        steps, 2.63 after 30 or more)."""
-        t_spin = time.perf_counter()
-        while time.perf_counter() - t_spin < spin_s:
-            p.run()
-            torch.cuda.synchronize(dev)
-        for _ in range(warmup):
-            p.run()
-        torch.cuda.synchronize(dev)
-        barrier()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-              for _ in range(steps)]
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for k in range(steps):
-            ev[k][0].record()          # same stream the kernel is launched on
-            p.launch(cold=True)        # deconv's cold start (w = 0) without a memset: PB_FLAG_COLD_START
-            ev[k][1].record()
-        torch.cuda.synchronize(dev)
-        barrier()
-        el = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([el], dtype=torch.float64, device=red_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        return el, float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    elapsed, kern_ms = timed(one_step, args.steps, args.warmup, args.spin_seconds)
+    value = float(V_total) * y_rep * n_iter * args.steps / elapsed
 
-    elapsed, kern_ms = timed(plan, args.steps, args.warmup, args.spin_seconds)
-
-    value = float(V_total) * n_iter * args.steps / elapsed
-    K = len(hrf)
     # One step = ONE pb_fista_solve call = up to two kernels (solver.launch_plan): the whole
     # rounds of waves on the dominant kernel, the remainder on the cheapest form.  The
     # dominant kernel is timed on its own here (same grid, same data, a few launches after
-    # the timed region) so that its duration can be set against its rocprofv3 average.
-    n_main, main_kernel, tail_kernel = solver.launch_plan(N, K, max(V, 1))
-    V_dom = n_main if (args.kernel in ("auto", "seq") and n_main > 0) else V
-    if V_dom != V:
-        plan_dom = solver.FistaPlan(Y[:V_dom], hrf, args.lbda, step, n_iter, force="fast2")
-        _, dom_ms = timed(plan_dom, max(3, min(args.steps, 5)), 1, 0.05)
+    # the timed region, THIS RANK ONLY: no collective, ranks may differ in their plans) so that
+    # its duration can be set against its rocprofv3 average.
+    n_main, main_kernel, tail_kernel = solver.launch_plan(N, K, max(P, 1))
+    P_dom = n_main if (args.kernel in ("auto", "seq") and n_main > 0) else P
+    if P_dom != P and P_dom % y_rep == 0:
+        lam_dom = lam[:P_dom] if torch.is_tensor(lam) else lam
+        plan_dom = solver.FistaPlan(Y[:P_dom // y_rep], hrf, lam_dom, step, n_iter, y_rep=y_rep, force="fast2")
+        _, dom_ms = timed_local(lambda: plan_dom.launch(cold=True), max(3, min(args.steps, 5)), 1, 0.05)
         del plan_dom
     else:
-        dom_ms = kern_ms
-    flops_launch = flops_per_voxel_iter(N, K) * float(V_dom) * n_iter      # dominant kernel, one launch
-    alg_bytes = BYTES_PER_VOXEL_ITER_PER_SCAN * N * float(V_dom) * n_iter
+        P_dom, dom_ms = P, kern_ms
+    pair_form = "two problems per row" in (main_kernel if n_main else tail_kernel)
+    flops_launch = flops_per_voxel_iter(N, K) * float(P_dom) * n_iter      # dominant kernel, one launch
+    exec_launch = (executed_flops_per_voxel_iter(N, K) if pair_form else flops_per_voxel_iter(N, K)) * float(P_dom) * n_iter
+    alg_bytes = BYTES_PER_VOXEL_ITER_PER_SCAN * N * float(P_dom) * n_iter
     valu_tflops = flops_launch / (dom_ms * 1e-3) / 1e12
     hbm_alg_gbs = alg_bytes / (dom_ms * 1e-3) / 1e9
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tfile):
+    if os.path.exists(tfile) and cfg == 3:
         try:
             tj = json.load(open(tfile))
-            if tj.get("voxels") == V_dom and tj.get("iters") == n_iter and tj.get("scans") == N:
+            if tj.get("voxels") == P_dom and tj.get("iters") == n_iter and tj.get("scans") == N:
                 traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
 
     ms_step = elapsed / args.steps * 1e3
+    what = {2: "BASELINE config 2: %d voxels x %d scans, L1 deconv" % (V_total, N),
+            3: "BASELINE config 3: %d voxels x %d scans, L1/TV block-signal deconv" % (V_total, N),
+            5: "BASELINE config 5: regularisation path, %d voxels x %d lambdas (logspace(-2,0,%d) x "
+               "lambda_max of each voxel) = %d problems x %d scans sharing each voxel's series"
+               % (V_total, N_LAMBDA, N_LAMBDA, V_total * N_LAMBDA, N)}[cfg]
     if world == 1:
-        workload = ("BASELINE config 3: %d voxels x %d scans, L1/TV block-signal deconv, fixed "
-                    "canonical HRF (K=%d), lambda=%g, %d FISTA iterations per step"
-                    % (V_total, N, K, args.lbda, n_iter))
+        workload = ("%s, fixed canonical HRF (K=%d), %s%d FISTA iterations per step"
+                    % (what, K, "" if cfg == 5 else "lambda=%g, " % args.lbda, n_iter))
     else:
-        workload = ("BASELINE config 3 on %d GPUs (%s scaling): %d voxels in all, %s per GPU, x %d "
-                    "scans, L1/TV block-signal deconv, fixed canonical HRF (K=%d), lambda=%g, %d FISTA "
-                    "iterations per step" % (world, args.scaling, V_total,
+        workload = ("%s on %d GPUs (%s scaling): %s voxels per GPU, fixed canonical HRF (K=%d), %s%d FISTA "
+                    "iterations per step" % (what, world, args.scaling,
                                              "%d" % V if args.scaling == "weak" else "ceil(%d/%d)" % (V_total, world),
-                                             N, K, args.lbda, n_iter))
+                                             K, "" if cfg == 5 else "lambda=%g, " % args.lbda, n_iter))
     out = {
         "metric": "voxel-iterations/sec", "value": value, "unit": "voxel-iterations/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -281,71 +349,212 @@ def run(args):
         "dtype_note": "FIR/scans/residual fp32 (packed), iterate and update fp64 on chip; "
                       "y fp32 in HBM; outputs fp64",
         "data": "synthetic",
-        "config": {"workload": workload,
-                   "voxels_total": V_total, "voxels_this_rank": V, "scans": N, "taps": int(K),
+        "config": {"workload": workload, "baseline_config": cfg,
+                   "voxels_total": V_total, "voxels_this_rank": V, "problems_this_rank": P,
+                   "scans": N, "taps": int(K),
                    "iters_per_step": n_iter, "kernel": kernel_name,
                    "launches_per_step": ([{"kernel": main_kernel, "problems": n_main}] if n_main else []) +
-                                        [{"kernel": tail_kernel, "problems": V - n_main}]
-                   if args.kernel in ("auto", "seq") else [{"kernel": kernel_name, "problems": V}],
+                                        [{"kernel": tail_kernel, "problems": P - n_main}]
+                   if args.kernel in ("auto", "seq") else [{"kernel": kernel_name, "problems": P}],
                    "parallelism": "contiguous voxel shards x%d, no data-path collective" % world},
         "roofline": {"bound": "valu_fp32", "achieved": valu_tflops, "peak": VALU_FP32_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": valu_tflops / VALU_FP32_PEAK_TFLOPS,
-                     "traffic": traffic, "kernel_ms": dom_ms, "kernel_problems": V_dom,
+                     "traffic": traffic, "kernel_ms": dom_ms, "kernel_problems": P_dom,
                      "step_kernels_ms": kern_ms,
-                     "step_valu_frac": flops_per_voxel_iter(N, K) * float(V) * n_iter /
+                     "step_valu_frac": flops_per_voxel_iter(N, K) * float(P) * n_iter /
                                        (kern_ms * 1e-3) / 1e12 / VALU_FP32_PEAK_TFLOPS,
                      "flops_per_voxel_iteration": flops_per_voxel_iter(N, K),
                      "algorithmic_flops_per_launch": flops_launch,
+                     "executed_flops_per_voxel_iteration": exec_launch / (float(P_dom) * n_iter),
+                     "achieved_executed": exec_launch / (dom_ms * 1e-3) / 1e12,
+                     "frac_executed": exec_launch / (dom_ms * 1e-3) / 1e12 / VALU_FP32_PEAK_TFLOPS,
                      "hbm_algorithmic_GBps": hbm_alg_gbs,
                      "hbm_algorithmic_frac": hbm_alg_gbs / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "hbm_traffic_GBps": (traffic / (dom_ms * 1e-3) / 1e9) if traffic else None,
-                     "note": "dominant kernel of the step (kernel_problems of the voxels; the rest "
+                     "note": "dominant kernel of the step (kernel_problems of the problems; the rest "
                              "runs in a second, short launch: config.launches_per_step; "
                              "step_kernels_ms = both). Register-resident multi-iteration kernel, "
                              "VALU-issue bound (PMC: profiles/): the binding roofline is the fp32 "
-                             "vector peak (v_pk_fma_f32), priced with the ALGORITHMIC flops of the "
-                             "direct form (4NK + 12N per voxel-iteration, SURVEY 8d) although the "
-                             "2-parallel fast FIRs execute 3/4 of those multiply-adds. State never "
+                             "vector peak (v_pk_fma_f32). `achieved`/`frac` price the ALGORITHMIC flops of "
+                             "the direct form (4NK + 12N per voxel-iteration, SURVEY 8d); the 2-parallel "
+                             "fast FIRs execute 3/4 of those multiply-adds: `achieved_executed`/"
+                             "`frac_executed` count what the kernel really issues (3NK + 12N). State never "
                              "leaves the chip during a solve, so the SURVEY-8d algorithmic-byte "
                              "rate (12*N B per voxel-iteration / kernel time) exceeds the HBM peak; "
                              "measured HBM traffic = one read of y and one write of w per launch. The peak assumes "
                              "2.4 GHz; while this kernel runs the package sits at its power limit (1.27-1.29 kW) "
                              "and the shader clock at 2.07-2.19 GHz (profiles/r2_clock_and_power_during_solve.txt, "
-                             "r2_pmc_sq_valu_utilisation.json): frac = 0.86-0.9 of the peak at the sustained clock."},
+                             "r2_pmc_sq_valu_utilisation.json)."},
     }
 
     if world > 1 and args.scaling == "strong":
-        # secondary figure: weak scaling (every rank its own `--voxels` voxels)
+        # secondary figure: weak scaling (every rank its own `--voxels` voxels); every rank takes
+        # part (the decision depends on `world` and the flags only, never on a rank's own plan)
         Yw = make_batch(args.voxels, 2000 + rank)
-        planw = solver.FistaPlan(Yw, hrf, args.lbda, step, n_iter, force=force)
+        if cfg == 5:
+            lamw = (solver.lambda_max(Yw, hrf)[:, None] *
+                    torch.logspace(-2.0, 0.0, N_LAMBDA, dtype=torch.float64, device=dev)[None, :]).reshape(-1)
+        else:
+            lamw = args.lbda
+        planw = solver.FistaPlan(Yw, hrf, lamw, step, n_iter, y_rep=y_rep, force=force)
         steps_w = max(3, min(args.steps, 5))
-        el_w, k_w = timed(planw, steps_w, 1)
-        out["weak_scaling"] = {"value": float(args.voxels) * world * n_iter * steps_w / el_w,
+        el_w, k_w = timed(lambda: planw.launch(cold=True), steps_w, 1)
+        out["weak_scaling"] = {"value": float(args.voxels) * y_rep * world * n_iter * steps_w / el_w,
                                "unit": "voxel-iterations/s", "voxels_per_gpu": args.voxels,
                                "ms_per_step": el_w / steps_w * 1e3, "steps": steps_w}
         del Yw, planw
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and args.busy_seconds > 0:
+        # sustained rate: back-to-back solves for several seconds (clocks and temperatures settled)
+        n_busy, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < args.busy_seconds:
+            for _ in range(20):
+                one_step()
+            torch.cuda.synchronize(dev)
+            n_busy += 20
+        dt = time.perf_counter() - t0
+        out["sustained"] = {"value": float(P) * n_iter * n_busy / dt, "unit": "voxel-iterations/s",
+                            "seconds": dt, "solves": n_busy}
+
+    if rank == 0 and world == 1 and cfg == 3:
         out.update(pcie_inclusive(plan, Y, hrf, args.lbda, step, n_iter, solver, torch, dev, args.extras))
 
-    if rank == 0 and world == 1 and args.extras:
+    if rank == 0 and world == 1 and args.extras and cfg == 3:
         others = {}
         for tag, V2 in (("config2_10000_voxels", 10000), ("config3_shard_of_8_12500_voxels", 12500)):
             V2 = min(V2, V)
             plan2 = solver.FistaPlan(Y[:V2].contiguous(), hrf, args.lbda, step, n_iter, force=None)
-            el2, k2 = timed(plan2, 10, 1, 0.1)
+            el2, k2 = timed_local(lambda: plan2.launch(cold=True), 10, 1, 0.1)
             others[tag] = {"value": V2 * n_iter * 10 / el2, "unit": "voxel-iterations/s",
                            "ms_per_solve": el2 / 10 * 1e3, "kernel_ms": k2,
                            "kernel": solver.which_kernel(N, K, V2)}
         out["other_configs"] = others
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
-        out["cpu_baseline"], out["parity"] = cpu_baseline(Y, plan.W, hrf, args.lbda, step, n_iter,
-                                                          args.cpu_seconds, cpu_dense)
+        port, out["parity"] = cpu_port_and_parity(Y, plan.W, hrf, lam, y_rep, step, n_iter, args.cpu_seconds,
+                                                  cpu_dense, n_main)
+        out["cpu_baseline"] = cpu_baseline_block(cpu_dense, port, n_iter)
     if dist is not None:
         dist.destroy_process_group()
     return json.dumps(out) if rank == 0 else None
+
+
+def run_config4(args, world, rank, dev, dist, V, V_total, lo, timed, timed_local, barrier):
+    """BASELINE config 4: semi-blind deconvolution, ONE HRF dilation shared by every voxel of every
+    rank (`distributed.bd_shared`; structure of pybold/bold_signal.py:281-382): 20 outer iterations
+    of z-step (100 inner iterations, step 1/||A^T A||_F) and theta-step (normal equations ->
+    all-reduce of K^2+K+2 float64 -> 1-D search on the device), then the closing z-step.  One
+    bench step = one whole `bd_shared` call = 21 z-steps of 100 iterations."""
+    import hashlib
+    import numpy as np
+    import torch
+    from pybold_amd import data, distributed, solver
+    from pybold_amd.hrf_model import spm_hrf
+    t_r, hrf_dur, lbda, nb_outer, nb_inner, theta_true = 0.75, 20.0, 1.7, 20, 100, 0.7
+    N = args.scans
+    h_true = spm_hrf(theta_true, t_r, hrf_dur, False)[0]
+    K = len(h_true)
+    Y, _, _ = data.gen_rnd_bloc_bold_batch(V, dur=N * t_r / 60.0, tr=t_r, hrf=h_true, nb_events=5, avg_dur=12.0,
+                                           std_dur=1.0, snr=10.0, seed=4000 + rank, device=dev)
+    comm = distributed.Comm()                    # RCCL under torchrun, gloo in the rehearsal, nothing for one process
+    res = {}
+
+    def one_step():
+        res["W"], res["h"], res["d"] = distributed.bd_shared(Y, t_r, lbda=lbda, theta_0=2.0, hrf_dur=hrf_dur,
+                                                             nb_iter=nb_outer, nb_inner=nb_inner, comm=comm)
+
+    elapsed, step_ms = timed(one_step, args.steps, args.warmup, args.spin_seconds)
+    n_z = nb_outer + 1
+    value = float(V_total) * n_z * nb_inner * args.steps / elapsed
+    d = res["d"]
+    # the z-steps alone (this rank, no collective): the shared-HRF pair kernel reading taps and step
+    # from device memory, warm-started, n_z launches of nb_inner iterations
+    taps = torch.from_numpy(np.ascontiguousarray(res["h"])).to(dev)
+    stepc = 1.0 / solver.gram_frobenius_batch(taps.reshape(1, -1), N)
+    Wz = torch.zeros((V, N), dtype=torch.float64, device=dev)
+
+    def z_steps():
+        for _ in range(n_z):
+            solver.fista_solve_pp(Y, taps, stepc, lbda, nb_inner, W0=Wz, inplace=True)
+    _, z_ms = timed_local(z_steps, 3, 1, 0.05)
+    n_main, main_kernel, tail_kernel = solver.launch_plan(N, K, max(V, 1))
+    V_dom = n_main if n_main > 0 else V
+    Wd = torch.zeros((V_dom, N), dtype=torch.float64, device=dev)
+    Yd = Y[:V_dom]
+    _, dom_ms = timed_local(lambda: solver.fista_solve_pp(Yd, taps, stepc, lbda, nb_inner, W0=Wd, inplace=True,
+                                                          force="fast2"), 10, 2, 0.05)
+    flops_launch = flops_per_voxel_iter(N, K) * float(V_dom) * nb_inner
+    exec_launch = executed_flops_per_voxel_iter(N, K) * float(V_dom) * nb_inner
+    alg_bytes = BYTES_PER_VOXEL_ITER_PER_SCAN * N * float(V_dom) * nb_inner
+    ms_step = elapsed / args.steps * 1e3
+    theta = np.asarray(d["theta"], dtype=np.float64)
+    out = {
+        "metric": "voxel-iterations/sec", "value": value, "unit": "voxel-iterations/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "untimed_spin_s": args.spin_seconds,
+        **({"rehearsal": True} if args.rehearse_on_one_gpu else {}),
+        "ms_per_step": ms_step, "wall_clock_to_eps_ms": ms_step, "higher_is_better": True,
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
+        "dtype_note": "z-steps: FIR/scans fp32 (packed), iterate fp64; normal equations, theta fit, HRF model, "
+                      "step constant and the all-reduce fp64",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE config 4: semi-blind deconvolution with ONE shared HRF dilation, %d voxels "
+                               "x %d scans (TR %.2f s, HRF %g s = %d taps, true dilation %.1f, start 2.0, SNR 10 dB), "
+                               "lambda=%g, %d outer x %d inner iterations + closing z-step per step%s"
+                               % (V_total, N, t_r, hrf_dur, K, theta_true, lbda, nb_outer, nb_inner,
+                                  "" if world == 1 else ", %d GPUs (%s scaling)" % (world, args.scaling)),
+                   "baseline_config": 4, "voxels_total": V_total, "voxels_this_rank": V, "scans": N, "taps": int(K),
+                   "iters_per_step": n_z * nb_inner,
+                   "kernel": solver.KERNEL_NAMES[2] + " reading ONE shared HRF from device memory",
+                   "launches_per_outer_iteration": "z-step (whole rounds + remainder), normal equations (cumsum "
+                                                   "and ||w||_1 folded in) + fixed-order reduce, theta fit (HRF, "
+                                                   "its step constant and the cost folded in)",
+                   "parallelism": "contiguous voxel shards x%d; ONE all-reduce (SUM) of %d float64 per outer "
+                                  "iteration" % (world, K * K + K + 2)},
+        "config4": {"end_to_end_ms": ms_step, "z_steps_ms": z_ms, "theta_steps_and_glue_ms": ms_step - z_ms,
+                    "z_step_fraction": z_ms / ms_step,
+                    "theta_final": float(theta[-1]), "theta_true": theta_true,
+                    "theta_trajectory": [round(float(t), 9) for t in theta],
+                    "theta_trajectory_sha256_16": hashlib.sha256(np.round(theta, 9).tobytes()).hexdigest()[:16],
+                    "cost_first_last": [float(d["J"][1]), float(d["J"][-1])]},
+        "roofline": {"bound": "valu_fp32", "achieved": flops_launch / (dom_ms * 1e-3) / 1e12,
+                     "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": flops_launch / (dom_ms * 1e-3) / 1e12 / VALU_FP32_PEAK_TFLOPS, "traffic": None,
+                     "kernel_ms": dom_ms, "kernel_problems": V_dom, "kernel_iterations": nb_inner,
+                     "flops_per_voxel_iteration": flops_per_voxel_iter(N, K),
+                     "algorithmic_flops_per_launch": flops_launch,
+                     "executed_flops_per_voxel_iteration": executed_flops_per_voxel_iter(N, K),
+                     "frac_executed": exec_launch / (dom_ms * 1e-3) / 1e12 / VALU_FP32_PEAK_TFLOPS,
+                     "hbm_algorithmic_GBps": alg_bytes / (dom_ms * 1e-3) / 1e9,
+                     "hbm_algorithmic_frac": alg_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "whole_job_valu_frac": flops_per_voxel_iter(N, K) * float(V) * n_z * nb_inner /
+                                            (step_ms * 1e-3) / 1e12 / VALU_FP32_PEAK_TFLOPS,
+                     "note": "dominant kernel = one z-step launch (100 iterations, warm start read from and written "
+                             "to HBM) of the pair form with the HRF in device memory; whole_job_valu_frac prices the "
+                             "whole bd_shared call (theta-steps, all-reduce and launch gaps included) the same way"},
+    }
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        # parity of the WHOLE loop on a sub-batch: GPU vs the float64 NumPy oracle, same 48 voxels, 3 outer iterations
+        from oracle.shared_ops import OracleOps
+        idx = np.random.RandomState(0).choice(V, size=min(48, V), replace=False)
+        Ys = Y[torch.from_numpy(np.sort(idx)).to(dev)].contiguous()
+        Wg, hg, dg = distributed.bd_shared(Ys, t_r, lbda=lbda, theta_0=2.0, hrf_dur=hrf_dur, nb_iter=3, nb_inner=nb_inner)
+        class _OneProcess:                       # the oracle run never talks to other ranks
+            world_size, rank = 1, 0
+
+            @staticmethod
+            def allreduce_(t):
+                return t
+        Wo, ho, do = distributed.bd_shared(Ys.cpu(), t_r, lbda=lbda, theta_0=2.0, hrf_dur=hrf_dur, nb_iter=3,
+                                           nb_inner=nb_inner, ops=OracleOps(N, t_r, hrf_dur), comm=_OneProcess())
+        Wg, Wo = Wg.cpu().numpy(), Wo.numpy()
+        out["parity"] = {"max_abs_dtheta_vs_cpu_oracle": float(np.abs(np.asarray(dg["theta"]) - np.asarray(do["theta"])).max()),
+                         "max_rel_l2_diff_z_vs_cpu_oracle": float((np.linalg.norm(Wg - Wo, axis=1) /
+                                                                   (np.linalg.norm(Wo, axis=1) + 1e-300)).max()),
+                         "voxels_checked": int(len(idx)), "outer_iterations_checked": 3, "tolerance": 1e-5,
+                         "sample": "random voxels of the batch solved alone, whole loop (z-steps, normal equations, "
+                                   "theta fits) on the GPU vs the float64 NumPy oracle"}
+    return out
 
 
 def pcie_inclusive(plan, Y, hrf, lbda, step, n_iter, solver, torch, dev, pipelined):
@@ -445,26 +654,67 @@ def cpu_dense_baseline(n_scans, n_iter, lbda, target_s):
             "seconds": inner, "seconds_incl_process_start": wall, "topology": topo}
 
 
-def cpu_baseline(Y, W_gpu, hrf, lbda, step, n_iter, target_s, dense):
-    """`value`: the dense-Toeplitz NumPy formulation on all usable host cores (see
-    cpu_dense_baseline).  `port_value`: the matrix-free C/OpenMP float64 port
-    (oracle/fista_oracle.c) on the same cores, whose output is also the parity check of the
-    GPU result on that sample."""
+def cpu_port_and_parity(Y, W_gpu, hrf, lam, y_rep, step, n_iter, target_s, dense, n_main):
+    """The matrix-free C/OpenMP float64 port (oracle/fista_oracle.c) on the usable host cores, timed
+    on a bounded sample of the same workload; its output is also the parity check of the GPU
+    result.  The sample is drawn at RANDOM over the whole batch and always holds >= 64 problems
+    of the remainder launch (problems >= n_main, another kernel form) and >= 64 of the second
+    half of the main launch."""
     import numpy as np
+    import torch
     from oracle import c_oracle
     topo = dense["topology"]
     cores = int(os.environ.get("PYBOLD_BENCH_CPU_THREADS", topo["usable_cores"]))
-    Yh = Y[:max(4 * cores, 64)].cpu().numpy().astype(np.float64)
+    P = W_gpu.shape[0]
+    rng = np.random.RandomState(12345)
+
+    def rows(idx):
+        idx = np.asarray(idx)
+        Yh = Y[torch.from_numpy(idx // y_rep).to(Y.device)].cpu().numpy().astype(np.float64)
+        lv = lam[torch.from_numpy(idx).to(lam.device)].cpu().numpy() if torch.is_tensor(lam) else lam
+        return Yh, lv
+
+    cal = rng.choice(P, size=min(P, 2 * cores), replace=False)
+    Yc, lc = rows(cal)
     t0 = time.perf_counter()
-    c_oracle.fista_batch(Yh[:2 * cores], hrf, lbda, step, n_iter, threads=cores)   # calibrate
-    per_voxel = (time.perf_counter() - t0) / (2 * cores)
-    n_sample = int(min(Y.shape[0], max(2 * cores, target_s / max(per_voxel, 1e-9))))
-    Yh = Y[:n_sample].cpu().numpy().astype(np.float64)
+    c_oracle.fista_batch(Yc, hrf, lc, step, n_iter, threads=cores)          # calibrate
+    per_problem = (time.perf_counter() - t0) / len(cal)
+    n_sample = int(min(P, max(2 * cores, target_s / max(per_problem, 1e-9))))
+    parts = []
+    if 0 < n_main < P:
+        parts.append(n_main + rng.choice(P - n_main, size=min(64, P - n_main), replace=False))
+        parts.append(n_main // 2 + rng.choice(n_main - n_main // 2, size=min(64, n_main - n_main // 2), replace=False))
+    else:
+        parts.append(P // 2 + rng.choice(P - P // 2, size=min(64, P - P // 2), replace=False))
+    forced = np.unique(np.concatenate(parts))
+    rest = np.setdiff1d(rng.choice(P, size=min(P, n_sample), replace=False), forced)[:max(0, n_sample - len(forced))]
+    idx = np.sort(np.concatenate([forced, rest]))
+    Yh, lv = rows(idx)
     t0 = time.perf_counter()
-    Wc, _, used = c_oracle.fista_batch(Yh, hrf, lbda, step, n_iter, threads=cores)
+    Wc, _, used = c_oracle.fista_batch(Yh, hrf, lv, step, n_iter, threads=cores)
     dt = time.perf_counter() - t0
-    Wg = W_gpu[:n_sample].cpu().numpy()
-    err = float((np.linalg.norm(Wg - Wc, axis=1) / (np.linalg.norm(Wc, axis=1) + 1e-300)).max())
+    Wg = W_gpu[torch.from_numpy(idx).to(W_gpu.device)].cpu().numpy()
+    nrm = np.linalg.norm(Wc, axis=1)
+    ok = nrm > 0                      # lambda = lambda_max: the solution is exactly 0 on both sides
+    err = float((np.linalg.norm(Wg - Wc, axis=1)[ok] / nrm[ok]).max()) if ok.any() else 0.0
+    zero_ok = bool(np.abs(Wg[~ok]).max() == 0.0) if (~ok).any() else True
+    port = {"port_value": len(idx) * n_iter / dt, "port_threads": int(used),
+            "port_sample": "%d problems drawn at random over the batch x %d iterations, C/OpenMP float64 "
+                           "matrix-free port (oracle/fista_oracle.c), %d threads, %.1f s"
+                           % (len(idx), n_iter, int(used), dt)}
+    parity = {"max_rel_l2_diff_z_vs_cpu_oracle": err, "voxels_checked": int(len(idx)), "tolerance": 1e-5,
+              "sample": "random over the whole batch; %d of the remainder launch, %d of the second half of the "
+                        "main launch" % (int((idx >= n_main).sum()) if 0 < n_main < P else 0,
+                                         int(((idx >= n_main // 2) & (idx < n_main)).sum()) if 0 < n_main < P
+                                         else int((idx >= P // 2).sum())),
+              "all_zero_solutions_match": zero_ok}
+    return port, parity
+
+
+def cpu_baseline_block(dense, port, n_iter):
+    """`value`: the reference's dense-Toeplitz NumPy formulation on all usable host cores (see
+    cpu_dense_baseline).  `port_value` (when measured): the matrix-free C/OpenMP port."""
+    topo = dense["topology"]
     base = {"value": dense["value"], "unit": "voxel-iterations/s", "cores": dense["workers"],
             "kind": "port",
             "sample": "%d worker processes x %d synthetic voxels x %d iterations of the reference's "
@@ -472,13 +722,10 @@ def cpu_baseline(Y, W_gpu, hrf, lbda, step, n_iter, target_s, dense):
                       "dense=True), BLAS threads = 1, %.1f s"
                       % (dense["workers"], dense["voxels_per_worker"], n_iter, dense["seconds"]),
             "cpu_count": topo["cpu_count"], "workers": dense["workers"],
-            "affinity": topo["affinity"], "cgroup_cpu_quota": topo["cgroup_cpu_quota"],
-            "port_value": n_sample * n_iter / dt, "port_threads": int(used),
-            "port_sample": "first %d voxels of the same batch x %d iterations, C/OpenMP float64 "
-                           "matrix-free port (oracle/fista_oracle.c), %d threads, %.1f s"
-                           % (n_sample, n_iter, int(used), dt)}
-    parity = {"max_rel_l2_diff_z_vs_cpu_oracle": err, "voxels_checked": n_sample, "tolerance": 1e-5}
-    return base, parity
+            "affinity": topo["affinity"], "cgroup_cpu_quota": topo["cgroup_cpu_quota"]}
+    if port:
+        base.update(port)
+    return base
 
 
 if __name__ == "__main__":

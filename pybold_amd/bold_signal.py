@@ -138,6 +138,12 @@ def _deconv_auto_lbda(y, hrf, early_stopping, tol, wind, nb_iter, nb_sub_iter, v
     sigma = np.atleast_1d(mad_daub_noise_est(y_host))
     Y, one_d = _y_to_device(y)
     if early_stopping and Y.dtype != torch.float64:
+        if Y.shape[0] >= 1024:
+            solver.warn_once("auto-lambda-f64",
+                             "deconv(lbda=None, early_stopping=True) on %d voxels runs on the all-float64 kernel "
+                             "(one problem per wave, ~3x slower than the float32-FIR batch kernels; the LDS kernel "
+                             "beyond 640 scans / 32 taps): its stop decisions sit on a rounding knife edge. "
+                             "early_stopping=False keeps the batch kernels." % Y.shape[0])
         # The inner window rule compares iterates with gradient points (the aliasing of
         # :65/:72), so its criterion tends to a CONSTANT proportional to lambda instead of 0;
         # the lambda search drives lambda down until that constant crosses `tol`, i.e. the
@@ -145,7 +151,10 @@ def _deconv_auto_lbda(y, hrf, early_stopping, tol, wind, nb_iter, nb_sub_iter, v
         # knife edge where the 1e-7 rounding of the float32-FIR kernels flips it (measured:
         # whole trajectories diverge).  This branch therefore runs on the all-float64 kernel
         # (one workgroup per voxel), which takes the reference's decisions.
-        Y = torch.from_numpy(np.ascontiguousarray(np.atleast_2d(y_host), dtype=np.float64)).to(Y.device)
+        if torch.is_tensor(y) and y.is_cuda:                 # already on the device: widen there
+            Y = Y.double() if y.dtype != torch.float64 else torch.atleast_2d(y).contiguous()
+        else:
+            Y = torch.from_numpy(np.ascontiguousarray(np.atleast_2d(y_host), dtype=np.float64)).to(Y.device)
     V, n = Y.shape
     dev = Y.device
     hrf = np.asarray(hrf, dtype=np.float64)

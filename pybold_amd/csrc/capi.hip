@@ -115,6 +115,9 @@ const ExactEntry kExact[] = {
 };
 #undef PB_EXACT
 
+// window lengths the register-resident forms carry (increment ring of wind - 2 slots in LDS)
+inline bool ring_wind(int wind) { return wind == 4 || wind == 6 || wind == 8; }
+
 // all-float64 register-resident form (one problem per wave): cheapest entry that holds (N, K)
 const ExactEntry* pick_exact(int N, int K) {
   const ExactEntry* best = nullptr;
@@ -536,10 +539,10 @@ int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mod
     if (P >= SPLIT_MIN_P && pair_carries(se, stop_mode, wind) && (stop_mode == PB_STOP_NONE || pick_wide(N, K)))
       return FORM_PAIR;
   const FastEntry* fe = pick_fast(N, K);
-  if (fe && stop_mode == PB_STOP_WINDOW && (wind != 6 || fe->S > 20)) fe = nullptr;
+  if (fe && stop_mode == PB_STOP_WINDOW && (!ring_wind(wind) || fe->S > 20)) fe = nullptr;
   if (!fe) {
     const WideEntry* we = pick_wide(N, K);
-    if (we && stop_mode == PB_STOP_WINDOW && (wind != 6 || we->S > 20)) we = nullptr;
+    if (we && stop_mode == PB_STOP_WINDOW && (!ring_wind(wind) || we->S > 20)) we = nullptr;
     return we ? 3 : 0;
   }
   Piece pc[4];
@@ -555,7 +558,7 @@ int pb_fista_plan(int N, int K, int P, int stop_mode, int wind, int* n_main, int
     tf = FORM_PAIR;                                     // one launch of the split pair form
   } else if (N >= 1 && K >= 1 && P >= 1) {
     const FastEntry* fe = pick_fast(N, K);
-    if (fe && stop_mode == PB_STOP_WINDOW && (wind != 6 || fe->S > 20)) fe = nullptr;
+    if (fe && stop_mode == PB_STOP_WINDOW && (!ring_wind(wind) || fe->S > 20)) fe = nullptr;
     if (fe) {
       Piece pc[4];
       const int npc = plan_pieces(P, pair_carries(fe, stop_mode, wind),
@@ -574,7 +577,7 @@ int pb_fista_plan(int N, int K, int P, int stop_mode, int wind, int* n_main, int
       } else { nm = 0; mf = 0; tf = pc[0].form; }
     } else {
       const WideEntry* we = pick_wide(N, K);
-      if (we && stop_mode == PB_STOP_WINDOW && (wind != 6 || we->S > 20)) we = nullptr;
+      if (we && stop_mode == PB_STOP_WINDOW && (!ring_wind(wind) || we->S > 20)) we = nullptr;
       tf = we ? FORM_WIDE : FORM_GENERIC;
     }
   }
@@ -612,6 +615,7 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
   a.y_rep = y_rep; a.P = P; a.N = N; a.n_iter = n_iter; a.stop_mode = stop_mode;
   a.taps_pp = nullptr; a.ldt = 0; a.step_vec = nullptr; a.step_shared = 0; a.K = K; a.p0 = 0;
   a.cold = (flags & PB_FLAG_COLD_START) ? 1 : 0;
+  a.wind = wind;
 
   // series of 16 S < N <= 32 S scans (the reference's 600-scan demo): the pair form with the two
   // halves of ONE series in the slots of a row, in one launch; the window rule as a certificate,
@@ -638,7 +642,7 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
   const FastEntry* fe = (flags & PB_FLAG_FORCE_GENERIC) ? nullptr : pick_fast(N, K);
   // the register-resident window rule keeps wind-1 = 5 iterates in VGPRs: wind = 6
   // (the reference default) on entries small enough to hold them; else LDS kernel
-  if (fe && stop_mode == PB_STOP_WINDOW && (wind != 6 || fe->S > 20)) fe = nullptr;
+  if (fe && stop_mode == PB_STOP_WINDOW && (!ring_wind(wind) || fe->S > 20)) fe = nullptr;
   if (fe && (flags & PB_FLAG_FORCE_WIDE)) fe = nullptr;
   // Window rule on the pair form: a per-iteration no-fire certificate (fista_pair_ffa.h), then an
   // exact re-solve of the problems it could not clear (n_done = -1) on the single-row form.  Worth
@@ -750,7 +754,7 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
   // long series: one problem per wave (window rule: wind = 6 and S <= 20, as above)
   if (!(flags & PB_FLAG_FORCE_GENERIC)) {
     const WideEntry* we = pick_wide(N, K);
-    if (we && stop_mode == PB_STOP_WINDOW && (wind != 6 || we->S > 20)) we = nullptr;
+    if (we && stop_mode == PB_STOP_WINDOW && (!ring_wind(wind) || we->S > 20)) we = nullptr;
     if (we) {
       if (we->fn(a, taps_host, K, J_dev != nullptr, stop_mode, (hipStream_t)stream) != 0)
         return fail(PB_ERR_INVALID, "pb_fista_solve: no one-problem-per-wave form for this stop rule");

@@ -61,6 +61,7 @@ struct FistaArgs {
   int stop_mode;
   int K;                  // number of taps actually used (<= KT)
   int cold;               // 1: the iterate starts from 0, a.w is written only
+  int wind = 6;           // window rule: stored iterates (register-resident forms: 4, 6 or 8)
   int only_flagged = 0;   // 1: solve only the problems with n_done[p] < 0 (left by the certificate
                           //    form of the pair kernel, fista_pair_ffa.h), skip the others
 };
@@ -101,8 +102,27 @@ struct Window {
 // LPV = lanes per problem: 16 (one DPP row, four problems per wave; series up to 16*S
 // scans) or 64 (one problem per wave for long series, up to 64*S scans: halo through
 // wave_shr/shl:1 chains, scans with the row_bcast steps).
-template <int S, int KT, bool WITH_J, int STOP, bool PP = false, int LPV = 16>
+// Weights of the window rule for `wind` = W stored iterates [u_{k-W+2} .. u_k, w_{k+1}]
+// (pybold/bold_signal.py:82-95: old = mean of the first W - W/2, new = mean of the last W/2).
+// With delta_i = u_i - u_{i-1}, e = w_{k+1} - u_k, NN = W/2, NO = W - NN:
+//   NN (new - old) = sum_{t=0}^{W-3} num(t) delta_{k-t} + e,   num(t) = c_t NN / NO - a_t
+//   NN new         = NN u_k + sum_t den(t) delta_{k-t} + e,    den(t) = -a_t
+//   a_t = max(NN - 2 - t, 0),  c_t = W - 1 - max(NN - 1, t + 1)
+// (W = 6: 2, 3, 2, 1 and -1, 0, 0, 0).  W - 2 increments are live: the newest plus W - 3 stored.
+template <int W>
+struct WinCoef {
+  static constexpr int NN = W / 2, NO = W - W / 2, NR = W - 2;
+  static constexpr int a(int t) { return NN - 2 - t > 0 ? NN - 2 - t : 0; }
+  static constexpr int c(int t) { return W - 1 - (NN - 1 > t + 1 ? NN - 1 : t + 1); }
+  static constexpr float num(int t) { return (float)(c(t) * NN) / (float)NO - (float)a(t); }
+  static constexpr float den(int t) { return -(float)a(t); }
+};
+
+template <int S, int KT, bool WITH_J, int STOP, bool PP = false, int LPV = 16, int WIND = 6>
 __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<KT> taps) {
+  static_assert(WIND >= 4 && WIND <= 8, "register-resident window rule: 4 <= wind <= 8");
+  using WC = WinCoef<WIND>;
+  constexpr int NR = WC::NR;                // ring slots: increments delta_k .. delta_{k-NR+1}
   static_assert(LPV == 16 || LPV == 64, "a problem occupies one DPP row or one wave");
   constexpr int H = KT - 1;                 // halo length
   constexpr int D = (H + S - 1) / S;        // neighbour lanes that contribute halo
@@ -175,23 +195,23 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
     if constexpr (PP) return even_v[t]; else return taps.even[t];
   };
 
-  // window rule (wind = 6): the criterion is a function of the current u_k, w_{k+1} and of
-  // the last four INCREMENTS delta_i = u_i - u_{i-1} only (see the update below).  u_{k-1}
-  // stays in float64 registers; the increments, small numbers, are stored as float32 in an
-  // LDS ring [slot = i mod 4][sample][lane] (relative accuracy 6e-8 of the increments, i.e.
-  // of the criterion itself).  Each lane reads back only what it wrote: no barrier.
-  constexpr int WIND = 6;
+  // window rule: the criterion is a function of the current u_k, w_{k+1} and of the last
+  // wind - 2 INCREMENTS delta_i = u_i - u_{i-1} only (WinCoef above).  u_{k-1} stays in float64
+  // registers; the increments, small numbers, are stored as float32 in an LDS ring
+  // [slot][sample][lane] (relative accuracy 6e-8 of the increments, i.e. of the criterion
+  // itself).  Each lane reads back only what it wrote: no barrier.
   double uprev[STOP == 2 ? S : 1];
   float* ring = nullptr;
+  int rp = 0;                               // ring slot that receives delta_k
   if constexpr (STOP == 2) {
     extern __shared__ __attribute__((aligned(16))) char fast_smem[];
-    ring = reinterpret_cast<float*>(fast_smem) + ((threadIdx.x / LPV) * 4 * S * LPV + sub);
+    ring = reinterpret_cast<float*>(fast_smem) + ((threadIdx.x / LPV) * NR * S * LPV + sub);
 #pragma unroll
     for (int j = 0; j < S; ++j) uprev[j] = 0.0;
-    // slots 1..3 are read (as delta_{k-1..k-3}) before iterations 1..3 have written them;
-    // each lane owns its slots, so it zeroes them itself and no barrier is needed
+    // the older slots are read before the first iterations have written them; each lane owns
+    // its slots, so it zeroes them itself and no barrier is needed
 #pragma unroll
-    for (int q = 0; q < 4 * S; ++q) ring[q * LPV] = 0.0f;
+    for (int q = 0; q < NR * S; ++q) ring[q * LPV] = 0.0f;
   }
 
   bool active = live;                       // per-problem (row-uniform) early-stop state; idle rows never hold a wave
@@ -346,21 +366,23 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
         num = seg_allsum_f64<LPV>(num);
         den = seg_allsum_f64<LPV>(den);
       } else {
-        // deconv window rule, wind = 6 (pybold/bold_signal.py:82-95): the stored iterates
-        // are [u_{k-4} .. u_k, w_{k+1}] (each stored w was overwritten in place by the next
-        // gradient step, :65/:72); old = mean of the first three, new = mean of the last
-        // three.  With delta_i = u_i - u_{i-1} and e = w_{k+1} - u_k:
-        //   3 (new - old) = delta_{k-3} + 2 delta_{k-2} + 3 delta_{k-1} + 2 delta_k + e
-        //   3 new         = 3 u_k - delta_k + e
-        // (sums left unscaled, so is the 1e-10 floor).  delta_k and e are differences of
-        // float64 values rounded to float32 (relative accuracy 6e-8 each); the two norms are
-        // then accumulated as one packed float32 pair.  The criterion is accurate to ~1e-6
-        // relative, well inside what the float32 FIRs of the iterate itself leave of it.
-        floor_eps = 3.0e-10;
-        const float* r1 = ring + ((it + 3) & 3) * S * LPV;   // delta_{k-1}
-        const float* r2 = ring + ((it + 2) & 3) * S * LPV;   // delta_{k-2}
-        const float* r3 = ring + ((it + 1) & 3) * S * LPV;   // delta_{k-3}
-        float* r0 = ring + (it & 3) * S * LPV;               // delta_k goes here
+        // deconv window rule (pybold/bold_signal.py:82-95): the stored iterates are
+        // [u_{k-W+2} .. u_k, w_{k+1}] (each stored w was overwritten in place by the next gradient
+        // step, :65/:72); old = mean of the first W - W/2, new = mean of the last W/2; weights:
+        // WinCoef (sums left unscaled by NN, so is the 1e-10 floor).  delta_k and e are
+        // differences of float64 values rounded to float32 (relative accuracy 6e-8 each); the two
+        // norms are then accumulated as one packed float32 pair.  The criterion is accurate to
+        // ~1e-6 relative, well inside what the float32 FIRs of the iterate itself leave of it.
+        floor_eps = WC::NN * 1.0e-10;
+        const float* rt[NR];                                   // rt[t] -> delta_{k-t}, t >= 1
+#pragma unroll
+        for (int t = 1; t < NR; ++t) {
+          int q = rp - t;
+          q = q < 0 ? q + NR : q;
+          rt[t] = ring + q * S * LPV;
+        }
+        float* r0 = ring + rp * S * LPV;                       // delta_k goes here
+        rp = (rp + 1 == NR) ? 0 : rp + 1;
         f2 nd = f2{0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < S; ++j) {
@@ -370,8 +392,19 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
           const float dk = (float)(u - uprev[j]);
           const float ef = (float)(wn - u);
           const float uf = (float)u;
-          const float dsum = fmaf(2.0f, dk, fmaf(3.0f, r1[j * LPV], fmaf(2.0f, r2[j * LPV], r3[j * LPV])));
-          const f2 v = f2{dsum + ef, fmaf(3.0f, uf, ef - dk)};
+          float dsum = WC::num(NR - 1) * rt[NR - 1][j * LPV];  // oldest first (num = 1: exact)
+          float dden = 0.0f;
+          static_for<1, NR - 1>([&](auto tc) {
+            constexpr int t = NR - 1 - decltype(tc)::value;    // NR-2 .. 1
+            const float dt = rt[t][j * LPV];
+            dsum = fmaf(WC::num(t), dt, dsum);
+            if constexpr (WC::den(t) != 0.0f) dden = fmaf(WC::den(t), dt, dden);
+          });
+          dsum = fmaf(WC::num(0), dk, dsum);
+          float tail = ef;
+          if constexpr (WC::den(0) != 0.0f) tail = fmaf(WC::den(0), dk, ef);
+          if constexpr (WC::NN > 3) tail += dden;
+          const f2 v = f2{dsum + ef, fmaf((float)WC::NN, uf, tail)};
           nd = __builtin_elementwise_fma(v, v, nd);
           r0[j * LPV] = dk;
           uprev[j] = u;
@@ -382,8 +415,8 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
       }
       if (active) {
         done = it + 1;
-        constexpr int first_test = (STOP == 1) ? 3 : WIND + 1;
-        static_assert(STOP != 2 || first_test >= 4, "the increment ring holds 4 valid slots from it = 3 on");
+        constexpr int first_test = (STOP == 1) ? 3 : WIND + 1;   // `idx > wind` (:85)
+        static_assert(STOP != 2 || first_test >= NR - 1, "every ring slot is valid at the first test");
         if (it >= first_test && sqrt(num) / (sqrt(den) + floor_eps) < a.tol) {
           active = false;
           if (live) {                           // this problem is finished: write it out now

@@ -19,10 +19,24 @@ int launch_fast(const FistaArgs& a, const double* taps, int K, bool with_j, int 
   } else if (stop == PB_STOP_LOOPS) {
     if (with_j) hipLaunchKernelGGL((fista_fast_kernel<S, KT, true, 1>), grid, block, 0, st, a, tp);
     else hipLaunchKernelGGL((fista_fast_kernel<S, KT, false, 1>), grid, block, 0, st, a, tp);
-  } else {   // PB_STOP_WINDOW with wind = 6 (checked by the caller): LDS ring of 4 increments
-    const size_t lds = (size_t)16 * 4 * S * 16 * sizeof(float);
-    if (with_j) hipLaunchKernelGGL((fista_fast_kernel<S, KT, true, 2>), grid, block, lds, st, a, tp);
-    else hipLaunchKernelGGL((fista_fast_kernel<S, KT, false, 2>), grid, block, lds, st, a, tp);
+  } else {   // PB_STOP_WINDOW with wind in {4, 6, 8} (checked by the caller): LDS ring of wind - 2 increments
+    if constexpr (S <= 20) {
+      const size_t lds = (size_t)16 * (a.wind - 2) * S * 16 * sizeof(float);
+      if (a.wind == 6) {
+        if (with_j) hipLaunchKernelGGL((fista_fast_kernel<S, KT, true, 2>), grid, block, lds, st, a, tp);
+        else hipLaunchKernelGGL((fista_fast_kernel<S, KT, false, 2>), grid, block, lds, st, a, tp);
+      } else if (a.wind == 4) {
+        if (with_j) hipLaunchKernelGGL((fista_fast_kernel<S, KT, true, 2, false, 16, 4>), grid, block, lds, st, a, tp);
+        else hipLaunchKernelGGL((fista_fast_kernel<S, KT, false, 2, false, 16, 4>), grid, block, lds, st, a, tp);
+      } else if (a.wind == 8) {
+        if (with_j) hipLaunchKernelGGL((fista_fast_kernel<S, KT, true, 2, false, 16, 8>), grid, block, lds, st, a, tp);
+        else hipLaunchKernelGGL((fista_fast_kernel<S, KT, false, 2, false, 16, 8>), grid, block, lds, st, a, tp);
+      } else {
+        return 1;
+      }
+    } else {
+      return 1;   // no increment ring for S > 20: the caller must not come here
+    }
   }
   return 0;
 }
@@ -38,11 +52,21 @@ int launch_wide(const FistaArgs& a, const double* taps, int K, bool with_j, int 
   } else if (stop == PB_STOP_LOOPS) {
     if (with_j) hipLaunchKernelGGL((fista_fast_kernel<S, KT, true, 1, false, 64>), grid, block, 0, st, a, tp);
     else hipLaunchKernelGGL((fista_fast_kernel<S, KT, false, 1, false, 64>), grid, block, 0, st, a, tp);
-  } else {   // PB_STOP_WINDOW, wind = 6 and S <= 20 (checked by the caller)
+  } else {   // PB_STOP_WINDOW, wind in {4, 6, 8} and S <= 20 (checked by the caller)
     if constexpr (S <= 20) {
-      const size_t lds = (size_t)4 * 4 * S * 64 * sizeof(float);
-      if (with_j) hipLaunchKernelGGL((fista_fast_kernel<S, KT, true, 2, false, 64>), grid, block, lds, st, a, tp);
-      else hipLaunchKernelGGL((fista_fast_kernel<S, KT, false, 2, false, 64>), grid, block, lds, st, a, tp);
+      const size_t lds = (size_t)4 * (a.wind - 2) * S * 64 * sizeof(float);
+      if (a.wind == 6) {
+        if (with_j) hipLaunchKernelGGL((fista_fast_kernel<S, KT, true, 2, false, 64>), grid, block, lds, st, a, tp);
+        else hipLaunchKernelGGL((fista_fast_kernel<S, KT, false, 2, false, 64>), grid, block, lds, st, a, tp);
+      } else if (a.wind == 4) {
+        if (with_j) hipLaunchKernelGGL((fista_fast_kernel<S, KT, true, 2, false, 64, 4>), grid, block, lds, st, a, tp);
+        else hipLaunchKernelGGL((fista_fast_kernel<S, KT, false, 2, false, 64, 4>), grid, block, lds, st, a, tp);
+      } else if (a.wind == 8) {
+        if (with_j) hipLaunchKernelGGL((fista_fast_kernel<S, KT, true, 2, false, 64, 8>), grid, block, lds, st, a, tp);
+        else hipLaunchKernelGGL((fista_fast_kernel<S, KT, false, 2, false, 64, 8>), grid, block, lds, st, a, tp);
+      } else {
+        return 1;
+      }
     } else {
       return 1;   // no increment ring for S > 20: the caller must not come here
     }

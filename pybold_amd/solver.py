@@ -33,6 +33,39 @@ _FORCE = {None: 0, "generic": PB_FLAG_FORCE_GENERIC, "fast": PB_FLAG_FORCE_FAST,
           "nocert": PB_FLAG_NO_CERT}
 
 
+_warned = set()
+
+
+def warn_once(key, message):
+    """One ``RuntimeWarning`` per process and ``key``: the silent performance cliffs of the
+    dispatch (LDS kernel, all-float64 kernel) are made loud here, not in a header."""
+    if key not in _warned:
+        _warned.add(key)
+        import warnings
+        warnings.warn(message, RuntimeWarning, stacklevel=3)
+
+
+def _warn_if_slow_kernel(lib, N, K, P, want_J, stop, wind, flags):
+    """The any-size LDS kernel is 10-20x slower per voxel-iteration than the register-resident
+    forms; say so once when a batch of some size lands on it by dispatch (not by `force`)."""
+    if P < 256 or (flags & (PB_FLAG_FORCE_GENERIC | PB_FLAG_FORCE_FAST)):
+        return
+    if lib.pb_fista_which_kernel(int(N), int(K), int(P), int(bool(want_J)), _STOP[stop], int(wind)) != 0:
+        return
+    why = []
+    if _STOP[stop] == PB_STOP_WINDOW and wind not in (4, 5, 6, 7, 8):
+        why.append("wind=%d (register-resident window rule: 4 <= wind <= 8)" % wind)
+    if _STOP[stop] == PB_STOP_WINDOW and N > 1216:
+        why.append("window rule beyond 1216 scans")
+    if K > 48:
+        why.append("HRF of %d taps (> 48)" % K)
+    if N > 2432:
+        why.append("series of %d scans (> 2432)" % N)
+    warn_once(("lds", N, K, _STOP[stop], wind),
+              "pybold_amd: %d problems (N=%d, K=%d) run on the any-size LDS kernel, 10-20x slower per "
+              "voxel-iteration than the register-resident kernels: %s" % (P, N, K, "; ".join(why) or "shape outside the tables"))
+
+
 def device(dev=None):
     """The HIP device to run on; raises when no GPU is visible (no CPU path)."""
     if not torch.cuda.is_available():
@@ -200,6 +233,7 @@ def fista_solve(Y, hrf, lbda, step, n_iter, W0=None, want_J=False, stop=None,
                 _stream_ptr(dev))
         _lib.check(rc, "pb_fista_solve_d")
         return W, J, n_done
+    _warn_if_slow_kernel(lib, N, taps.size, P, want_J, stop, wind, _FORCE[force])
     with torch.cuda.device(dev):
         rc = lib.pb_fista_solve(
             Y.data_ptr(), _ld(Y), int(y_rep), W.data_ptr(), _ld(W), P, N,
@@ -215,8 +249,11 @@ def fista_solve(Y, hrf, lbda, step, n_iter, W0=None, want_J=False, stop=None,
 
 class FistaPlan:
     """Pre-allocated, launch-only form of :func:`fista_solve` for hot loops and
-    graph capture: ``run()`` enqueues a memset of the iterate and ONE
-    ``pb_fista_solve`` launch on the current stream and allocates nothing."""
+    graph capture: ``run()`` makes ONE ``pb_fista_solve`` call on the current stream of the
+    plan's device (a cold start: no memset, the kernels start from 0) and allocates nothing.
+    That call enqueues up to four kernels -- whole rounds of waves on the densest form, the
+    remainder on others, part of it on the library's side stream (forked from and joined back
+    into the current stream; see ``include/pybold_hip.h``)."""
 
     def __init__(self, Y, hrf, lbda, step, n_iter, y_rep=1, force="fast", W=None):
         self.lib = _lib.load()
@@ -247,12 +284,14 @@ class FistaPlan:
     def launch(self, cold=False):
         """Only the solver launch: the iterate continues from its current value, or
         (``cold``) starts from 0 without being read."""
-        rc = self.lib.pb_fista_solve(
-            self.Y.data_ptr(), _ld(self.Y), self.y_rep, self.W.data_ptr(), _ld(self.W), self.P,
-            self.N, self.taps.ctypes.data, self.taps_dev.data_ptr(), self.taps.size, self.step,
-            self.lbda, self.lbda_dev.data_ptr() if self.lbda_dev is not None else None,
-            self.betas.data_ptr(), self.n_iter, None, 0, PB_STOP_NONE, 0.0, 0,
-            self.n_done.data_ptr(), self.flags | (PB_FLAG_COLD_START if cold else 0), _stream_ptr(self.dev))
+        # the library finds its per-device side stream and wave count through the CURRENT device
+        with torch.cuda.device(self.dev):
+            rc = self.lib.pb_fista_solve(
+                self.Y.data_ptr(), _ld(self.Y), self.y_rep, self.W.data_ptr(), _ld(self.W), self.P,
+                self.N, self.taps.ctypes.data, self.taps_dev.data_ptr(), self.taps.size, self.step,
+                self.lbda, self.lbda_dev.data_ptr() if self.lbda_dev is not None else None,
+                self.betas.data_ptr(), self.n_iter, None, 0, PB_STOP_NONE, 0.0, 0,
+                self.n_done.data_ptr(), self.flags | (PB_FLAG_COLD_START if cold else 0), _stream_ptr(self.dev))
         _lib.check(rc, "pb_fista_solve")
 
     def run(self):

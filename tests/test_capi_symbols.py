@@ -59,7 +59,9 @@ def test_version_and_dispatch_table(lib):
     assert lib.pb_fista_which_kernel(300, 30, 100000, 1, 0, 6) == 2      # cost trace: pair form too
     assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 2, 6) == 2      # window rule: certificate on the pair form
     assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 1, 6) == 1      # _loops_deconv rule: single-row form
-    assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 2, 4) == 0
+    assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 2, 4) == 1      # wind 4 / 8: full rule, single-row form
+    assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 2, 8) == 1
+    assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 2, 5) == 0      # other windows: LDS kernel (the Python layer warns)
     assert lib.pb_fista_which_kernel(300, 30, 1, 0, 0, 6) == 3           # a few short series: one per wave
     assert lib.pb_fista_which_kernel(300, 30, 10000, 0, 0, 6) == 2       # config 2: half a round of pair waves + a remainder
     assert lib.pb_fista_which_kernel(300, 30, 4096, 0, 0, 6) == 1        # single-row kernel

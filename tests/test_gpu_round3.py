@@ -219,3 +219,50 @@ def test_split_pair_form_window_rule(solver):
     Wd, _, ndd = solver.fista_solve(Yb, hrf, 0.7, 1.0 / lip, 200, want_J=True, stop="window", tol=1e-6, wind=6)
     Wp, _, _ = solver.fista_solve(Yb, hrf, 0.7, 1.0 / lip, 200, want_J=True)
     assert int(ndd.min()) == 200 and torch.equal(Wd, Wp)
+
+
+# ---- window rule at wind = 4 and 8, and float32 ring vs float64 kernel ------------------------------
+@pytest.mark.parametrize("wind", [4, 8])
+@pytest.mark.parametrize("force", ["fast1", "wide", None])
+def test_window_rule_other_window_lengths(solver, golden, wind, force):
+    """wind = 4 / 8 stay register-resident (increment ring of wind - 2 slots): stop iterations and
+    iterates equal the float64 oracle's (pybold/bold_signal.py:82-95 with that `wind`)."""
+    g = golden("early_stop")
+    hrf, lip = g["hrf"], float(g["lipschitz"])
+    assert "LDS" not in solver.which_kernel(300, 30, 5000, stop="window", wind=wind)
+    Y, _ = synthetic(11, seed=20 + wind)
+    Y[4] = torch.from_numpy(g["y"]).float().cuda()
+    Yh = Y.cpu().numpy().astype(np.float64)
+    fired = 0
+    for tol in (0.1, 0.02, 0.005):
+        out = [orc.deconv_fixed_lbda(Yh[v], hrf, 1.0, nb_iter=400, tol=tol, wind=wind, lipschitz=lip, dense=False)
+               for v in range(len(Yh))]
+        Wr, nr = np.stack([o[2] for o in out]), np.array([o[4] for o in out])
+        fired += int((nr < 400).sum())
+        W, J, nd = solver.fista_solve(Y, hrf, 1.0, 1.0 / lip, 400, want_J=True, stop="window", tol=tol, wind=wind,
+                                      force=force)
+        assert (nd.cpu().numpy() == nr).all(), (wind, force, tol, nd.cpu().numpy(), nr)
+        assert rel_rows(W.cpu().numpy(), Wr) < EPS
+    assert fired >= 11, fired                           # the rule did fire in a good part of the cases
+
+
+def test_window_rule_float32_ring_agrees_with_float64_kernel(solver, golden):
+    """Consecutive increments alternate in sign, so the window combination cancels: the batch kernels
+    (float32 FIRs, float32 increment ring) must still stop where the all-float64 kernel does.
+    Allowed mismatch: none of 3 x 3 x 64 cases may differ by more than one iteration, at most
+    1 % may differ at all."""
+    g = golden("early_stop")
+    hrf, lip = g["hrf"], float(g["lipschitz"])
+    Y, _ = synthetic(64, seed=99)
+    total, differ = 0, 0
+    for tol in (1e-2, 2e-3, 5e-4):
+        for lbda in (0.3, 1.0, 3.0):
+            _, _, n64 = solver.fista_solve(Y.double(), hrf, lbda, 1.0 / lip, 2000, stop="window", tol=tol, wind=6)
+            for force in ("fast1", "wide"):
+                _, _, n32 = solver.fista_solve(Y, hrf, lbda, 1.0 / lip, 2000, stop="window", tol=tol, wind=6, force=force)
+                d = (n32 - n64).abs()
+                assert int(d.max()) <= 1, (tol, lbda, force, int(d.max()))
+                total += d.numel()
+                differ += int((d > 0).sum())
+            assert int(n64.min()) < 2000
+    assert differ <= 0.01 * total, (differ, total)

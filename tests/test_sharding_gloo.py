@@ -97,34 +97,11 @@ def test_single_voxel_shared_fit_equals_reference_style_fit():
 
 
 # ---- shared-HRF blind loop with the device theta-step (normal equations) -------------
-class OracleOps:
-    """CPU stand-in for distributed.HipOps: same five steps, float64 NumPy oracle."""
+from oracle.shared_ops import OracleOps as _OracleOps   # noqa: E402
 
-    def __init__(self, n):
-        self.n = n
 
-    def hrf(self, theta):
-        return torch.from_numpy(orc.spm_hrf(float(theta[0]), T_R, HRF_DUR, False)[0].copy())
-
-    def z_step(self, Y, taps, lbda, nb_inner, W):
-        if Y.shape[0] == 0:
-            return W
-        h = taps.numpy()
-        step = 1.0 / orc.gram_lipschitz(h, self.n)
-        return torch.from_numpy(orc.fista_batch(Y.numpy().astype(np.float64), h, lbda, step,
-                                                nb_inner, W0=W.numpy()))
-
-    def normal_eq(self, W, Y, K):
-        G, b, yy = orc.hrf_normal_eq(np.cumsum(W.numpy(), axis=1), Y.numpy().astype(np.float64), K) \
-            if Y.shape[0] else (np.zeros((K, K)), np.zeros(K), 0.0)
-        return torch.from_numpy(np.concatenate([G.ravel(), b, [yy]]))
-
-    def theta_fit(self, ne, bounds):
-        K = int(round((-1 + np.sqrt(1 + 4 * (ne.numel() - 1))) / 2))
-        v = ne.numpy()
-        th, f, h = orc.theta_fit_normal_eq(v[:K * K].reshape(K, K), v[K * K:K * K + K], v[-1],
-                                           T_R, HRF_DUR, bounds)
-        return torch.tensor([th]), torch.tensor([f]), torch.from_numpy(h.copy())
+def OracleOps(n):
+    return _OracleOps(n, T_R, HRF_DUR)
 
 
 def _bd_worker(rank, world, port, n_vox, ret):
