@@ -339,6 +339,30 @@ int pb_theta_fit(const double* ne_dev, int64_t ldne, int M, int K, const double*
                  double lo, double hi, int n_refine, double* theta_dev, double* cost_dev,
                  double* taps_dev, int64_t ldt, void* stream);
 
+/*
+ * The two launches of an outer iteration of the shared-HRF blind loop beside its z-step
+ * (bd, pybold/bold_signal.py:320-342, with ONE dilation for all voxels: BASELINE config 4):
+ *
+ * pb_hrf_normal_eq_w   pb_hrf_normal_eq (shared form, float32 y) straight from the INNOVATION
+ *                      w = diff_z: the cumulative sum z = cumsum(w) (:326) is taken inside the pass
+ *                      (same summation tree as pb_integ_op: bit-identical sets) and ||w||_1 (the
+ *                      regularisation term of the cost, :337-342) is summed in the same pass.
+ *                      out_dev [len + 1] = the normal equations followed by sum_v ||w_v||_1: the
+ *                      message of the outer iteration's one all-reduce.  work_dev >= len + 1.
+ * pb_theta_fit_step    pb_theta_fit on ONE such message (M = 1) that also leaves what the next
+ *                      z-step and the cost trace need on the device: step_dev [1] =
+ *                      1 / ||A^T A||_F for h(theta*) on N scans (:249-254, pb_gram_frobenius's
+ *                      closed form) and jcost_dev [1] = (2 F(theta*) + lbda ||w||_1) / ||y||^2.
+ */
+int pb_hrf_normal_eq_w(const double* w_dev, int64_t ldw, const float* y_dev, int64_t ldy,
+                       int V, int N, int K, double* work_dev, int64_t work_len, double* out_dev,
+                       void* stream);
+int pb_theta_fit_step(const double* msg_dev, int K, const double* t_dev,
+                      double a_peak, double loc_peak, double a_under, double loc_under, double ratio,
+                      double lo, double hi, int n_refine, int N, double lbda, double* theta_dev,
+                      double* cost_dev, double* taps_dev, double* step_dev, double* jcost_dev,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -104,6 +104,10 @@ SIGNATURES = {
                                     _ptr, _c_i64, _ptr, _ptr]),
     "pb_theta_fit": (_c_int, [_ptr, _c_i64, _c_int, _c_int, _ptr, _c_dbl, _c_dbl, _c_dbl, _c_dbl,
                               _c_dbl, _c_dbl, _c_dbl, _c_int, _ptr, _ptr, _ptr, _c_i64, _ptr]),
+    "pb_hrf_normal_eq_w": (_c_int, [_ptr, _c_i64, _ptr, _c_i64, _c_int, _c_int, _c_int, _ptr, _c_i64,
+                                    _ptr, _ptr]),
+    "pb_theta_fit_step": (_c_int, [_ptr, _c_int, _ptr, _c_dbl, _c_dbl, _c_dbl, _c_dbl, _c_dbl, _c_dbl,
+                                   _c_dbl, _c_int, _c_int, _c_dbl, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
 }
 
 _lib = None

@@ -127,12 +127,18 @@ __host__ __device__ inline int ne_sum_lds_doubles(int N, int K) {
   return ne_sk(N + NE_LB + NE_JB) + 1 + ne_sk(N + K + NE_LB + NE_JB) + 1 + K * K + 2 * NE_LB * 16 + 2 * K + 16;
 }
 
-template <typename TY>
+// FROM_W: `z` holds the innovation w = diff_z; the block integrates it after staging (the
+// summation tree of block_cumsum in generic.h: same z, bit for bit, as pb_integ_op gives) and
+// also sums |w| -- part[ne] = ||w||_1 of the block's voxels, one entry more per block -- so
+// that an outer iteration of the shared-HRF loop needs no pass of its own for either.
+template <typename TY, bool FROM_W = false>
 __global__ __launch_bounds__(NE_THREADS) void normal_eq_sum_kernel(const double* z, int64_t ldz,
                                                                    const TY* y, int64_t ldy, int V,
                                                                    int N, int K, double* part_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int ne = ne_len(K);
+  const int ne_out = ne + (FROM_W ? 1 : 0);
+  double l1 = 0.0;
   static_assert(NE_JB == 8 && NE_LB == 8, "ne_sk() pads every 8 samples");
   const int nz = N + NE_LB + NE_JB, ny = N + K + NE_LB + NE_JB;      // logical lengths
   double* lz = reinterpret_cast<double*>(smem);
@@ -205,6 +211,34 @@ __global__ __launch_bounds__(NE_THREADS) void normal_eq_sum_kernel(const double*
       }
     }
     __syncthreads();
+    if constexpr (FROM_W) {
+      // z = cumsum(w) in place: per-thread chunk, wave scan, 4-wave combine (block_cumsum's tree)
+      const int chunk = (N + NE_THREADS - 1) / NE_THREADS;
+      const int lo = t * chunk, hi2 = min(lo + chunk, N);
+      double local = 0.0;
+      for (int i = lo; i < hi2; ++i) {
+        const double wv = lz[ne_sk(i)];
+        local += wv;
+        l1 += fabs(wv);
+      }
+      double incl = local;
+      const int lane = t & 63, wid = t >> 6;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const double up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+      }
+      if (lane == 63) red8[wid] = incl;
+      __syncthreads();
+      double woff = 0.0;
+      for (int i = 0; i < wid; ++i) woff += red8[i];
+      double run = woff + incl - local;
+      for (int i = lo; i < hi2; ++i) {
+        run += lz[ne_sk(i)];
+        lz[ne_sk(i)] = run;
+      }
+      __syncthreads();
+    }
     if (worker) {
       for (int j0 = slice * NE_JB; j0 < jrange; j0 += slices * NE_JB) {
         double a[NE_JB], b[NE_JB + NE_LB - 1];
@@ -257,8 +291,10 @@ __global__ __launch_bounds__(NE_THREADS) void normal_eq_sum_kernel(const double*
     bulk[e] = sum;
   }
   yy = block_sum(yy, red8);                    // (syncs inside: bulk[] is visible afterwards)
-  double* part = part_out + (int64_t)blockIdx.x * ne;
+  if constexpr (FROM_W) l1 = block_sum(l1, red8);
+  double* part = part_out + (int64_t)blockIdx.x * ne_out;
   for (int e = t; e < ne; e += NE_THREADS) part[e] = 0.0;            // entries with no sample
+  if (FROM_W && t == 0) part[ne] = l1;
   __syncthreads();
   if (t < K) {
     const int d = t;
@@ -352,7 +388,8 @@ __global__ __launch_bounds__(256) void theta_fit_kernel(const double* ne_sets, i
                                                         int K, const double* t, HrfModel hm,
                                                         double lo, double hi, int n_refine,
                                                         double* theta, double* cost, double* taps,
-                                                        int64_t ldt) {
+                                                        int64_t ldt, int n_scans, double* step_out,
+                                                        double lbda, double* jcost_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int s = blockIdx.x;
   if (s >= M) return;
@@ -468,6 +505,19 @@ __global__ __launch_bounds__(256) void theta_fit_kernel(const double* ne_sets, i
   if (taps) {
     double* trow = taps + (int64_t)s * ldt;
     for (int k = threadIdx.x; k < K; k += 256) trow[k] = h1[k];
+  }
+  // what the next z-step needs beside the taps: its step 1 / ||A^T A||_F for the new HRF
+  // (pybold/bold_signal.py:249-254; closed form of gram_frobenius_fir_wave, first wave), and the
+  // normalised cost of this outer iteration (2 F + lbda ||w||_1) / ||y||^2 (:337-342), ||w||_1
+  // being the entry behind the normal equations (pb_hrf_normal_eq_w)
+  if (step_out && n_scans > 0 && wv == 0) {
+    const double fro = gram_frobenius_fir_wave(h1, K, n_scans, v1 + K, lane);
+    if (lane == 0) step_out[s] = 1.0 / fro;
+  }
+  if (jcost_out && threadIdx.x == 0) {
+    double f = 0.0;
+    for (int m = 0; m < K; ++m) f += v1[m];
+    jcost_out[s] = (2.0 * (0.5 * yy + f) + lbda * src[ne]) / yy;
   }
 }
 

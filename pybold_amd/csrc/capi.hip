@@ -1018,8 +1018,54 @@ int pb_theta_fit(const double* ne_dev, int64_t ldne, int M, int K, const double*
                   std::exp(-lgamma(a_under))};
   hipLaunchKernelGGL(pb::theta_fit_kernel, dim3(M), dim3(256), (size_t)nd * sizeof(double),
                      (hipStream_t)stream, ne_dev, ldne, M, K, t_dev, hm, lo, hi, n_refine, theta_dev,
-                     cost_dev, taps_dev, ldt);
+                     cost_dev, taps_dev, ldt, 0, (double*)nullptr, 0.0, (double*)nullptr);
   return check_launch("pb_theta_fit");
+}
+
+int pb_theta_fit_step(const double* msg_dev, int K, const double* t_dev, double a_peak,
+                      double loc_peak, double a_under, double loc_under, double ratio, double lo,
+                      double hi, int n_refine, int N, double lbda, double* theta_dev,
+                      double* cost_dev, double* taps_dev, double* step_dev, double* jcost_dev,
+                      void* stream) {
+  if (K < 1 || K > 127 || N < K || n_refine < 1 || !(a_peak > 0.0) || !(a_under > 0.0) || !(lo <= hi))
+    return fail(PB_ERR_INVALID, "pb_theta_fit_step: bad argument");
+  const int64_t nd = (int64_t)pb::ne_len(K) + 1 + 64 * (int64_t)K + 256;
+  if (nd > LDS_DOUBLES_MAX) return fail(PB_ERR_INVALID, "pb_theta_fit_step: K=%d exceeds LDS", K);
+  if (!msg_dev || !t_dev || !theta_dev || !cost_dev || !taps_dev || !step_dev || !jcost_dev)
+    return fail(PB_ERR_INVALID, "pb_theta_fit_step: NULL pointer");
+  pb::HrfModel hm{a_peak, loc_peak, lgamma(a_peak), a_under, loc_under, lgamma(a_under), ratio,
+                  pb::hrf_int_power(a_peak), pb::hrf_int_power(a_under), std::exp(-lgamma(a_peak)),
+                  std::exp(-lgamma(a_under))};
+  hipLaunchKernelGGL(pb::theta_fit_kernel, dim3(1), dim3(256), (size_t)nd * sizeof(double),
+                     (hipStream_t)stream, msg_dev, (int64_t)pb::ne_len(K) + 1, 1, K, t_dev, hm, lo, hi,
+                     n_refine, theta_dev, cost_dev, taps_dev, (int64_t)K, N, step_dev, lbda, jcost_dev);
+  return check_launch("pb_theta_fit_step");
+}
+
+int pb_hrf_normal_eq_w(const double* w_dev, int64_t ldw, const float* y_dev, int64_t ldy, int V,
+                       int N, int K, double* work_dev, int64_t work_len, double* out_dev,
+                       void* stream) {
+  if (V < 0 || N < 1 || K < 1 || K > 127 || ldw < N || ldy < N)
+    return fail(PB_ERR_INVALID, "pb_hrf_normal_eq_w: bad size (V=%d N=%d K=%d)", V, N, K);
+  const int ne = pb::ne_len(K) + 1;
+  const int64_t nd = (int64_t)pb::ne_sum_lds_doubles(N, K);
+  if (nd > LDS_DOUBLES_MAX) return fail(PB_ERR_INVALID, "pb_hrf_normal_eq_w: N=%d K=%d exceeds LDS", N, K);
+  if (!out_dev) return fail(PB_ERR_INVALID, "pb_hrf_normal_eq_w: NULL output");
+  int blocks = V < NE_MAX_BLOCKS ? V : NE_MAX_BLOCKS;
+  if (work_len / ne < blocks) blocks = (int)(work_len / ne);
+  if (V > 0) {
+    if (blocks < 1 || !work_dev)
+      return fail(PB_ERR_INVALID, "pb_hrf_normal_eq_w: work buffer must hold at least %d doubles", ne);
+    if (!w_dev || !y_dev) return fail(PB_ERR_INVALID, "pb_hrf_normal_eq_w: NULL pointer");
+    hipLaunchKernelGGL((pb::normal_eq_sum_kernel<float, true>), dim3(blocks), dim3(pb::NE_THREADS),
+                       (size_t)nd * sizeof(double), (hipStream_t)stream, w_dev, ldw, y_dev, ldy, V, N, K,
+                       work_dev);
+  } else {
+    blocks = 0;
+  }
+  hipLaunchKernelGGL(pb::normal_eq_reduce_kernel, dim3(ne), dim3(pb::NE_THREADS), 0,
+                     (hipStream_t)stream, work_dev, blocks, ne, out_dev);
+  return check_launch("pb_hrf_normal_eq_w");
 }
 
 

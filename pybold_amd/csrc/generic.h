@@ -206,14 +206,13 @@ __global__ __launch_bounds__(GEN_THREADS) void gram_frobenius_kernel(const doubl
 // first K-2 partial sums of the K-1 diagonals with d <= K-2 are accumulated term by term
 // (for d >= K-1 they are S * prefix(c), shared by all those diagonals).  One wave per HRF.
 // LDS: c[K] C[K] E[K].
-__global__ __launch_bounds__(64) void gram_frobenius_fir_kernel(const double* taps, int64_t ldt, int K,
-                                                               int N, double* out) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  double* c = reinterpret_cast<double*>(smem);   // c[t], t < K (c[K-1] = S)
+// (one wave; h may live in LDS or global memory; lds3k = 3 K doubles of scratch; the result is
+// valid in lane 0 -- all 64 lanes must call)
+__device__ __forceinline__ double gram_frobenius_fir_wave(const double* h, int K, int N, double* lds3k,
+                                                          int lane) {
+  double* c = lds3k;                             // c[t], t < K (c[K-1] = S)
   double* C = c + K;                             // C[T] = sum_{t<=T} c[t]
   double* E = C + K;                             // E[T] = sum_{T'<=T} (S C[T'])^2
-  const double* h = taps + (int64_t)blockIdx.x * ldt;
-  const int lane = threadIdx.x;
   if (lane == 0) {
     double run = 0.0;
     for (int t = 0; t < K; ++t) { run += h[t]; c[t] = run; }
@@ -226,7 +225,9 @@ __global__ __launch_bounds__(64) void gram_frobenius_fir_kernel(const double* ta
       E[t] = es;
     }
   }
-  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   const double S = c[K - 1], S2 = S * S;
   double part = 0.0;
   for (int d = lane; d < N; d += 64) {
@@ -255,7 +256,15 @@ __global__ __launch_bounds__(64) void gram_frobenius_fir_kernel(const double* ta
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o, 64);
-  if (lane == 0) out[blockIdx.x] = sqrt(part);
+  return sqrt(part);
+}
+
+__global__ __launch_bounds__(64) void gram_frobenius_fir_kernel(const double* taps, int64_t ldt, int K,
+                                                               int N, double* out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const double r = gram_frobenius_fir_wave(taps + (int64_t)blockIdx.x * ldt, K, N,
+                                           reinterpret_cast<double*>(smem), threadIdx.x);
+  if (threadIdx.x == 0) out[blockIdx.x] = r;
 }
 
 // cost[c][v] = 0.5 || y_v - taps * z_v ||^2 ; grid = (V, n_hrf).  taps index:

@@ -111,7 +111,12 @@ def shared_theta_fit(local_cost, theta0, bounds, comm, maxiter=999, pgtol=1.0e-1
 class HipOps:
     """The compute steps of :func:`bd_shared`, each one (or two) launches of the HIP
     library on the current stream; nothing returns to the host.  (The gloo test of the
-    multi-rank logic substitutes the CPU oracle for this class.)"""
+    multi-rank logic substitutes the CPU oracle for this class.)
+
+    ``fused`` (the default): an outer iteration is z-step + ``normal_eq_msg`` (cumulative sum and
+    ``||w||_1`` folded into the pass over the data) + all-reduce + ``theta_step`` (the step constant
+    of the next z-step and the normalised cost folded into the fit) -- no other launch."""
+    fused = True
 
     def __init__(self, t_r, hrf_dur, n):
         from . import solver
@@ -121,20 +126,29 @@ class HipOps:
     def hrf(self, theta):                       # (1,) -> (K,)
         return self.s.spm_hrf_batch(theta, self.t_r, self.hrf_dur)[0]
 
-    def z_step(self, Y, taps, lbda, nb_inner, W):
-        step = 1.0 / self.s.gram_frobenius_batch(taps.reshape(1, -1), self.n)    # (1,)
+    def z_step(self, Y, taps, lbda, nb_inner, W, step=None):
+        if step is None:
+            step = 1.0 / self.s.gram_frobenius_batch(taps.reshape(1, -1), self.n)    # (1,)
         W, _ = self.s.fista_solve_pp(Y, taps, step, lbda, nb_inner, W0=W, inplace=True)
         return W
 
     def normal_eq(self, W, Y, K):
         Z = self.s.integ_op(W)
         if self.work is None:
-            self.work = torch.empty((2048 * (K * K + K + 1),), dtype=torch.float64, device=Y.device)
+            self.work = torch.empty((2048 * (K * K + K + 2),), dtype=torch.float64, device=Y.device)
         return self.s.hrf_normal_eq(Z, Y, K, work=self.work)
+
+    def normal_eq_msg(self, W, Y, K, out):      # -> out (K*K + K + 2,): normal equations, ||w||_1
+        if self.work is None:
+            self.work = torch.empty((2048 * (K * K + K + 2),), dtype=torch.float64, device=Y.device)
+        return self.s.hrf_normal_eq_w(W, Y, K, work=self.work, out=out)
 
     def theta_fit(self, ne, bounds):            # -> theta (1,), F(theta) (1,), taps (K,)
         theta, f, taps = self.s.theta_fit(ne, self.t_r, self.hrf_dur, bounds)
         return theta, f, taps[0]
+
+    def theta_step(self, msg, bounds, lbda):    # -> theta, F, taps, step of the next z-step, normalised cost
+        return self.s.theta_fit_step(msg, self.t_r, self.hrf_dur, bounds, self.n, lbda)
 
 
 def bd_shared(Y, t_r, lbda=1.0, theta_0=None, hrf_dur=20.0, bounds=None, nb_iter=20,
@@ -173,19 +187,29 @@ def bd_shared(Y, t_r, lbda=1.0, theta_0=None, hrf_dur=20.0, bounds=None, nb_iter
     W = torch.zeros((V, n), dtype=torch.float64, device=dev)
     msg = torch.empty((ne_len + 1,), dtype=torch.float64, device=dev)
     thetas, costs = [theta], []
+    fused = bool(getattr(ops, "fused", False))
+    step = None                                  # fused: 1 / ||A^T A||_F comes out of the theta step
     for it in range(nb_iter + 1):
-        W = ops.z_step(Y, taps, lbda, nb_inner, W)
-        msg[:ne_len] = ops.normal_eq(W, Y, K)
-        msg[ne_len] = W.abs().sum()
+        W = ops.z_step(Y, taps, lbda, nb_inner, W, step) if fused else ops.z_step(Y, taps, lbda, nb_inner, W)
+        if fused:
+            ops.normal_eq_msg(W, Y, K, msg)      # cumulative sum and ||w||_1 inside the one pass
+        else:
+            msg[:ne_len] = ops.normal_eq(W, Y, K)
+            msg[ne_len] = W.abs().sum()
         comm.allreduce_(msg)                     # the ONE collective of the outer iteration
         ne = msg[:ne_len]
-        if it < nb_iter:
+        if it < nb_iter and fused:
+            theta, f, taps, step, jc = ops.theta_step(msg, bounds[0], lbda)
+            thetas.append(theta)
+            costs.append(jc)
+        elif it < nb_iter:
             theta, f, taps = ops.theta_fit(ne, bounds[0])
             thetas.append(theta)
+            costs.append((2.0 * f + lbda * msg[ne_len]) / ne[ne_len - 1])
         else:                                    # last z-step: price the current HRF
             G, b = ne[:K * K].reshape(K, K), ne[K * K:K * K + K]
             f = (0.5 * ne[ne_len - 1] - taps.dot(b) + 0.5 * taps.dot(G.mv(taps))).reshape(1)
-        costs.append((2.0 * f + lbda * msg[ne_len]) / ne[ne_len - 1])
+            costs.append((2.0 * f + lbda * msg[ne_len]) / ne[ne_len - 1])
         if verbose > 0 and comm.rank == 0:
             print("bd_shared outer %d: theta=%.6f J=%.6f" % (it, float(theta), float(costs[-1])))
     d = {"theta": torch.cat(thetas).cpu().numpy(),

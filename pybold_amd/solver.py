@@ -762,3 +762,50 @@ def theta_fit(ne, t_r, dur, bounds, n_refine=3, dt=0.001, p_delay=6, undershoot=
                               _ld(taps), _stream_ptr(dev))
     _lib.check(rc, "pb_theta_fit")
     return theta, cost, taps
+
+
+# ---- the shared-HRF outer iteration in three launches (z-step, normal equations, theta fit) -------
+def hrf_normal_eq_w(W, Y, n_taps, work=None, out=None):
+    """:func:`hrf_normal_eq` (summed over voxels) straight from the innovation ``W = diff_z``: the
+    cumulative sum (pybold/bold_signal.py:326) and ``sum_v ||w_v||_1`` are taken in the same pass.
+    Returns float64 ``(K*K + K + 2,)``: the normal equations followed by the L1 sum -- the message of
+    the outer iteration's one all-reduce (``pb_hrf_normal_eq_w``)."""
+    lib = _lib.load()
+    W = _rows(W, torch.float64, "W")
+    Y = _rows(Y, torch.float32, "Y")
+    dev = W.device
+    V, N = W.shape
+    K = int(n_taps)
+    ne = int(lib.pb_hrf_normal_eq_len(K)) + 1
+    if out is None:
+        out = torch.empty((ne,), dtype=torch.float64, device=dev)
+    if work is None or work.numel() < ne:
+        work = torch.empty((2048 * ne,), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.pb_hrf_normal_eq_w(W.data_ptr(), _ld(W) if V else N, Y.data_ptr(), _ld(Y) if V else N, V, N, K,
+                                    work.data_ptr(), work.numel(), out.data_ptr(), _stream_ptr(dev))
+    _lib.check(rc, "pb_hrf_normal_eq_w")
+    return out
+
+
+def theta_fit_step(msg, t_r, dur, bounds, n_scans, lbda, n_refine=3, dt=0.001, p_delay=6, undershoot=16.0,
+                   p_disp=1.0, u_disp=1.0, p_u_ratio=0.167):
+    """:func:`theta_fit` on ONE message of :func:`hrf_normal_eq_w` that also leaves on the device what the
+    next z-step and the cost trace need: returns ``(theta (1,), cost (1,), taps (K,), step (1,),
+    jcost (1,))`` with ``step = 1 / ||A^T A||_F`` for the new HRF on ``n_scans`` scans and ``jcost =
+    (2 F(theta*) + lbda ||w||_1) / ||y||^2`` (pybold/bold_signal.py:249-254, :337-342)."""
+    lib = _lib.load()
+    dev = msg.device
+    t_dev = _sample_times_on(dev, t_r, dur, dt)
+    K = t_dev.numel()
+    if msg.dtype != torch.float64 or msg.numel() != int(lib.pb_hrf_normal_eq_len(K)) + 1 or not msg.is_contiguous():
+        raise ValueError("msg must be the contiguous float64 output of hrf_normal_eq_w for %d taps" % K)
+    out = torch.empty((4 + K,), dtype=torch.float64, device=dev)
+    theta, cost, step, jc, taps = out[0:1], out[1:2], out[2:3], out[3:4], out[4:]
+    with torch.cuda.device(dev):
+        rc = lib.pb_theta_fit_step(msg.data_ptr(), K, t_dev.data_ptr(), p_delay / p_disp, dt / p_disp,
+                                   undershoot / u_disp, dt / u_disp, p_u_ratio, float(bounds[0]), float(bounds[1]),
+                                   int(n_refine), int(n_scans), float(lbda), theta.data_ptr(), cost.data_ptr(),
+                                   taps.data_ptr(), step.data_ptr(), jc.data_ptr(), _stream_ptr(dev))
+    _lib.check(rc, "pb_theta_fit_step")
+    return theta, cost, taps, step, jc

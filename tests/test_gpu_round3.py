@@ -255,7 +255,7 @@ def test_window_rule_float32_ring_agrees_with_float64_kernel(solver, golden):
     hrf, lip = g["hrf"], float(g["lipschitz"])
     Y, _ = synthetic(64, seed=99)
     total, differ = 0, 0
-    for tol in (1e-2, 2e-3, 5e-4):
+    for tol in (1e-2, 3e-3, 1e-3):
         for lbda in (0.3, 1.0, 3.0):
             _, _, n64 = solver.fista_solve(Y.double(), hrf, lbda, 1.0 / lip, 2000, stop="window", tol=tol, wind=6)
             for force in ("fast1", "wide"):
@@ -266,3 +266,49 @@ def test_window_rule_float32_ring_agrees_with_float64_kernel(solver, golden):
                 differ += int((d > 0).sum())
             assert int(n64.min()) < 2000
     assert differ <= 0.01 * total, (differ, total)
+
+
+# ---- config 4: an outer iteration of the shared-HRF loop in three launches --------------------------
+def test_fused_outer_iteration_pieces(solver):
+    """pb_hrf_normal_eq_w == pb_hrf_normal_eq(pb_integ_op(w)) bit for bit, plus sum ||w||_1;
+    pb_theta_fit_step == pb_theta_fit, plus 1 / pb_gram_frobenius of the new HRF and the
+    normalised cost; an empty shard gives zeros."""
+    t_r, dur, n = 0.75, 20.0, 300
+    rng = np.random.RandomState(0)
+    for V in (1, 7, 3000):
+        W = dev64(rng.randn(V, n) * (rng.rand(V, n) < 0.1))
+        Y = dev32(rng.randn(V, n))
+        K = 27
+        ne = solver.hrf_normal_eq(solver.integ_op(W), Y, K)
+        msg = solver.hrf_normal_eq_w(W, Y, K)
+        assert msg.shape == (K * K + K + 2,)
+        assert torch.equal(msg[:-1], ne)
+        np.testing.assert_allclose(float(msg[-1]), float(W.abs().sum()), rtol=1e-13)
+        theta, f, taps = solver.theta_fit(ne, t_r, dur, (0.6, 1.9))
+        th2, f2, taps2, step, jc = solver.theta_fit_step(msg, t_r, dur, (0.6, 1.9), n, 1.7)
+        assert torch.equal(theta, th2) and torch.equal(f, f2) and torch.equal(taps[0], taps2)
+        fro = solver.gram_frobenius_batch(taps, n)
+        assert torch.equal(step, 1.0 / fro)
+        np.testing.assert_allclose(float(jc), float((2.0 * f + 1.7 * msg[-1]) / msg[-2]), rtol=1e-14)
+    empty = solver.hrf_normal_eq_w(dev64(np.zeros((0, n))), dev32(np.zeros((0, n))), 27)
+    assert float(empty.abs().sum()) == 0.0
+
+
+def test_bd_shared_fused_equals_unfused():
+    """The three-launch outer iteration changes no number: theta after every outer iteration, the
+    cost trace and the iterates equal those of the round-2 sequence of launches."""
+    from pybold_amd import data, distributed
+    from pybold_amd.hrf_model import spm_hrf
+    t_r, dur = 0.75, 20.0
+    h_true = spm_hrf(0.7, t_r, dur, False)[0]
+    Y, _, _ = data.gen_rnd_bloc_bold_batch(3000, dur=3.75, tr=t_r, hrf=h_true, nb_events=5, avg_dur=12.0,
+                                           std_dur=1.0, snr=10.0, seed=3)
+    W1, h1, d1 = distributed.bd_shared(Y, t_r, lbda=1.7, theta_0=2.0, hrf_dur=dur, nb_iter=6, nb_inner=50)
+
+    class Unfused(distributed.HipOps):
+        fused = False
+    W0, h0, d0 = distributed.bd_shared(Y, t_r, lbda=1.7, theta_0=2.0, hrf_dur=dur, nb_iter=6, nb_inner=50,
+                                       ops=Unfused(t_r, dur, Y.shape[1]))
+    assert np.array_equal(d1["theta"], d0["theta"])
+    np.testing.assert_allclose(d1["J"], d0["J"], rtol=1e-13)
+    assert torch.equal(W1, W0) and np.array_equal(h1, h0)
