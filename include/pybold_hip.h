@@ -57,6 +57,7 @@ extern "C" {
 #define PB_FLAG_NO_CERT 512u       /* PB_STOP_WINDOW: always evaluate the rule in full (fista_fast_kernel), never
                                      the no-fire certificate of the pair form + re-solve (see pb_fista_solve) */
 #define PB_FLAG_CERT_NO_RESOLVE 2048u /* diagnostic: certificate launch only; uncleared problems keep n_done = -1 */
+#define PB_FLAG_MFMA 8192u         /* experimental: plain solves of 289..320 scans on the matrix-pipe kernel (fista_mfma.h) */
 #define PB_FLAG_FORCE_CERT 1024u   /* PB_STOP_WINDOW, wind = 6: certificate path whatever tol * n_iter is */
 #define PB_FLAG_ONE_LAUNCH 32u    /* never split a plain solve into a full-rounds launch and a
                                      remainder launch (see pb_fista_solve) */

@@ -23,6 +23,7 @@ PB_FLAG_COLD_START = 256
 PB_FLAG_NO_CERT = 512
 PB_FLAG_FORCE_CERT = 1024
 PB_FLAG_CERT_NO_RESOLVE = 2048
+PB_FLAG_MFMA = 8192
 PB_STOP_NONE = 0
 PB_STOP_LOOPS = 1
 PB_STOP_WINDOW = 2

@@ -16,6 +16,7 @@
 #include "fista_pair_ffa.h"
 #include "fista_exact.h"
 #include "blind.h"
+#include "fista_mfma.h"
 
 namespace {
 
@@ -73,6 +74,9 @@ namespace pb {
 #undef PB_FAST
 }  // namespace pb
 
+namespace pb {
+extern template int launch_mfma<10>(const FistaArgs&, const double*, int, hipStream_t);
+}
 namespace pb {
 #define PB_WIDE(S, KT)                                                                            \
   extern template int launch_wide<S, KT>(const FistaArgs&, const double*, int, bool, int, hipStream_t); \
@@ -617,6 +621,12 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
   a.cold = (flags & PB_FLAG_COLD_START) ? 1 : 0;
   a.wind = wind;
 
+  // experimental: both operators on the matrix pipe (fista_mfma.h); plain solves of 289..320 scans
+  if ((flags & PB_FLAG_MFMA) && stop_mode == PB_STOP_NONE && !J_dev && N > 288 && N <= 320 && K <= 33) {
+    if (pb::launch_mfma<10>(a, taps_host, K, (hipStream_t)stream) != 0)
+      return fail(PB_ERR_INVALID, "pb_fista_solve: matrix-pipe kernel rejected the launch");
+    return check_launch("fista_mfma_kernel");
+  }
   // series of 16 S < N <= 32 S scans (the reference's 600-scan demo): the pair form with the two
   // halves of ONE series in the slots of a row, in one launch; the window rule as a certificate,
   // re-solved on the one-problem-per-wave form

@@ -30,7 +30,7 @@ _FORCE = {None: 0, "generic": PB_FLAG_FORCE_GENERIC, "fast": PB_FLAG_FORCE_FAST,
           # tol * n_iter is; "nocert" = always the full rule (single-row form)
           "cert": PB_FLAG_FORCE_CERT, "cert2": PB_FLAG_FORCE_CERT | PB_FLAG_FORCE_PAIR | PB_FLAG_ONE_LAUNCH,
           "certonly": PB_FLAG_FORCE_CERT | PB_FLAG_FORCE_PAIR | PB_FLAG_ONE_LAUNCH | _lib.PB_FLAG_CERT_NO_RESOLVE,
-          "nocert": PB_FLAG_NO_CERT}
+          "nocert": PB_FLAG_NO_CERT, "mfma": _lib.PB_FLAG_MFMA}
 
 
 _warned = set()
