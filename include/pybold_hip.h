@@ -57,7 +57,8 @@ extern "C" {
 #define PB_FLAG_NO_CERT 512u       /* PB_STOP_WINDOW: always evaluate the rule in full (fista_fast_kernel), never
                                      the no-fire certificate of the pair form + re-solve (see pb_fista_solve) */
 #define PB_FLAG_CERT_NO_RESOLVE 2048u /* diagnostic: certificate launch only; uncleared problems keep n_done = -1 */
-#define PB_FLAG_MFMA 8192u         /* experimental: plain solves of 289..320 scans on the matrix-pipe kernel (fista_mfma.h) */
+#define PB_FLAG_FORCE_MFMA 16384u  /* the matrix-pipe form also with per-problem lambdas (see pb_fista_solve) */
+#define PB_FLAG_NO_MFMA 8192u      /* plain solves: never the matrix-pipe form (fista_mfma_kernel), vector forms only */
 #define PB_FLAG_FORCE_CERT 1024u   /* PB_STOP_WINDOW, wind = 6: certificate path whatever tol * n_iter is */
 #define PB_FLAG_ONE_LAUNCH 32u    /* never split a plain solve into a full-rounds launch and a
                                      remainder launch (see pb_fista_solve) */
@@ -87,7 +88,8 @@ int pb_fista_has_fast_path(int N, int K);
 /* Which kernel pb_fista_solve will run for this call shape (no flags): 0 = generic
  * LDS kernel, 1 = register-resident, one problem per 16-lane row (fista_fast_kernel),
  * 2 = register-resident, two problems per row (fista_pair_kernel), 3 = register-resident,
- * one problem per wave (long series).  Host-only query. */
+ * one problem per wave (long series), 4 = register-resident, 16 problems per wave, both operators
+ * on the matrix pipe (fista_mfma_kernel; assumes n_done_dev is given).  Host-only query. */
 int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mode, int wind);
 
 /* How pb_fista_solve (no flags) lays P problems out: problems [0, *n_main) in one launch of
@@ -96,6 +98,9 @@ int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mod
  * Host-only query; any output pointer may be NULL. */
 int pb_fista_plan(int N, int K, int P, int stop_mode, int wind, int* n_main, int* main_form,
                   int* tail_form);
+/* The same for a call that passes `flags` (PB_FLAG_NO_MFMA: the plan of the vector forms). */
+int pb_fista_plan_ex(int N, int K, int P, int stop_mode, int wind, unsigned flags, int* n_main,
+                     int* main_form, int* tail_form);
 
 /*
  * Fused FISTA-like solver: n_iter iterations of the recurrence of

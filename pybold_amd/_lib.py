@@ -23,7 +23,8 @@ PB_FLAG_COLD_START = 256
 PB_FLAG_NO_CERT = 512
 PB_FLAG_FORCE_CERT = 1024
 PB_FLAG_CERT_NO_RESOLVE = 2048
-PB_FLAG_MFMA = 8192
+PB_FLAG_NO_MFMA = 8192
+PB_FLAG_FORCE_MFMA = 16384
 PB_STOP_NONE = 0
 PB_STOP_LOOPS = 1
 PB_STOP_WINDOW = 2
@@ -41,6 +42,7 @@ SIGNATURES = {
     "pb_fista_has_fast_path": (_c_int, [_c_int, _c_int]),
     "pb_fista_which_kernel": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int]),
     "pb_fista_plan": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr, _ptr]),
+    "pb_fista_plan_ex": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, ctypes.c_uint, _ptr, _ptr, _ptr]),
     "pb_fista_solve": (_c_int, [
         _ptr, _c_i64, _c_int,            # y_dev, ldy, y_rep
         _ptr, _c_i64, _c_int, _c_int,    # w_dev, ldw, P, N

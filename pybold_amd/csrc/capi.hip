@@ -3,6 +3,7 @@
 #include "../../include/pybold_hip.h"
 
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cmath>
 #include <cstring>
@@ -75,8 +76,20 @@ namespace pb {
 }  // namespace pb
 
 namespace pb {
-extern template int launch_mfma<10>(const FistaArgs&, const double*, int, hipStream_t);
+#define PB_MFMA(NB) extern template int launch_mfma<NB>(const FistaArgs&, const double*, int, bool, hipStream_t);
+PB_MFMA(5) PB_MFMA(6) PB_MFMA(7) PB_MFMA(8) PB_MFMA(9) PB_MFMA(10)
+#undef PB_MFMA
 }
+namespace {
+typedef int (*mfma_launch_fn)(const pb::FistaArgs&, const double*, int, bool, hipStream_t);
+// the matrix-pipe form (fista_mfma.h): NB = ceil(N / 32) blocks of 32 samples, 129 <= N <= 320, K <= 33
+mfma_launch_fn pick_mfma(int N, int K) {
+  static const mfma_launch_fn tab[] = {&pb::launch_mfma<5>, &pb::launch_mfma<6>, &pb::launch_mfma<7>,
+                                       &pb::launch_mfma<8>, &pb::launch_mfma<9>, &pb::launch_mfma<10>};
+  const int nb = (N + 31) / 32;
+  return (K >= 1 && K <= 33 && nb >= 5 && nb <= 10) ? tab[nb - 5] : nullptr;
+}
+}  // namespace
 namespace pb {
 #define PB_WIDE(S, KT)                                                                            \
   extern template int launch_wide<S, KT>(const FistaArgs&, const double*, int, bool, int, hipStream_t); \
@@ -213,7 +226,7 @@ constexpr int SPLIT_MIN_P = 1024;
 // exceeds half a round of pair waves, as a concurrent group (plan_pieces below).
 constexpr double COST_FAST1 = 0.63, COST_WIDE = 0.19, COST_PARTIAL = 0.56;
 constexpr double COST_LAUNCH = 0.03, COST_LAUNCH_WIDE = 0.05;
-enum Form { FORM_GENERIC = 0, FORM_FAST1 = 1, FORM_PAIR = 2, FORM_WIDE = 3 };
+enum Form { FORM_GENERIC = 0, FORM_FAST1 = 1, FORM_PAIR = 2, FORM_WIDE = 3, FORM_MFMA = 4 };
 
 double wave_slots() {
   static const double slots = [] {
@@ -388,6 +401,28 @@ int plan_pieces(int P, bool has_pair, bool has_wide, bool one_launch, bool one_s
   return n;
 }
 
+// Plan with the matrix-pipe form as the main form (plain solves, cost trace or not): one wave per
+// SIMD carries 16 problems, so a round is the same 16 384 problems as a round of pair waves but takes
+// ~0.68 of its time (measured, tools/r3_mfma_probe.py), and -- the waves being alone on their SIMDs --
+// ANY remainder launched on it costs a full round.  Whole rounds therefore go to the matrix pipe,
+// a remainder above half a round too; a smaller one keeps the plan of the vector forms
+// (plan_pieces: pair waves alone on their SIMDs, single-row and one-problem waves beside them).
+int plan_pieces_mfma(int P, bool has_pair, bool has_wide, bool one_launch, bool one_stream, Piece* out) {
+  const int round = (int)wave_slots() * 8;           // 16 problems x (slots / 2) waves
+  const int whole = (P / round) * round;
+  const int R = P - whole;
+  int n = 0;
+  if (one_launch || R == 0 || R > round / 2) {
+    out[n++] = Piece{FORM_MFMA, 0, P, false, false};
+    return n;
+  }
+  if (whole > 0) out[n++] = Piece{FORM_MFMA, 0, whole, false, false};
+  Piece sub[4];
+  const int m = plan_pieces(R, has_pair, has_wide, false, one_stream, sub);
+  for (int i = 0; i < m; ++i) out[n++] = Piece{sub[i].form, sub[i].p0 + whole, sub[i].p1 + whole, sub[i].side, sub[i].group};
+  return n;
+}
+
 template <int KIND>
 int launch_op(const double* x, int64_t ldx, double* out, int64_t ldo, int V, int n_src, int n_dst,
               const double* taps, int K, void* stream, const char* name) {
@@ -543,6 +578,11 @@ int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mod
     if (P >= SPLIT_MIN_P && pair_carries(se, stop_mode, wind) && (stop_mode == PB_STOP_NONE || pick_wide(N, K)))
       return FORM_PAIR;
   const FastEntry* fe = pick_fast(N, K);
+  if (fe && stop_mode == PB_STOP_NONE && pick_mfma(N, K)) {
+    Piece pc[6];
+    plan_pieces_mfma(P, fe->fn_pair != nullptr, pick_wide_small(N, K) != nullptr, false, false, pc);
+    return pc[0].form;
+  }
   if (fe && stop_mode == PB_STOP_WINDOW && (!ring_wind(wind) || fe->S > 20)) fe = nullptr;
   if (!fe) {
     const WideEntry* we = pick_wide(N, K);
@@ -556,10 +596,30 @@ int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mod
 
 int pb_fista_plan(int N, int K, int P, int stop_mode, int wind, int* n_main, int* main_form,
                   int* tail_form) {
+  return pb_fista_plan_ex(N, K, P, stop_mode, wind, 0u, n_main, main_form, tail_form);
+}
+
+int pb_fista_plan_ex(int N, int K, int P, int stop_mode, int wind, unsigned flags, int* n_main,
+                     int* main_form, int* tail_form) {
   int nm = 0, mf = 0, tf = 0;
+  const bool no_mfma = (flags & (PB_FLAG_NO_MFMA | PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_DIRECT_FIR)) != 0;
   const FastEntry* se = (N >= 1 && K >= 1 && P >= SPLIT_MIN_P) ? pick_split(N, K) : nullptr;
   if (se && pair_carries(se, stop_mode, wind) && (stop_mode == PB_STOP_NONE || pick_wide(N, K))) {
     tf = FORM_PAIR;                                     // one launch of the split pair form
+  } else if (N >= 1 && K >= 1 && P >= 1 && stop_mode == PB_STOP_NONE && !no_mfma && pick_fast(N, K) && pick_mfma(N, K)) {
+    Piece pc[6];
+    const int npc = plan_pieces_mfma(P, pick_fast(N, K)->fn_pair != nullptr, pick_wide_small(N, K) != nullptr,
+                                     false, false, pc);
+    int i = 1;
+    while (i < npc && pc[i].form == pc[0].form) ++i;
+    if (i < npc) {
+      nm = pc[i - 1].p1;
+      mf = pc[0].form;
+      int big = i;
+      for (int k = i + 1; k < npc; ++k)
+        if (pc[k].p1 - pc[k].p0 > pc[big].p1 - pc[big].p0) big = k;
+      tf = pc[big].form;
+    } else { nm = 0; mf = 0; tf = pc[0].form; }
   } else if (N >= 1 && K >= 1 && P >= 1) {
     const FastEntry* fe = pick_fast(N, K);
     if (fe && stop_mode == PB_STOP_WINDOW && (!ring_wind(wind) || fe->S > 20)) fe = nullptr;
@@ -620,13 +680,8 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
   a.taps_pp = nullptr; a.ldt = 0; a.step_vec = nullptr; a.step_shared = 0; a.K = K; a.p0 = 0;
   a.cold = (flags & PB_FLAG_COLD_START) ? 1 : 0;
   a.wind = wind;
+  if (const char* yb = getenv("PB_MFMA_YBITS")) a.ybits = atoi(yb);     // development aid
 
-  // experimental: both operators on the matrix pipe (fista_mfma.h); plain solves of 289..320 scans
-  if ((flags & PB_FLAG_MFMA) && stop_mode == PB_STOP_NONE && !J_dev && N > 288 && N <= 320 && K <= 33) {
-    if (pb::launch_mfma<10>(a, taps_host, K, (hipStream_t)stream) != 0)
-      return fail(PB_ERR_INVALID, "pb_fista_solve: matrix-pipe kernel rejected the launch");
-    return check_launch("fista_mfma_kernel");
-  }
   // series of 16 S < N <= 32 S scans (the reference's 600-scan demo): the pair form with the two
   // halves of ONE series in the slots of a row, in one launch; the window rule as a certificate,
   // re-solved on the one-problem-per-wave form
@@ -661,11 +716,25 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
   const bool cert = fe && stop_mode == PB_STOP_WINDOW && wind == 6 && fe->fn_pair_cert && n_done_dev &&
                     P >= 2 && !(flags & (PB_FLAG_NO_PAIR | PB_FLAG_NO_CERT | PB_FLAG_DIRECT_FIR)) &&
                     ((flags & PB_FLAG_FORCE_CERT) || tol * (double)n_iter < 0.5);
+  // plain solves (cost trace or not) of 129..320 scans, HRFs up to 33 taps: both operators on the
+  // matrix pipe (fista_mfma.h).  Needs n_done_dev: a problem whose scaled operands left the float16
+  // range comes back with n_done = -1 and is re-solved on the single-row form.
+  // Not with one lambda per problem, unless asked for (PB_FLAG_FORCE_MFMA): along a regularisation
+  // path a third of the problems (lambda near lambda_max) fail that kernel's accuracy guard and
+  // would be solved twice.
+  const mfma_launch_fn mfma = (fe && stop_mode == PB_STOP_NONE && n_done_dev && (!lbda_dev || (flags & PB_FLAG_FORCE_MFMA)) &&
+                               !(flags & (PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_DIRECT_FIR | PB_FLAG_NO_MFMA)))
+                                  ? pick_mfma(N, K) : nullptr;
   if (fe) {
     auto run = [&](int form, int p0, int p1) -> int {
       pb::FistaArgs b = a;
       b.p0 = p0;
       b.P = p1;
+      if (form == FORM_MFMA) {
+        if (!mfma || mfma(b, taps_host, K, J_dev != nullptr, (hipStream_t)stream) != 0)
+          return fail(PB_ERR_INVALID, "pb_fista_solve: matrix-pipe kernel rejected the launch");
+        return check_launch("fista_mfma_kernel");
+      }
       if (form == FORM_PAIR && cert) {
         if (fe->fn_pair_cert(b, taps_host, K, (hipStream_t)stream) != 0)
           return fail(PB_ERR_INVALID, "pb_fista_solve: certificate kernel rejected the launch");
@@ -695,7 +764,7 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
       b.p0 = q0;
       b.P = q1;
       b.only_flagged = 1;
-      if (fe->fn(b, taps_host, K, J_dev != nullptr, PB_STOP_WINDOW, (hipStream_t)stream) != 0)
+      if (fe->fn(b, taps_host, K, J_dev != nullptr, stop_mode, (hipStream_t)stream) != 0)
         return fail(PB_ERR_INVALID, "pb_fista_solve: no single-row form for the re-solve");
       return check_launch("fista_fast_kernel(re-solve)");
     };
@@ -712,20 +781,22 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
     // stop rules; the one-problem-per-wave form has them all); a remainder that fits beside
     // half a round of pair waves runs on the side stream
     const bool pair_ok = (fe->fn_pair != nullptr && stop_mode == PB_STOP_NONE) || cert;
-    Piece pc[4];
+    Piece pc[6];
     const bool one_stream = (flags & PB_FLAG_ONE_STREAM) != 0 || stream_is_capturing((hipStream_t)stream);
-    const int npc = plan_pieces(P, pair_ok, pick_wide_small(N, K) != nullptr,
-                                (flags & PB_FLAG_ONE_LAUNCH) != 0, one_stream, pc);
+    const int npc = mfma ? plan_pieces_mfma(P, pair_ok, pick_wide_small(N, K) != nullptr,
+                                            (flags & PB_FLAG_ONE_LAUNCH) != 0, one_stream, pc)
+                         : plan_pieces(P, pair_ok, pick_wide_small(N, K) != nullptr,
+                                       (flags & PB_FLAG_ONE_LAUNCH) != 0, one_stream, pc);
     bool any_side = false;
-    int q0 = P, q1 = 0;                          // range covered by the pair pieces (contiguous)
+    int q0 = P, q1 = 0;                          // range of the pieces that may leave n_done = -1 (contiguous)
     for (int i = 0; i < npc; ++i) {
       any_side |= pc[i].side;
-      if (pc[i].form == FORM_PAIR) {
+      if ((pc[i].form == FORM_PAIR && cert) || pc[i].form == FORM_MFMA) {
         q0 = pc[i].p0 < q0 ? pc[i].p0 : q0;
         q1 = pc[i].p1 > q1 ? pc[i].p1 : q1;
       }
     }
-    auto finish = [&](int rc) -> int { return (rc == PB_OK && cert && q1 > q0) ? resolve(q0, q1) : rc; };
+    auto finish = [&](int rc) -> int { return (rc == PB_OK && q1 > q0) ? resolve(q0, q1) : rc; };
     if (!any_side) {
       for (int i = 0; i < npc; ++i) {
         const int rc = run(pc[i].form, pc[i].p0, pc[i].p1);
@@ -1112,9 +1183,6 @@ int pb_fista_solve_pp(const float* y_dev, int64_t ldy, double* w_dev, int64_t ld
       // (the remainder of the whole rounds on the single-row or the one-problem-per-wave kernel,
       // both reading the shared HRF through their per-problem-taps form)
       const WideEntry* ws = pick_wide_small(N, K);
-      Plan pl{0, FORM_GENERIC, FORM_PAIR};
-      if (!(flags & PB_FLAG_FORCE_PAIR))
-        pl = plan_plain(P, true, ws != nullptr, (flags & PB_FLAG_ONE_LAUNCH) != 0);
       auto run = [&](int form, int p0, int p1) -> int {
         pb::FistaArgs b = a;
         b.p0 = p0;
@@ -1125,11 +1193,43 @@ int pb_fista_solve_pp(const float* y_dev, int64_t ldy, double* w_dev, int64_t ld
         if (bad) return fail(PB_ERR_INVALID, "pb_fista_solve_pp: launch rejected");
         return check_launch(form == FORM_PAIR ? "fista_pair_ffa_kernel(shared taps)" : "fista_fast_kernel(pp)");
       };
-      if (pl.n_main > 0) {
-        const int rc = run(pl.main_form, 0, pl.n_main);
+      // whole rounds (and a remainder above half a round) on the matrix-pipe form, which reads the
+      // shared HRF and its step from device memory like the pair form (plan_pieces_mfma)
+      int base = 0;
+      const mfma_launch_fn mfma = (n_done_dev && !(flags & (PB_FLAG_FORCE_PAIR | PB_FLAG_NO_MFMA))) ? pick_mfma(N, K) : nullptr;
+      if (mfma) {
+        const int round = (int)wave_slots() * 8;
+        base = (P / round) * round;
+        if (P - base > round / 2 || (flags & PB_FLAG_ONE_LAUNCH)) base = P;
+        if (base > 0) {
+          pb::FistaArgs b = a;
+          b.P = base;
+          if (mfma(b, nullptr, K, false, (hipStream_t)stream) != 0)
+            return fail(PB_ERR_INVALID, "pb_fista_solve_pp: matrix-pipe kernel rejected the launch");
+          const int rc = check_launch("fista_mfma_kernel(shared taps)");
+          if (rc != PB_OK) return rc;
+        }
+      }
+      if (base < P) {
+        Plan pl{0, FORM_GENERIC, FORM_PAIR};
+        if (!(flags & PB_FLAG_FORCE_PAIR))
+          pl = plan_plain(P - base, P - base >= 2, ws != nullptr, (flags & PB_FLAG_ONE_LAUNCH) != 0);
+        if (pl.n_main > 0) {
+          const int rc = run(pl.main_form, base, base + pl.n_main);
+          if (rc != PB_OK) return rc;
+        }
+        const int rc = run(pl.tail_form, base + pl.n_main, P);
         if (rc != PB_OK) return rc;
       }
-      return run(pl.tail_form, pl.n_main, P);
+      if (base > 0) {                              // problems the matrix-pipe form handed back (n_done = -1)
+        pb::FistaArgs b = a;
+        b.P = base;
+        b.only_flagged = 1;
+        if (fe->fn_pp(b, stop_mode, (hipStream_t)stream) != 0)
+          return fail(PB_ERR_INVALID, "pb_fista_solve_pp: launch rejected");
+        return check_launch("fista_fast_kernel(pp, re-solve)");
+      }
+      return PB_OK;
     }
     // one HRF per problem: single-row form, or one problem per wave where that finishes first
     // (small batches are latency-bound: 0.37 ms against 0.93 ms per 500 iterations up to 2 048)

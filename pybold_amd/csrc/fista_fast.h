@@ -62,6 +62,7 @@ struct FistaArgs {
   int K;                  // number of taps actually used (<= KT)
   int cold;               // 1: the iterate starts from 0, a.w is written only
   int wind = 6;           // window rule: stored iterates (register-resident forms: 4, 6 or 8)
+  int ybits = 14;         // matrix-pipe form: every series is scaled so that max |y| lies in [2^(ybits-1), 2^ybits)
   int only_flagged = 0;   // 1: solve only the problems with n_done[p] < 0 (left by the certificate
                           //    form of the pair kernel, fista_pair_ffa.h), skip the others
 };
@@ -136,13 +137,11 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
   bool live = prob < a.P;
   const int p = live ? prob : a.P - 1;
   const int base = sub * S;
-  if constexpr (STOP == 2) {
-    // re-solve pass behind the certificate kernel: only flagged problems; a wave none of whose
-    // rows is flagged leaves at once (no barrier anywhere in this kernel)
-    if (a.only_flagged) {
-      live = live && a.n_done[p] < 0;
-      if (__builtin_amdgcn_ballot_w64(live) == 0) return;
-    }
+  // re-solve pass behind the certificate / matrix-pipe kernels: only flagged problems; a wave
+  // none of whose rows is flagged leaves at once (no barrier anywhere in this kernel)
+  if (a.only_flagged) {
+    live = live && a.n_done[p] < 0;
+    if (__builtin_amdgcn_ballot_w64(live) == 0) return;
   }
 
   // ---- load the problem: y strip (fp32), w strip (fp64) -------------------

@@ -7,7 +7,11 @@
 // WHOLE linear operator moves to v_mfma_f32_16x16x32_f16, scans included:
 //
 //   x = K_h (cumsum w) = T_c w,    T_c[t][s] = c[t - s],  c = cumsum(h)  (c[m] = S = sum h for m >= K-1)
-//   g = cumsum^T K_h^T r = T_c^T r
+//   g = cumsum^T K_h^T r = T_c^T r,   r = x - y
+//
+// (The reference's other form, g = T_c^T x - T_c^T y with the second term precomputed, was measured
+// and is WORSE here: the 22-bit rounding of x then enters at the scale of y instead of the scale of
+// the residual -- 3e-6 instead of 2.5e-7 on diff_z, tools/r3_mfma_precision.py.)
 //
 // T_c is lower triangular Toeplitz with a CONSTANT far field, so per block of 32 samples
 //   x_q = C0 w_q + C1 w_{q-1} + S 1 1^T (w_0 + ... + w_{q-2})
@@ -19,7 +23,7 @@
 // hi.hi + hi.lo + lo.hi, float32 accumulation in the matrix unit), the iterate and its update
 // stay float64 as in the other kernels.  Emulated on the golden inputs (tools/emulate_f16_split.py,
 // DESIGN 3): 2e-7 on diff_z after 500 iterations against 4e-8 for float32 operators; tolerance 1e-5.
-// float16 range: every voxel is scaled by a power of two so that max|y| lies in [2^9, 2^10) (the
+// float16 range: every voxel is scaled by a power of two so that max|y| lies in [2^13, 2^14) (the
 // problem is scale-covariant, threshold included: exact), taps by a power of two given by the host.
 //
 // Mapping: one wave = 16 problems; lane (v = lane & 15, g = lane >> 4) owns samples
@@ -45,6 +49,8 @@ namespace pb {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+constexpr float MFMA_RHO_MAX = 0.02f;
 
 struct MfmaTaps {
   float c[64];      // 2^a * cumsum(h)[m], m < 64 (constant from m = K-1 on)
@@ -73,7 +79,17 @@ struct Frag {
   h8 hi, lo;
 };
 
-// eight float32 -> float16 hi / lo parts (hi = RTZ(x), lo = RTZ(x - hi): 22 bits, saturating)
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+// two float32 -> packed float16, round to nearest even (v_cvt_pk_f16_f32).  The LOW parts are
+// rounded, not truncated: a truncated split shrinks every operand by ~2^-23 on average, a bias
+// that adds up coherently over samples and iterations (measured: 14x the error of float32
+// operators along a regularisation path, tools/r3_mfma_precision.py).
+__device__ __forceinline__ unsigned pk_rne(float x0, float x1) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f2v{x0, x1}, h2));
+}
+
+// eight float32 -> float16 hi / lo parts (hi = RTZ(x), lo = RNE(x - hi): 22 bits, unbiased)
 __device__ __forceinline__ Frag split8(const float (&x)[8]) {
   u4 ph, pl;
 #pragma unroll
@@ -83,7 +99,7 @@ __device__ __forceinline__ Frag split8(const float (&x)[8]) {
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(h2), "v"(x[2 * p]));
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(h2), "v"(x[2 * p + 1]));
     ph[p] = h2;
-    pl[p] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l0, l1));
+    pl[p] = pk_rne(l0, l1);
   }
   return Frag{__builtin_bit_cast(h8, ph), __builtin_bit_cast(h8, pl)};
 }
@@ -97,11 +113,15 @@ __device__ __forceinline__ f4 mma3(const Frag& A, const Frag& B, f4 acc) {
 }
 
 // NB blocks of 32 samples per series, 32 (NB - 1) < N <= 32 NB (only the last block can hold
-// padding), HRFs of up to 33 taps.
-// Plain solve (no cost trace, no stop rule).  A problem whose scaled operands came near the
-// float16 range (checked every 8 iterations and at the end; never seen on BOLD-like data: the
-// margin is 2^8) is left untouched with n_done = -1 for the exact kernels (capi.hip).
-template <int NB>
+// padding), HRFs of up to 33 taps.  No stop rule.
+// WITH_J: cost trace, J[it] = 0.5 ||T_c w_{it+1} - y||^2 + lbda ||w_{it+1}||_1 (pybold/bold_signal.py:74-77)
+//   from the residual of the NEXT forward pass (the loop is rotated: one forward pass in front).
+// TAPS_DEV: the HRF and the step are read from device memory (a.taps_pp: K float64 shared by every
+//   problem, a.step_vec[0]): the shared-HRF blind step, whose taps never pass through the host.
+// A problem whose scaled operands came near the float16 range (checked every 8 iterations and at
+// the end; never seen on BOLD-like data: the margin is 2^8) is left untouched with n_done = -1
+// for the exact kernels (capi.hip re-solves it).
+template <int NB, bool WITH_J = false, bool TAPS_DEV = false>
 __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps tp) {
   const int lane = threadIdx.x & 63;
   const int v = lane & 15, g = lane >> 4;
@@ -111,11 +131,41 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
   const int p = live ? prob : a.P - 1;
   const int tb = 8 * g;                          // this lane's offset inside a block of 32
 
+  extern __shared__ __attribute__((aligned(16))) char mf_smem[];
+  u4* lrf = reinterpret_cast<u4*>(mf_smem) + ((threadIdx.x >> 6) * NB * 2 * 64 + lane);
+  float* lc = reinterpret_cast<float*>(mf_smem + (size_t)4 * NB * 2 * 64 * sizeof(u4)) + (threadIdx.x >> 6) * 64;
+  auto wave_sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+
+  // ---- cumulative taps c[m] = sum_{k <= min(m, K-1)} h[k], scaled by 2^a so that max |c| is in [4, 8) ----
+  double step = a.step, g_scale = tp.g_scale;
+  float y_scale = tp.y_scale;
+  if constexpr (TAPS_DEV) {
+    double run = 0.0;
+    for (int k = 0; k <= lane && k < a.K; ++k) run += (double)(float)a.taps_pp[k];
+    float cm = fabsf((float)run);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) cm = fmaxf(cm, __shfl_xor(cm, o, 64));
+    int e = 0;
+    if (cm > 0.0f) (void)frexpf(cm, &e);
+    const int sa = 3 - e;
+    lc[lane] = (float)ldexp(run, sa);
+    g_scale = ldexp(1.0, -2 * sa);
+    y_scale = ldexpf(1.0f, sa);
+    step = a.step_vec[0];
+  } else {
+    lc[lane] = tp.c[lane];
+  }
+  wave_sync();
+
   // ---- operator tiles (A operands): lane holds row rho = lane & 15, k = 8 (lane >> 4) + j ----
   Frag An[2][2], Bn[2][2], Ff;                   // forward near [r][o], adjoint near [r][o], far field
   {
     const int rho = lane & 15, kg = lane >> 4, gp = rho >> 2, i = rho & 3;
-    auto cval = [&](int lag) -> float { return lag < 0 ? 0.0f : tp.c[lag > 63 ? 63 : lag]; };
+    auto cval = [&](int lag) -> float { return lag < 0 ? 0.0f : lc[lag > 63 ? 63 : lag]; };
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -131,7 +181,7 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
       }
     float ff[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ff[j] = tp.c[63];
+    for (int j = 0; j < 8; ++j) ff[j] = lc[63];
     Ff = split8(ff);
   }
 
@@ -157,10 +207,10 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
     if (m > 0.0f && m < 3.0e38f) {
       int e;
       (void)frexpf(m, &e);                       // m = f 2^e, f in [0.5, 1)
-      sigma = ldexpf(1.0f, 10 - e);
-      inv_sigma = ldexpf(1.0f, e - 10);
+      sigma = ldexpf(1.0f, a.ybits - e);
+      inv_sigma = ldexpf(1.0f, e - a.ybits);
     }
-    const float ys = -sigma * tp.y_scale;
+    const float ys = -sigma * y_scale;
     const double* wrow = a.w + (int64_t)p * a.ldw;
 #pragma unroll
     for (int q = 0; q < NB; ++q)
@@ -171,14 +221,18 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
         w[q][j] = (t < a.N && !a.cold) ? wrow[t] * (double)sigma : 0.0;
       }
   }
-  const double th = lb * a.step * (double)sigma;
-  const double nstep = -a.step * tp.g_scale;
-  float guard = 0.0f;                            // running max of |operands| on the checked iterations
+  const double th = lb * step * (double)sigma;
+  const double nstep = -step * g_scale;
+  float guard = 0.0f;                            // largest |operand| seen by the range checks
+  float wlast = 0.0f;                            // largest |sigma w| of this lane at the last check
+  // cost trace: 0.5 ||r''||^2 / (2^a sigma)^2 + lbda ||w'||_1 / sigma
+  const float jq = 0.5f * (inv_sigma / y_scale) * (inv_sigma / y_scale), jl = (float)lb * inv_sigma;
+  float jsq = 0.0f, jl1 = 0.0f;
 
-  // Register placement: the operator tiles and the residual fragments are read by matrix
-  // instructions only and -y'' once per iteration: they live in the accumulator half of the
-  // register file (the asm constraints put them there; MFMA reads A/B operands from either
-  // half), the float64 iterate and everything the vector pipe touches in the other.
+  // Register placement: the operator tiles are read by matrix instructions only and -y'' once per
+  // iteration: they live in the accumulator half of the register file (the asm constraints put
+  // them there; MFMA reads A/B operands from either half), the float64 iterate and everything
+  // the vector pipe touches in the other.
 #pragma unroll
   for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -190,151 +244,153 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
 #pragma unroll
     for (int j = 0; j < 8; ++j) asm volatile("" : "+a"(ysn[q][j]));
 
-  extern __shared__ __attribute__((aligned(16))) char mf_smem[];
-  u4* lrf = reinterpret_cast<u4*>(mf_smem) + ((threadIdx.x >> 6) * NB * 2 * 64 + lane);
-  // One iteration, straight-line.  The matrix pipe takes one instruction per 16 cycles and holds
+  // The iteration is straight-line.  The matrix pipe takes one instruction per 16 cycles and holds
   // the vector issue port for 8 of them, so the source is software-pipelined BY HAND at that grain
-  // (this translation unit is built with -enable-misched=0: source order is kept): every matrix
-  // instruction of block q is followed by a slice of the vector work of its neighbours -- the
-  // float16 fragments of block q+1, the residual (or the update) of the block before.
+  // (sched_barrier after every slot keeps the order): every matrix instruction of block q is
+  // followed by a slice of the vector work of its neighbours -- the float16 fragments of block
+  // q+1, the residual (or the update) of the block before.
   auto mfma_part = [](const Frag& A, const Frag& B, f4 acc, int part) __attribute__((always_inline)) -> f4 {
     // the three products of a split pair, one per call: hi.hi, hi.lo, lo.hi
+#ifdef PB_MFMA_LOLO
+    if (part == 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A.lo, B.lo, acc, 0, 0, 0);
+#endif
     return part == 0   ? __builtin_amdgcn_mfma_f32_16x16x32_f16(A.hi, B.hi, acc, 0, 0, 0)
            : part == 1 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(A.hi, B.lo, acc, 0, 0, 0)
                        : __builtin_amdgcn_mfma_f32_16x16x32_f16(A.lo, B.hi, acc, 0, 0, 0);
   };
-  auto iteration = [&](const double beta) __attribute__((always_inline)) {
+  // ---- forward: r = T_c w - y, block by block (ascending); fragments of r go to LDS -------------
+  auto forward = [&]() __attribute__((always_inline)) {
+    f4 carry = f4{0.f, 0.f, 0.f, 0.f};            // S * (sum of the blocks up to q-2), every row
+    Frag wf[NB + 1];
+    f4 acc[NB + 1][2];
+    unsigned ph[NB + 1][4], pl[NB + 1][4];
+    unsigned rh[NB][4], rl[NB][4];
+    if constexpr (WITH_J) { jsq = 0.0f; jl1 = 0.0f; }
+    auto prep_pair = [&](auto qc, auto pc) {      // samples 2p, 2p+1 of block q -> float16 hi / lo
+      constexpr int q = decltype(qc)::value, pp = decltype(pc)::value;
+      float x0, x1;                               // (asm: the conversion stays HERE, not behind the update)
+      asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(x0) : "v"(w[q][2 * pp]));
+      asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(x1) : "v"(w[q][2 * pp + 1]));
+      if constexpr (WITH_J) jl1 += fabsf(x0) + fabsf(x1);
+      const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+      float l0, l1;
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(h2), "v"(x0));
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(h2), "v"(x1));
+      ph[q][pp] = h2;
+      pl[q][pp] = pk_rne(l0, l1);
+      if constexpr (pp == 3) {
+        wf[q].hi = __builtin_bit_cast(h8, u4{ph[q][0], ph[q][1], ph[q][2], ph[q][3]});
+        wf[q].lo = __builtin_bit_cast(h8, u4{pl[q][0], pl[q][1], pl[q][2], pl[q][3]});
+      }
+    };
+    auto cinit = [&](auto qc, auto rc, const f4& cy) {   // accumulators of block q start from carry - y
+      constexpr int q = decltype(qc)::value, r = decltype(rc)::value;
+      acc[q][r] = f4{cy[0] + ysn[q][4 * r + 0], cy[1] + ysn[q][4 * r + 1], cy[2] + ysn[q][4 * r + 2],
+                     cy[3] + ysn[q][4 * r + 3]};
+    };
+    auto finish_pair = [&](auto qc, auto pc) {    // residual samples 2p, 2p+1 of block q -> fragment
+      constexpr int q = decltype(qc)::value, pp = decltype(pc)::value;
+      float x0 = acc[q][pp >> 1][(2 * pp) & 3], x1 = acc[q][pp >> 1][(2 * pp + 1) & 3];
+      if constexpr (q == NB - 1) {                // padding behind sample N-1 (last block only)
+        x0 = (32 * q + tb + 2 * pp < a.N) ? x0 : 0.0f;
+        x1 = (32 * q + tb + 2 * pp + 1 < a.N) ? x1 : 0.0f;
+      }
+      if constexpr (WITH_J) jsq = fmaf(x1, x1, fmaf(x0, x0, jsq));
+      const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+      float l0, l1;
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(h2), "v"(x0));
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(h2), "v"(x1));
+      rh[q][pp] = h2;
+      rl[q][pp] = pk_rne(l0, l1);
+      if constexpr (pp == 3) {
+        // the residual fragments wait in LDS for the adjoint pass (each lane reads back only what
+        // it wrote: no barrier); in registers they would cost 80 accumulator-file copies per iteration
+        lrf[(2 * q) * 64] = u4{rh[q][0], rh[q][1], rh[q][2], rh[q][3]};
+        lrf[(2 * q + 1) * 64] = u4{rl[q][0], rl[q][1], rl[q][2], rl[q][3]};
+      }
+    };
+    static_for<0, 4>([&](auto pc) { prep_pair(std::integral_constant<int, 0>{}, pc); });
+    cinit(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, carry);
+    cinit(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, carry);
+    static_for<0, NB>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      f4 cn = carry;                              // carry of block q+1
+      static_for<0, 15>([&](auto sc) {
+        constexpr int sl = decltype(sc)::value;
+        // -- the matrix instruction of this slot
+        if constexpr (sl < 3) {
+          if constexpr (q >= 1 && q + 1 < NB) cn = mfma_part(Ff, wf[q - 1], cn, sl);
+        } else {
+          constexpr int c = sl - 3, r = c & 1, k = c >> 1;
+          if constexpr (k < 3) acc[q][r] = mfma_part(An[r][0], wf[q], acc[q][r], k);
+          else if constexpr (q >= 1) acc[q][r] = mfma_part(An[r][1], wf[q - 1], acc[q][r], k - 3);
+        }
+        // -- a slice of the neighbours' vector work
+        if constexpr (sl < 4) {
+          if constexpr (q + 1 < NB) prep_pair(std::integral_constant<int, q + 1>{}, sc);
+        } else if constexpr (sl < 8) {
+          if constexpr (q >= 1) finish_pair(std::integral_constant<int, q - 1>{}, std::integral_constant<int, sl - 4>{});
+        } else if constexpr (sl == 10 || sl == 11) {
+          if constexpr (q + 1 < NB) cinit(std::integral_constant<int, q + 1>{}, std::integral_constant<int, sl - 10>{}, cn);
+        }
+        PB_MFMA_SB;
+      });
+      carry = cn;
+    });
+    static_for<0, 4>([&](auto pc) { finish_pair(std::integral_constant<int, NB - 1>{}, pc); });
+  };
+  // ---- adjoint and update: g = T_c^T r, block by block (descending) ------------------------------
+  auto backward = [&](const double beta) __attribute__((always_inline)) {
     const double nb1 = -(1.0 + beta);
-    // ---- forward: r = T_c w - y, block by block (ascending) -------------------------------
-    {
-      f4 carry = f4{0.f, 0.f, 0.f, 0.f};          // S * (sum of the blocks up to q-2), every row
-      Frag wf[NB + 1];
-      f4 acc[NB + 1][2];
-      unsigned ph[NB + 1][4], pl[NB + 1][4];
-      float r8[NB][8];
-      auto prep_pair = [&](auto qc, auto pc) {    // samples 2p, 2p+1 of block q -> float16 hi / lo
-        constexpr int q = decltype(qc)::value, pp = decltype(pc)::value;
-        float x0, x1;                             // (asm: the conversion stays HERE, not behind the update)
-        asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(x0) : "v"(w[q][2 * pp]));
-        asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(x1) : "v"(w[q][2 * pp + 1]));
-        const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
-        float l0, l1;
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(h2), "v"(x0));
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(h2), "v"(x1));
-        ph[q][pp] = h2;
-        pl[q][pp] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l0, l1));
-        if constexpr (pp == 3) {
-          wf[q].hi = __builtin_bit_cast(h8, u4{ph[q][0], ph[q][1], ph[q][2], ph[q][3]});
-          wf[q].lo = __builtin_bit_cast(h8, u4{pl[q][0], pl[q][1], pl[q][2], pl[q][3]});
+    f4 carry = f4{0.f, 0.f, 0.f, 0.f};            // S * (sum of the residual blocks from q+2 on)
+    f4 acc[NB + 1][2];
+    Frag rf[NB + 2];
+    auto fetch = [&](auto qc) {                   // residual fragment of block q: LDS -> registers
+      constexpr int q = decltype(qc)::value;
+      rf[q].hi = __builtin_bit_cast(h8, lrf[(2 * q) * 64]);
+      rf[q].lo = __builtin_bit_cast(h8, lrf[(2 * q + 1) * 64]);
+    };
+    auto update = [&](auto qc, auto jc) {
+      constexpr int q = decltype(qc)::value, j = decltype(jc)::value;
+      const double gj = (double)acc[q][j >> 2][j & 3];
+      const double u = fma(nstep, gj, w[q][j]);
+      const double d = fmin(fmax(u, -th), th);
+      w[q][j] = fma(nb1, d, u);
+    };
+    fetch(std::integral_constant<int, NB - 1>{});
+    static_for<0, NB>([&](auto qq) {
+      constexpr int q = NB - 1 - decltype(qq)::value;
+      f4 cn = carry;                              // carry of block q-1
+      if constexpr (q >= 1) fetch(std::integral_constant<int, q - 1>{});   // one block ahead
+      static_for<0, 15>([&](auto sc) {
+        constexpr int sl = decltype(sc)::value;
+        if constexpr (sl < 3) {
+          if constexpr (q >= 1 && q + 1 < NB) cn = mfma_part(Ff, rf[q + 1], cn, sl);
+        } else {
+          constexpr int c = sl - 3, r = c & 1, k = c >> 1;
+          if constexpr (k == 0) acc[q][r] = mfma_part(Bn[r][0], rf[q], carry, 0);
+          else if constexpr (k < 3) acc[q][r] = mfma_part(Bn[r][0], rf[q], acc[q][r], k);
+          else if constexpr (q + 1 < NB) acc[q][r] = mfma_part(Bn[r][1], rf[q + 1], acc[q][r], k - 3);
         }
-      };
-      auto cinit = [&](auto qc, auto rc, const f4& cy) {   // accumulators of block q start from carry - y
-        constexpr int q = decltype(qc)::value, r = decltype(rc)::value;
-        acc[q][r] = f4{cy[0] + ysn[q][4 * r + 0], cy[1] + ysn[q][4 * r + 1], cy[2] + ysn[q][4 * r + 2],
-                       cy[3] + ysn[q][4 * r + 3]};
-      };
-      unsigned rh[NB][4], rl[NB][4];
-      auto finish_pair = [&](auto qc, auto pc) {  // residual samples 2p, 2p+1 of block q -> fragment
-        constexpr int q = decltype(qc)::value, pp = decltype(pc)::value;
-        float x0 = acc[q][pp >> 1][(2 * pp) & 3], x1 = acc[q][pp >> 1][(2 * pp + 1) & 3];
-        if constexpr (q == NB - 1) {              // padding behind sample N-1 (last block only)
-          x0 = (32 * q + tb + 2 * pp < a.N) ? x0 : 0.0f;
-          x1 = (32 * q + tb + 2 * pp + 1 < a.N) ? x1 : 0.0f;
-        }
-        const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
-        float l0, l1;
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(h2), "v"(x0));
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(h2), "v"(x1));
-        rh[q][pp] = h2;
-        rl[q][pp] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l0, l1));
-        if constexpr (pp == 3) {
-          // the residual fragments wait in LDS for the adjoint pass (each lane reads back only what
-          // it wrote: no barrier); in registers they would cost 80 accumulator-file copies per iteration
-          lrf[(2 * q) * 64] = u4{rh[q][0], rh[q][1], rh[q][2], rh[q][3]};
-          lrf[(2 * q + 1) * 64] = u4{rl[q][0], rl[q][1], rl[q][2], rl[q][3]};
-        }
-      };
-      (void)r8;
-      static_for<0, 4>([&](auto pc) { prep_pair(std::integral_constant<int, 0>{}, pc); });
-      cinit(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, carry);
-      cinit(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, carry);
-      static_for<0, NB>([&](auto qc) {
-        constexpr int q = decltype(qc)::value;
-        f4 cn = carry;                            // carry of block q+1
-        static_for<0, 15>([&](auto sc) {
-          constexpr int sl = decltype(sc)::value;
-          // -- the matrix instruction of this slot
-          if constexpr (sl < 3) {
-            if constexpr (q >= 1 && q + 1 < NB) cn = mfma_part(Ff, wf[q - 1], cn, sl);
-          } else {
-            constexpr int c = sl - 3, r = c & 1, k = c >> 1;
-            if constexpr (k < 3) acc[q][r] = mfma_part(An[r][0], wf[q], acc[q][r], k);
-            else if constexpr (q >= 1) acc[q][r] = mfma_part(An[r][1], wf[q - 1], acc[q][r], k - 3);
-          }
-          // -- a slice of the neighbours' vector work
-          if constexpr (sl < 4) {
-            if constexpr (q + 1 < NB) prep_pair(std::integral_constant<int, q + 1>{}, sc);
-          } else if constexpr (sl < 8) {
-            if constexpr (q >= 1) finish_pair(std::integral_constant<int, q - 1>{}, std::integral_constant<int, sl - 4>{});
-          } else if constexpr (sl == 10 || sl == 11) {
-            if constexpr (q + 1 < NB) cinit(std::integral_constant<int, q + 1>{}, std::integral_constant<int, sl - 10>{}, cn);
-          }
-          PB_MFMA_SB;
-        });
-        carry = cn;
+        if constexpr ((sl & 1) == 0 && q + 1 < NB)
+          update(std::integral_constant<int, q + 1>{}, std::integral_constant<int, sl / 2>{});
+        PB_MFMA_SB;
       });
-      static_for<0, 4>([&](auto pc) { finish_pair(std::integral_constant<int, NB - 1>{}, pc); });
-    }
-    // ---- adjoint and update: g = T_c^T r, block by block (descending) ----------------------
-    {
-      f4 carry = f4{0.f, 0.f, 0.f, 0.f};          // S * (sum of the residual blocks from q+2 on)
-      f4 acc[NB + 1][2];
-      Frag rf[NB + 2];
-      auto fetch = [&](auto qc) {                 // residual fragment of block q: LDS -> registers
-        constexpr int q = decltype(qc)::value;
-        rf[q].hi = __builtin_bit_cast(h8, lrf[(2 * q) * 64]);
-        rf[q].lo = __builtin_bit_cast(h8, lrf[(2 * q + 1) * 64]);
-      };
-      fetch(std::integral_constant<int, NB - 1>{});
-      auto update = [&](auto qc, auto jc) {
-        constexpr int q = decltype(qc)::value, j = decltype(jc)::value;
-        const double gj = (double)acc[q][j >> 2][j & 3];
-        const double u = fma(nstep, gj, w[q][j]);
-        const double d = fmin(fmax(u, -th), th);
-        w[q][j] = fma(nb1, d, u);
-      };
-      static_for<0, NB>([&](auto qq) {
-        constexpr int q = NB - 1 - decltype(qq)::value;
-        f4 cn = carry;                            // carry of block q-1
-        if constexpr (q >= 1) fetch(std::integral_constant<int, q - 1>{});   // one block ahead
-        static_for<0, 15>([&](auto sc) {
-          constexpr int sl = decltype(sc)::value;
-          if constexpr (sl < 3) {
-            if constexpr (q >= 1 && q + 1 < NB) cn = mfma_part(Ff, rf[q + 1], cn, sl);
-          } else {
-            constexpr int c = sl - 3, r = c & 1, k = c >> 1;
-            if constexpr (k == 0) acc[q][r] = mfma_part(Bn[r][0], rf[q], carry, 0);
-            else if constexpr (k < 3) acc[q][r] = mfma_part(Bn[r][0], rf[q], acc[q][r], k);
-            else if constexpr (q + 1 < NB) acc[q][r] = mfma_part(Bn[r][1], rf[q + 1], acc[q][r], k - 3);
-          }
-          if constexpr ((sl & 1) == 0 && q + 1 < NB)
-            update(std::integral_constant<int, q + 1>{}, std::integral_constant<int, sl / 2>{});
-          PB_MFMA_SB;
-        });
-        carry = cn;
-      });
-      static_for<0, 8>([&](auto jc) { update(std::integral_constant<int, 0>{}, jc); });
-    }
+      carry = cn;
+    });
+    static_for<0, 8>([&](auto jc) { update(std::integral_constant<int, 0>{}, jc); });
   };
   // Range guard, every 8th iteration and after the last one: the largest |sigma w| (registers) and
   // the largest exponent among the hi halves of the residual fragments (LDS copy) -- a small block
   // of its own, so that the iteration body exists once.
   auto range_check = [&]() {
-    float m = 0.0f;
+    unsigned mb = 0;                              // largest |sigma w| by its float32 bits: NaN and inf rank highest
 #pragma unroll
     for (int q = 0; q < NB; ++q)
 #pragma unroll
-      for (int j = 0; j < 8; j += 2) m = __builtin_fmaxf(m, __builtin_fmaxf(fabsf((float)w[q][j]), fabsf((float)w[q][j + 1])));
+      for (int j = 0; j < 8; ++j) mb = max(mb, __builtin_bit_cast(unsigned, (float)w[q][j]) & 0x7fffffffu);
+    const float m = mb >= 0x7f800000u ? 65504.0f : __builtin_bit_cast(float, mb);
+    wlast = m;
     unsigned e = 0;
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
@@ -348,16 +404,43 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
     // float16 bits of |hi|: 0x7800 = 32768
     guard = __builtin_fmaxf(guard, __builtin_fmaxf(m, e >= 0x7800u ? 65504.0f : 0.0f));
   };
-  for (int it = 0; it < a.n_iter; ++it) {
-    const double beta = a.betas[it];
-    iteration(beta);
-    if (PB_MFMA_CHECKS && (((it & 7) == 7) || (it == a.n_iter - 1))) range_check();
+
+  if constexpr (!WITH_J) {
+    for (int it = 0; it < a.n_iter; ++it) {
+      const double beta = a.betas[it];
+      forward();
+      backward(beta);
+      if (PB_MFMA_CHECKS && (((it & 7) == 7) || (it == a.n_iter - 1))) range_check();
+    }
+  } else {
+    forward();
+    for (int it = 0; it < a.n_iter; ++it) {
+      const double beta = a.betas[it];
+      backward(beta);
+      forward();
+      float sq = jsq, l1 = jl1;                   // this lane's 8 NB samples -> the problem's 32 NB
+      sq += __shfl_xor(sq, 16, 64);
+      l1 += __shfl_xor(l1, 16, 64);
+      sq += __shfl_xor(sq, 32, 64);
+      l1 += __shfl_xor(l1, 32, 64);
+      if (live && g == 0) a.J[(int64_t)p * a.ldj + it] = fmaf(jq, sq, jl * l1);
+      if (PB_MFMA_CHECKS && (((it & 7) == 7) || (it == a.n_iter - 1))) range_check();
+    }
   }
 
   // ---- store (unscaled); a problem that came near the float16 range is handed back ----------
   guard = fmaxf(guard, __shfl_xor(guard, 16, 64));
   guard = fmaxf(guard, __shfl_xor(guard, 32, 64));
-  const bool bad = !(guard < 30000.0f);          // NaN-safe
+  wlast = fmaxf(wlast, __shfl_xor(wlast, 16, 64));
+  wlast = fmaxf(wlast, __shfl_xor(wlast, 32, 64));
+  // Accuracy guard.  An error eps in the gradient moves an entry of the solution by ~eps th, so the
+  // relative error of a solution grows like th / max|w| -- for every arithmetic; the 22-bit operands
+  // here start 8x above float32 operators.  Measured along regularisation paths
+  // (tools/r3_mfma_precision.py): <= 2e-6 on diff_z for th / max|w| < 0.03, up to 1.5e-5 beyond 0.1.
+  // Problems above MFMA_RHO_MAX (sparse solutions, lambda near lambda_max) go back to the float32
+  // operators like those that left the float16 range.
+  const bool bad = !(guard < 60000.0f) ||        // NaN-safe (float16: 65504)
+                   (wlast > 0.0f && (float)th > MFMA_RHO_MAX * wlast);
   if (live && !bad) {
     double* wrow = a.w + (int64_t)p * a.ldw;
 #pragma unroll
@@ -371,14 +454,21 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
   if (live && a.n_done && g == 0) a.n_done[p] = bad ? -1 : a.n_iter;
 }
 
+// 16 problems per wave, 4 waves per workgroup, one wave per SIMD
 template <int NB>
-int launch_mfma(const FistaArgs& a, const double* taps, int K, hipStream_t st) {
-  if (a.N > 32 * NB || a.N <= 32 * (NB - 1) || K > 33) return 1;
-  const MfmaTaps tp = make_mfma_taps(taps, K);
+int launch_mfma(const FistaArgs& a, const double* taps, int K, bool with_j, hipStream_t st) {
+  if (a.N > 32 * NB || a.N <= 32 * (NB - 1) || K > 33 || K < 1) return 1;
   const int64_t waves = ((int64_t)(a.P - a.p0) + 15) / 16;
   const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-  const size_t lds = (size_t)4 * NB * 2 * 64 * sizeof(u4);      // residual fragments: 8 KB per block of 32 samples
-  hipLaunchKernelGGL((fista_mfma_kernel<NB>), grid, block, lds, st, a, tp);
+  const size_t lds = (size_t)4 * NB * 2 * 64 * sizeof(u4) + 4 * 64 * sizeof(float);   // residual fragments (8 KB per block of 32 samples), taps
+  if (a.taps_pp) {                              // shared HRF and step in device memory; no cost trace
+    const MfmaTaps none{};
+    hipLaunchKernelGGL((fista_mfma_kernel<NB, false, true>), grid, block, lds, st, a, none);
+    return 0;
+  }
+  const MfmaTaps tp = make_mfma_taps(taps, K);
+  if (with_j) hipLaunchKernelGGL((fista_mfma_kernel<NB, true, false>), grid, block, lds, st, a, tp);
+  else hipLaunchKernelGGL((fista_mfma_kernel<NB, false, false>), grid, block, lds, st, a, tp);
   return 0;
 }
 

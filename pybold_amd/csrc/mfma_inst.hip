@@ -1,5 +1,9 @@
-// The matrix-pipe form of the fused FISTA kernel (fista_mfma.h): series of up to 320 scans.
+// The matrix-pipe form of the fused FISTA kernel (fista_mfma.h): series of 129..320 scans
+// (NB blocks of 32 samples; only the last block may hold padding), HRFs of up to 33 taps.
 #include "fista_mfma.h"
+#ifndef PB_NB
+#error "compile with -DPB_NB=<blocks of 32 samples>"
+#endif
 namespace pb {
-template int launch_mfma<10>(const FistaArgs&, const double*, int, hipStream_t);
+template int launch_mfma<PB_NB>(const FistaArgs&, const double*, int, bool, hipStream_t);
 }

@@ -30,7 +30,10 @@ _FORCE = {None: 0, "generic": PB_FLAG_FORCE_GENERIC, "fast": PB_FLAG_FORCE_FAST,
           # tol * n_iter is; "nocert" = always the full rule (single-row form)
           "cert": PB_FLAG_FORCE_CERT, "cert2": PB_FLAG_FORCE_CERT | PB_FLAG_FORCE_PAIR | PB_FLAG_ONE_LAUNCH,
           "certonly": PB_FLAG_FORCE_CERT | PB_FLAG_FORCE_PAIR | PB_FLAG_ONE_LAUNCH | _lib.PB_FLAG_CERT_NO_RESOLVE,
-          "nocert": PB_FLAG_NO_CERT, "mfma": _lib.PB_FLAG_MFMA}
+          "nocert": PB_FLAG_NO_CERT,
+          # "valu": library dispatch without the matrix-pipe form; "mfma": everything on it, one launch
+          "valu": _lib.PB_FLAG_NO_MFMA, "valuseq": _lib.PB_FLAG_NO_MFMA | PB_FLAG_ONE_STREAM,
+          "mfma": PB_FLAG_ONE_LAUNCH | _lib.PB_FLAG_FORCE_MFMA}
 
 
 _warned = set()
@@ -153,7 +156,8 @@ def has_fast_path(n_scans, n_taps):
 
 KERNEL_NAMES = {0: "fista_generic_kernel (LDS)", 1: "fista_fast_kernel (register-resident)",
                 2: "fista_pair_ffa_kernel (register-resident, two problems per row, fast FIRs)",
-                3: "fista_fast_kernel (register-resident, one problem per wave)"}
+                3: "fista_fast_kernel (register-resident, one problem per wave)",
+                4: "fista_mfma_kernel (register-resident, 16 problems per wave, both operators on the matrix pipe)"}
 
 
 def which_kernel(n_scans, n_taps, n_problems, want_J=False, stop=None, wind=6):
@@ -162,13 +166,14 @@ def which_kernel(n_scans, n_taps, n_problems, want_J=False, stop=None, wind=6):
         int(n_scans), int(n_taps), int(n_problems), int(bool(want_J)), _STOP[stop], int(wind))]
 
 
-def launch_plan(n_scans, n_taps, n_problems, stop=None, wind=6):
+def launch_plan(n_scans, n_taps, n_problems, stop=None, wind=6, force=None):
     """``(n_main, main kernel, tail kernel)``: how :func:`fista_solve` lays the problems out --
-    the first ``n_main`` (whole rounds of waves) in one launch, the rest in a second one."""
+    the first ``n_main`` (whole rounds of waves) in one launch, the rest in a second one
+    (``force="valu"``: the plan without the matrix-pipe form)."""
     import ctypes
     nm, mf, tf = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
-    _lib.load().pb_fista_plan(int(n_scans), int(n_taps), int(n_problems), _STOP[stop], int(wind),
-                              ctypes.byref(nm), ctypes.byref(mf), ctypes.byref(tf))
+    _lib.load().pb_fista_plan_ex(int(n_scans), int(n_taps), int(n_problems), _STOP[stop], int(wind),
+                                 _FORCE[force], ctypes.byref(nm), ctypes.byref(mf), ctypes.byref(tf))
     return nm.value, (KERNEL_NAMES[mf.value] if nm.value else None), KERNEL_NAMES[tf.value]
 
 
@@ -304,10 +309,11 @@ def round_size(n_scans, n_taps, dev=None):
     """Problems in one full round of waves of the densest plain kernel form for this shape
     (two waves on every SIMD of the device), or None when only the LDS kernel applies."""
     n_main, main, tail = launch_plan(n_scans, n_taps, 1 << 22)
-    per_wave = {KERNEL_NAMES[2]: 8, KERNEL_NAMES[1]: 4, KERNEL_NAMES[3]: 1}.get(main if n_main else tail)
-    if per_wave is None:
+    # problems per wave x waves per SIMD of each form
+    per_simd = {KERNEL_NAMES[4]: 16, KERNEL_NAMES[2]: 16, KERNEL_NAMES[1]: 8, KERNEL_NAMES[3]: 2}.get(main if n_main else tail)
+    if per_simd is None:
         return None
-    return torch.cuda.get_device_properties(device(dev)).multi_processor_count * 4 * 2 * per_wave
+    return torch.cuda.get_device_properties(device(dev)).multi_processor_count * 4 * per_simd
 
 
 class HostPipeline:

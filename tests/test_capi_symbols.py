@@ -55,17 +55,20 @@ def test_version_and_dispatch_table(lib):
     # dispatch of a plain solve: pair kernel for machine-filling batches (with or without
     # the cost trace, and for the window rule at wind = 6: no-fire certificate + re-solve, round 3),
     # single-row kernel for small ones and for the _loops_deconv rule
-    assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 0, 6) == 2
-    assert lib.pb_fista_which_kernel(300, 30, 100000, 1, 0, 6) == 2      # cost trace: pair form too
+    assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 0, 6) == 4      # plain solves: both operators on the matrix pipe (round 3)
+    assert lib.pb_fista_which_kernel(300, 30, 100000, 1, 0, 6) == 4      # cost trace: matrix-pipe form too
     assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 2, 6) == 2      # window rule: certificate on the pair form
     assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 1, 6) == 1      # _loops_deconv rule: single-row form
     assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 2, 4) == 1      # wind 4 / 8: full rule, single-row form
     assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 2, 8) == 1
     assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 2, 5) == 0      # other windows: LDS kernel (the Python layer warns)
     assert lib.pb_fista_which_kernel(300, 30, 1, 0, 0, 6) == 3           # a few short series: one per wave
-    assert lib.pb_fista_which_kernel(300, 30, 10000, 0, 0, 6) == 2       # config 2: half a round of pair waves + a remainder
+    assert lib.pb_fista_which_kernel(300, 30, 10000, 0, 0, 6) == 4       # config 2: one (partial) round of matrix-pipe waves
     assert lib.pb_fista_which_kernel(300, 30, 4096, 0, 0, 6) == 1        # single-row kernel
-    assert lib.pb_fista_which_kernel(300, 30, 12500, 0, 0, 6) == 2       # config 3's shard on 8 GPUs
+    assert lib.pb_fista_which_kernel(300, 30, 12500, 0, 0, 6) == 4       # config 3's shard on 8 GPUs
+    assert lib.pb_fista_which_kernel(300, 30, 8000, 0, 0, 6) == 2        # under half a round: the vector forms
+    assert lib.pb_fista_which_kernel(240, 27, 50000, 0, 0, 6) == 4       # 129..320 scans, up to 33 taps
+    assert lib.pb_fista_which_kernel(128, 16, 50000, 0, 0, 6) == 2       # shorter series: pair form
     assert lib.pb_fista_which_kernel(300, 30, 8192, 1, 2, 6) == 2        # the deconv default call: pair form
     assert lib.pb_fista_which_kernel(300, 30, 8192, 1, 1, 6) == 1        # _loops_deconv rule: single-row kernel
     assert lib.pb_fista_which_kernel(300, 30, 3, 1, 2, 6) == 3           # ... or one problem per wave

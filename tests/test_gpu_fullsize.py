@@ -37,24 +37,24 @@ def rel_rows_t(a, b):
 def test_full_batch_properties(setup):
     solver, hrf, Y = setup
     step = 1.0 / LIP
-    for force in ("fast1", "fast2", "fast2d"):          # both register-resident kernels
+    for force in ("fast1", "fast2", "fast2d", "mfma"):  # the register-resident kernel forms
         W, _, n_done = solver.fista_solve(Y, hrf, 1.0, step, 60, force=force)
         assert W.shape == (V, N) and bool(torch.isfinite(W).all()) and int(n_done.min()) == 60
         # batch independence (bitwise): odd-sized slice, different workgroup/row packing
         lo, hi = 31337, 31337 + 4099
         Ws, _, _ = solver.fista_solve(Y[lo:hi].contiguous(), hrf, 1.0, step, 60, force=force)
         assert torch.equal(Ws, W[lo:hi]), force
-        # odd symmetry (bitwise)
+        # odd symmetry (bitwise; the matrix unit's float32 accumulation is not sign-symmetric in its last bit)
         Wn, _, _ = solver.fista_solve(-Y, hrf, 1.0, step, 60, force=force)
-        assert torch.equal(Wn, -W), force
+        assert (torch.equal(Wn, -W) if force != "mfma" else rel_rows_t(Wn, -W) < 1e-6), force
         # positive homogeneity
         Wh, _, _ = solver.fista_solve(Y * 4.0, hrf, 4.0, step, 60, force=force)  # power of two: exact
         assert torch.equal(Wh, 4.0 * W), force
         Wh, _, _ = solver.fista_solve(Y * 3.0, hrf, 3.0, step, 60, force=force)
         assert rel_rows_t(Wh, 3.0 * W) < 1e-5
-    # the two kernels agree (different summation order inside the FIR)
+    # the kernel forms agree (different summation order inside the FIR; float16 split products)
     W1, _, _ = solver.fista_solve(Y, hrf, 1.0, step, 60, force="fast1")
-    assert rel_rows_t(W, W1) < 1e-6
+    assert rel_rows_t(W, W1) < 2e-6
 
 
 def test_full_batch_linearity_without_prox(setup):

@@ -425,7 +425,8 @@ def orc_fista_one(y, hrf, lbda, step, n_iter, w0):
 
 
 def test_side_stream_remainder(solver, golden):
-    """8 192 < P < 16 384 problems: half a round of pair waves on the caller's stream with the
+    """The plan of the VECTOR forms (force="valu": since round 3 plain solves of this shape go to the
+    matrix-pipe form above half a round).  8 192 < P < 16 384 problems: half a round of pair waves on the caller's stream with the
     remainder beside it on the library's side stream (fork/join by events).  Where the
     one-stream plan uses the same pieces the results are bitwise equal; results are complete in
     the caller's stream order (consumed at once, no synchronisation); repeated calls; a
@@ -437,11 +438,11 @@ def test_side_stream_remainder(solver, golden):
     rng = np.random.RandomState(3)
     for P in (8200, 10000, 12288, 12500, 12800):
         Y = torch.from_numpy(rng.randn(P, 300).astype(np.float32)).cuda()
-        n_main, main_k, tail_k = solver.launch_plan(300, 30, P)
+        n_main, main_k, tail_k = solver.launch_plan(300, 30, P, force="valu")
         assert n_main == 8192 and "two problems per row" in main_k
-        W, _, _ = solver.fista_solve(Y, hrf, 1.0, step, 40)
+        W, _, _ = solver.fista_solve(Y, hrf, 1.0, step, 40, force="valu")
         s1 = W.abs().sum()                       # consumer on the caller's stream, right away
-        Wq, _, _ = solver.fista_solve(Y, hrf, 1.0, step, 40, force="seq")
+        Wq, _, _ = solver.fista_solve(Y, hrf, 1.0, step, 40, force="valuseq")
         # (the one-stream plan uses the same pieces up to 12 288 problems, other kernels beyond)
         if P <= 12288:
             assert torch.equal(W, Wq), P
@@ -456,11 +457,11 @@ def test_side_stream_remainder(solver, golden):
     # one-problem waves beside them
     for P in (4500, 6144, 21000):
         Y = torch.from_numpy(rng.randn(P, 300).astype(np.float32)).cuda()
-        n_main, main_k, tail_k = solver.launch_plan(300, 30, P)
+        n_main, main_k, tail_k = solver.launch_plan(300, 30, P, force="valu")
         assert n_main == (16384 if P == 21000 else 4096) and ("one problem per wave" in tail_k or P == 21000)
-        W, _, _ = solver.fista_solve(Y, hrf, 1.0, step, 30)
+        W, _, _ = solver.fista_solve(Y, hrf, 1.0, step, 30, force="valu")
         s1 = W.abs().sum()
-        Wq, _, _ = solver.fista_solve(Y, hrf, 1.0, step, 30, force="seq")
+        Wq, _, _ = solver.fista_solve(Y, hrf, 1.0, step, 30, force="valuseq")
         assert float(((W - Wq).norm(dim=1) / Wq.norm(dim=1)).max()) < 1e-6 and float(s1) == float(W.abs().sum())
         idx = np.r_[0, 4095, 4096, P - 1, rng.choice(P, 6, replace=False)]
         Wo, _, _ = c_oracle.fista_batch(Y.cpu().numpy()[idx].astype(np.float64), hrf, 1.0, step, 30, threads=4)
@@ -469,16 +470,16 @@ def test_side_stream_remainder(solver, golden):
     # the one-stream plan: 24 576 on the pair kernel, 424 one per wave)
     for P in (25000, 41500):
         Y = torch.from_numpy(rng.randn(P, 300).astype(np.float32)).cuda()
-        n_main, main_k, tail_k = solver.launch_plan(300, 30, P)
+        n_main, main_k, tail_k = solver.launch_plan(300, 30, P, force="valu")
         assert n_main == (P // 8192) * 8192 and "two problems per row" in main_k and "one problem per wave" in tail_k
-        W, _, _ = solver.fista_solve(Y, hrf, 1.0, step, 30)
+        W, _, _ = solver.fista_solve(Y, hrf, 1.0, step, 30, force="valu")
         s1 = W.abs().sum()
-        Wq, _, _ = solver.fista_solve(Y, hrf, 1.0, step, 30, force="seq")
+        Wq, _, _ = solver.fista_solve(Y, hrf, 1.0, step, 30, force="valuseq")
         assert torch.equal(W, Wq) and float(s1) == float(Wq.abs().sum()), P
     # the cost trace through the concurrent group (every piece writes its own rows of J)
     Y = torch.from_numpy(rng.randn(12500, 300).astype(np.float32)).cuda()
-    W, J, _ = solver.fista_solve(Y, hrf, 1.0, step, 30, want_J=True)
-    Wq, Jq, _ = solver.fista_solve(Y, hrf, 1.0, step, 30, want_J=True, force="seq")
+    W, J, _ = solver.fista_solve(Y, hrf, 1.0, step, 30, want_J=True, force="valu")
+    Wq, Jq, _ = solver.fista_solve(Y, hrf, 1.0, step, 30, want_J=True, force="valuseq")
     assert bool(torch.isfinite(J).all())
     assert float(((W - Wq).norm(dim=1) / Wq.norm(dim=1)).max()) < 1e-6
     assert float(((J - Jq).abs() / Jq.abs()).max()) < 1e-5
@@ -491,8 +492,8 @@ def test_side_stream_remainder(solver, golden):
     Yv = torch.from_numpy(rng.randn(600, 300).astype(np.float32)).cuda()
     lam = np.tile(np.logspace(-2, 0, 20), 600)
     W0 = torch.from_numpy(0.01 * rng.randn(12000, 300)).cuda()
-    W, _, n_done = solver.fista_solve(Yv, hrf, lam, step, 30, W0=W0, y_rep=20)
-    Wq, _, _ = solver.fista_solve(Yv, hrf, lam, step, 30, W0=W0, y_rep=20, force="seq")
+    W, _, n_done = solver.fista_solve(Yv, hrf, lam, step, 30, W0=W0, y_rep=20, force="valu")
+    Wq, _, _ = solver.fista_solve(Yv, hrf, lam, step, 30, W0=W0, y_rep=20, force="valuseq")
     assert torch.equal(W, Wq) and int(n_done.min()) == 30
     idx = np.r_[0, 8191, 8192, 8193, 11999, rng.choice(12000, 8, replace=False)]
     Wo = np.stack([orc_fista_one(Yv[i // 20].cpu().numpy().astype(np.float64), hrf, lam[i], step, 30,
@@ -500,18 +501,18 @@ def test_side_stream_remainder(solver, golden):
     assert rel_rows(W.cpu().numpy()[idx], Wo) < 1e-5
     # back-to-back calls on a non-default stream, each result consumed in stream order
     Y = torch.from_numpy(rng.randn(10000, 300).astype(np.float32)).cuda()
-    ref, _, _ = solver.fista_solve(Y, hrf, 1.0, step, 25, force="seq")
+    ref, _, _ = solver.fista_solve(Y, hrf, 1.0, step, 25, force="valuseq")
     st = torch.cuda.Stream()
     torch.cuda.synchronize()
     sums = []
     with torch.cuda.stream(st):
         for _ in range(5):
-            W, _, _ = solver.fista_solve(Y, hrf, 1.0, step, 25)
+            W, _, _ = solver.fista_solve(Y, hrf, 1.0, step, 25, force="valu")
             sums.append((W - ref).abs().max())
     st.synchronize()
     assert all(float(s) == 0.0 for s in sums)
     # graph capture: no cross-stream work is captured, the replay equals the eager result
-    plan = solver.FistaPlan(Y, hrf, 1.0, step, 25, force=None)
+    plan = solver.FistaPlan(Y, hrf, 1.0, step, 25, force="valu")
     plan.run()
     torch.cuda.synchronize()
     eager = plan.W.clone()

@@ -160,7 +160,16 @@ def test_launch_plan_of_a_plain_solve():
               14000: (8192, pair, row), 14400: (0, None, pair), 16384: (0, None, pair), 25000: (24576, pair, wave),
               29000: (24576, pair, row), 50000: (49152, pair, wave), 100000: (98304, pair, wave)}
     for P, want in expect.items():
+        assert solver.launch_plan(300, 30, P, force="valu") == want, P
+    # with the matrix-pipe form (round 3; 129..320 scans, up to 33 taps): whole rounds of 16 384 problems
+    # and any remainder above half a round on it, a smaller remainder on the vector forms' plan
+    mm = solver.KERNEL_NAMES[4]
+    expect = {1: (0, None, wave), 4096: (0, None, row), 8192: (0, None, pair), 8193: (0, None, mm), 10000: (0, None, mm),
+              12500: (0, None, mm), 16384: (0, None, mm), 21000: (16384, mm, row), 25000: (0, None, mm),
+              50000: (49152, mm, wave), 100000: (98304, mm, wave)}
+    for P, want in expect.items():
         assert solver.launch_plan(300, 30, P) == want, P
+    assert solver.launch_plan(128, 16, 100000)[1] == pair and row in solver.launch_plan(300, 40, 100000)[1:]
     # the window rule at the reference's wind = 6 rides the pair form (no-fire certificate +
     # re-solve); the _loops_deconv rule does not; shapes outside the tables go to the LDS kernel
     assert solver.launch_plan(300, 30, 100000, stop="window") == (98304, pair, wave)
