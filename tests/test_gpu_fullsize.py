@@ -196,6 +196,25 @@ def test_config4_shared_hrf_full_size():
     assert abs(float(th[0]) - float(th2[0])) < 1e-9
     assert float(f[0]) == pytest.approx(float(solver.hrf_cost(Z, Y4, orc.spm_hrf(float(th[0]), t_r, dur, False)[0]).sum()),
                                         rel=1e-7)                       # quadratic form == direct cost
+    # the whole loop against the float64 oracle: 256 voxels of the batch solved alone, the dilation
+    # after each of the first 3 outer iterations (z-steps, normal equations, 1-D search)
+    from oracle.shared_ops import OracleOps
+
+    class _One:
+        world_size, rank = 1, 0
+
+        @staticmethod
+        def allreduce_(t):
+            return t
+    sub = torch.from_numpy(np.sort(np.random.RandomState(7).choice(V4, 256, replace=False))).cuda()
+    Ys = Y4[sub].contiguous()
+    Wg, hg, dg = distributed.bd_shared(Ys, t_r, lbda=1.7, theta_0=2.0, hrf_dur=dur, nb_iter=3, nb_inner=100)
+    Wo, ho, do = distributed.bd_shared(Ys.cpu(), t_r, lbda=1.7, theta_0=2.0, hrf_dur=dur, nb_iter=3, nb_inner=100,
+                                       ops=OracleOps(300, t_r, dur), comm=_One())
+    print("config 4, 256 voxels alone: theta GPU", np.round(dg["theta"], 8), "oracle", np.round(do["theta"], 8))
+    assert np.abs(np.asarray(dg["theta"]) - np.asarray(do["theta"])).max() < 1e-6
+    np.testing.assert_allclose(dg["J"], do["J"], rtol=1e-6)
+    assert float(((Wg.cpu() - Wo).norm(dim=1) / Wo.norm(dim=1)).max()) < 1e-5
     # first z-step (theta_0 = 2.0, from zero) of a 64-voxel sample against the oracle
     W0, h0, d0 = distributed.bd_shared(Y4, t_r, lbda=1.7, theta_0=2.0, hrf_dur=dur, nb_iter=0, nb_inner=100)
     h20 = orc.spm_hrf(2.0, t_r, dur, False)[0]
