@@ -578,7 +578,7 @@ int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mod
     if (P >= SPLIT_MIN_P && pair_carries(se, stop_mode, wind) && (stop_mode == PB_STOP_NONE || pick_wide(N, K)))
       return FORM_PAIR;
   const FastEntry* fe = pick_fast(N, K);
-  if (fe && stop_mode == PB_STOP_NONE && pick_mfma(N, K)) {
+  if (fe && pair_carries(fe, stop_mode, wind) && pick_mfma(N, K)) {   // plain solves and the window-rule certificate
     Piece pc[6];
     plan_pieces_mfma(P, fe->fn_pair != nullptr, pick_wide_small(N, K) != nullptr, false, false, pc);
     return pc[0].form;
@@ -606,7 +606,8 @@ int pb_fista_plan_ex(int N, int K, int P, int stop_mode, int wind, unsigned flag
   const FastEntry* se = (N >= 1 && K >= 1 && P >= SPLIT_MIN_P) ? pick_split(N, K) : nullptr;
   if (se && pair_carries(se, stop_mode, wind) && (stop_mode == PB_STOP_NONE || pick_wide(N, K))) {
     tf = FORM_PAIR;                                     // one launch of the split pair form
-  } else if (N >= 1 && K >= 1 && P >= 1 && stop_mode == PB_STOP_NONE && !no_mfma && pick_fast(N, K) && pick_mfma(N, K)) {
+  } else if (N >= 1 && K >= 1 && P >= 1 && !no_mfma && pick_fast(N, K) && pair_carries(pick_fast(N, K), stop_mode, wind) &&
+             pick_mfma(N, K)) {
     Piece pc[6];
     const int npc = plan_pieces_mfma(P, pick_fast(N, K)->fn_pair != nullptr, pick_wide_small(N, K) != nullptr,
                                      false, false, pc);
@@ -722,7 +723,12 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
   // Not with one lambda per problem, unless asked for (PB_FLAG_FORCE_MFMA): along a regularisation
   // path a third of the problems (lambda near lambda_max) fail that kernel's accuracy guard and
   // would be solved twice.
-  const mfma_launch_fn mfma = (fe && stop_mode == PB_STOP_NONE && n_done_dev && (!lbda_dev || (flags & PB_FLAG_FORCE_MFMA)) &&
+  // The window rule rides it as the same no-fire certificate as on the pair form (`cert` above).
+  // (its bound rests on four tracked samples per problem instead of sixteen: only where the rule is
+  // far from firing, tol * n_iter < 0.02; closer calls stay on the pair form)
+  const bool mfma_cert = cert && ((flags & PB_FLAG_FORCE_MFMA) || tol * (double)n_iter < 0.02);
+  const mfma_launch_fn mfma = (fe && (stop_mode == PB_STOP_NONE || mfma_cert) && n_done_dev &&
+                               (!lbda_dev || (flags & PB_FLAG_FORCE_MFMA)) &&
                                !(flags & (PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_DIRECT_FIR | PB_FLAG_NO_MFMA)))
                                   ? pick_mfma(N, K) : nullptr;
   if (fe) {

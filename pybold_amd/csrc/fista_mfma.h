@@ -35,6 +35,7 @@
 //
 // Reference: pybold/bold_signal.py:62-72, pybold/linear.py:73-113, pybold/convolution.py:105-132.
 #pragma once
+#include "../../include/pybold_hip.h"
 #include "common.h"
 #include "fista_fast.h"
 #ifndef PB_MFMA_CHECKS
@@ -121,8 +122,13 @@ __device__ __forceinline__ f4 mma3(const Frag& A, const Frag& B, f4 acc) {
 // A problem whose scaled operands came near the float16 range (checked every 8 iterations and at
 // the end; never seen on BOLD-like data: the margin is 2^8) is left untouched with n_done = -1
 // for the exact kernels (capi.hip re-solves it).
-template <int NB, bool WITH_J = false, bool TAPS_DEV = false>
+// CERT: the deconv window rule (wind = 6) as the per-iteration NO-FIRE CERTIFICATE of
+//   fista_pair_ffa.h: numerator bounded from below by ONE tracked sample per lane (four per problem,
+//   in four different blocks), denominator from above by ||w_k|| + 2 ||w_{k+1}|| + 4 th sqrt(N);
+//   a problem that cannot be cleared is handed back (n_done = -1) for the exact rule.  Implies WITH_J.
+template <int NB, bool WITH_J = false, bool TAPS_DEV = false, bool CERT = false>
 __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps tp) {
+  static_assert(!CERT || (WITH_J && !TAPS_DEV), "the certificate runs in the rotated (cost trace) loop");
   const int lane = threadIdx.x & 63;
   const int v = lane & 15, g = lane >> 4;
   const int wave = (int)((blockIdx.x * 256 + threadIdx.x) >> 6);
@@ -134,6 +140,13 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
   extern __shared__ __attribute__((aligned(16))) char mf_smem[];
   u4* lrf = reinterpret_cast<u4*>(mf_smem) + ((threadIdx.x >> 6) * NB * 2 * 64 + lane);
   float* lc = reinterpret_cast<float*>(mf_smem + (size_t)4 * NB * 2 * 64 * sizeof(u4)) + (threadIdx.x >> 6) * 64;
+  // CERT: per-lane words behind the taps (slot-major: conflict-free): [0..3] ring of the tracked
+  // sample's last four increments, [4,5] its u_{k-1} (float64 halves), [6] this lane's ||w_k||^2 part
+  float* lt = reinterpret_cast<float*>(mf_smem + (size_t)4 * NB * 2 * 64 * sizeof(u4)) + 4 * 64 + threadIdx.x;
+  if constexpr (CERT) {
+#pragma unroll
+    for (int q = 0; q < 7; ++q) lt[q * 256] = 0.0f;
+  }
   auto wave_sync = [] {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -228,6 +241,17 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
   // cost trace: 0.5 ||r''||^2 / (2^a sigma)^2 + lbda ||w'||_1 / sigma
   const float jq = 0.5f * (inv_sigma / y_scale) * (inv_sigma / y_scale), jl = (float)lb * inv_sigma;
   float jsq = 0.0f, jl1 = 0.0f;
+  // CERT: tracked sample = sample 3 of block CQ[g] (one block per lane group, spread over the series)
+  constexpr int CQ0 = NB / 8, CQ1 = (3 * NB) / 8, CQ2 = (5 * NB) / 8, CQ3 = (7 * NB) / 8;
+  static_assert(!CERT || (CQ0 < CQ1 && CQ1 < CQ2 && CQ2 < CQ3), "four distinct blocks");
+  double cu = 0.0, cw = 0.0;                     // u_k and w_{k+1} of the tracked sample
+  float jw2 = 0.0f, cvsq = 0.0f;                 // this lane's ||w||^2 part, its v^2
+  bool cflag = false;
+  int cert_it = -1;
+  constexpr float CP1 = 0.3133f, CP2 = 0.6467f, CP3 = 0.04f;
+  const float cert_t2 = ((float)a.tol * 1.001f) * ((float)a.tol * 1.001f);
+  const float cert_c0 = (float)th * (4.0f * 1.0001f) * __builtin_sqrtf(32.0f * NB) + 3.1e-10f * sigma;
+  const float cert_lim = cert_t2 * cert_c0 * cert_c0 * (1.0001f / CP3);
 
   // Register placement: the operator tiles are read by matrix instructions only and -y'' once per
   // iteration: they live in the accumulator half of the register file (the asm constraints put
@@ -266,12 +290,14 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
     unsigned ph[NB + 1][4], pl[NB + 1][4];
     unsigned rh[NB][4], rl[NB][4];
     if constexpr (WITH_J) { jsq = 0.0f; jl1 = 0.0f; }
+    if constexpr (CERT) jw2 = 0.0f;
     auto prep_pair = [&](auto qc, auto pc) {      // samples 2p, 2p+1 of block q -> float16 hi / lo
       constexpr int q = decltype(qc)::value, pp = decltype(pc)::value;
       float x0, x1;                               // (asm: the conversion stays HERE, not behind the update)
       asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(x0) : "v"(w[q][2 * pp]));
       asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(x1) : "v"(w[q][2 * pp + 1]));
       if constexpr (WITH_J) jl1 += fabsf(x0) + fabsf(x1);
+      if constexpr (CERT) jw2 = fmaf(x1, x1, fmaf(x0, x0, jw2));
       const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
       float l0, l1;
       asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(h2), "v"(x0));
@@ -356,6 +382,11 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
       const double u = fma(nstep, gj, w[q][j]);
       const double d = fmin(fmax(u, -th), th);
       w[q][j] = fma(nb1, d, u);
+      if constexpr (CERT && j == 3 && (q == CQ0 || q == CQ1 || q == CQ2 || q == CQ3)) {
+        constexpr int gq = q == CQ0 ? 0 : (q == CQ1 ? 1 : (q == CQ2 ? 2 : 3));
+        cu = (g == gq) ? u : cu;
+        cw = (g == gq) ? w[q][j] : cw;
+      }
     };
     fetch(std::integral_constant<int, NB - 1>{});
     static_for<0, NB>([&](auto qq) {
@@ -379,6 +410,22 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
       carry = cn;
     });
     static_for<0, 8>([&](auto jc) { update(std::integral_constant<int, 0>{}, jc); });
+    if constexpr (CERT) {
+      // the window combination on this lane's tracked sample (see fista_pair_ffa.h): float32 from
+      // float64 differences; its rounding, and that of the stored increments, is below 2^-21 M
+      const float d1 = lt[((cert_it + 3) & 3) * 256], d2 = lt[((cert_it + 2) & 3) * 256], d3 = lt[((cert_it + 1) & 3) * 256];
+      const unsigned ulo = __builtin_bit_cast(unsigned, lt[4 * 256]), uhi = __builtin_bit_cast(unsigned, lt[5 * 256]);
+      const double up = __builtin_bit_cast(double, ((unsigned long long)uhi << 32) | ulo);
+      const float dk = (float)(cu - up), e = (float)(cw - cu);
+      const float v = fmaf(2.0f, d2, fmaf(3.0f, d1, fmaf(2.0f, dk, e))) + d3;
+      const float m = fmaf(2.0f, fabsf(d2), fmaf(3.0f, fabsf(d1), fmaf(2.0f, fabsf(dk), fabsf(e)))) + fabsf(d3);
+      const float vs = fmaxf(fmaf(-0x1p-21f, m, fabsf(v)), 0.0f);
+      cvsq = vs * vs;
+      lt[(cert_it & 3) * 256] = dk;
+      const unsigned long long ub = __builtin_bit_cast(unsigned long long, cu);
+      lt[4 * 256] = __builtin_bit_cast(float, (unsigned)ub);
+      lt[5 * 256] = __builtin_bit_cast(float, (unsigned)(ub >> 32));
+    }
   };
   // Range guard, every 8th iteration and after the last one: the largest |sigma w| (registers) and
   // the largest exponent among the hi halves of the residual fragments (LDS copy) -- a small block
@@ -414,8 +461,10 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
     }
   } else {
     forward();
+    if constexpr (CERT) lt[6 * 256] = jw2;       // ||w_0||^2 part
     for (int it = 0; it < a.n_iter; ++it) {
       const double beta = a.betas[it];
+      cert_it = it;
       backward(beta);
       forward();
       float sq = jsq, l1 = jl1;                   // this lane's 8 NB samples -> the problem's 32 NB
@@ -423,7 +472,16 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
       l1 += __shfl_xor(l1, 16, 64);
       sq += __shfl_xor(sq, 32, 64);
       l1 += __shfl_xor(l1, 32, 64);
-      if (live && g == 0) a.J[(int64_t)p * a.ldj + it] = fmaf(jq, sq, jl * l1);
+      if (live && g == 0 && (!CERT || (a.J != nullptr && !cflag))) a.J[(int64_t)p * a.ldj + it] = fmaf(jq, sq, jl * l1);
+      if constexpr (CERT) {
+        // close the certificate of iteration `it` (the rule is first tested at wind + 1 = 7):
+        // sum over the problem's four lanes of v^2 - tol^2 (||w_k||^2 / p1 + 4 ||w_{k+1}||^2 / p2)
+        float t = cvsq - cert_t2 * ((1.0001f / CP1) * lt[6 * 256] + (4.0001f / CP2) * jw2);
+        t += __shfl_xor(t, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        cflag = cflag | ((it >= 7) & !(t >= cert_lim));      // NaN-safe: anything unclear is flagged
+        lt[6 * 256] = jw2;
+      }
       if (PB_MFMA_CHECKS && (((it & 7) == 7) || (it == a.n_iter - 1))) range_check();
     }
   }
@@ -440,7 +498,7 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
   // Problems above MFMA_RHO_MAX (sparse solutions, lambda near lambda_max) go back to the float32
   // operators like those that left the float16 range.
   const bool bad = !(guard < 60000.0f) ||        // NaN-safe (float16: 65504)
-                   (wlast > 0.0f && (float)th > MFMA_RHO_MAX * wlast);
+                   (wlast > 0.0f && (float)th > MFMA_RHO_MAX * wlast) || (CERT && cflag);
   if (live && !bad) {
     double* wrow = a.w + (int64_t)p * a.ldw;
 #pragma unroll
@@ -460,14 +518,18 @@ int launch_mfma(const FistaArgs& a, const double* taps, int K, bool with_j, hipS
   if (a.N > 32 * NB || a.N <= 32 * (NB - 1) || K > 33 || K < 1) return 1;
   const int64_t waves = ((int64_t)(a.P - a.p0) + 15) / 16;
   const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-  const size_t lds = (size_t)4 * NB * 2 * 64 * sizeof(u4) + 4 * 64 * sizeof(float);   // residual fragments (8 KB per block of 32 samples), taps
+  const bool cert = a.stop_mode == PB_STOP_WINDOW;
+  if (cert && (!a.n_done || a.taps_pp)) return 1;
+  const size_t lds = (size_t)4 * NB * 2 * 64 * sizeof(u4) + 4 * 64 * sizeof(float) +    // residual fragments (8 KB per block of 32 samples), taps
+                     (cert ? 7 * 256 * sizeof(float) : 0);                                // certificate state
   if (a.taps_pp) {                              // shared HRF and step in device memory; no cost trace
     const MfmaTaps none{};
     hipLaunchKernelGGL((fista_mfma_kernel<NB, false, true>), grid, block, lds, st, a, none);
     return 0;
   }
   const MfmaTaps tp = make_mfma_taps(taps, K);
-  if (with_j) hipLaunchKernelGGL((fista_mfma_kernel<NB, true, false>), grid, block, lds, st, a, tp);
+  if (cert) hipLaunchKernelGGL((fista_mfma_kernel<NB, true, false, true>), grid, block, lds, st, a, tp);
+  else if (with_j) hipLaunchKernelGGL((fista_mfma_kernel<NB, true, false>), grid, block, lds, st, a, tp);
   else hipLaunchKernelGGL((fista_mfma_kernel<NB, false, false>), grid, block, lds, st, a, tp);
   return 0;
 }

@@ -35,7 +35,9 @@ _FORCE = {None: 0, "generic": PB_FLAG_FORCE_GENERIC, "fast": PB_FLAG_FORCE_FAST,
           "valu": _lib.PB_FLAG_NO_MFMA, "valuseq": _lib.PB_FLAG_NO_MFMA | PB_FLAG_ONE_STREAM,
           "mfma": PB_FLAG_ONE_LAUNCH | _lib.PB_FLAG_FORCE_MFMA,
           # diagnostic: no re-solve of the problems a guard handed back (they keep n_done = -1)
-          "mfmaonly": PB_FLAG_ONE_LAUNCH | _lib.PB_FLAG_FORCE_MFMA | _lib.PB_FLAG_CERT_NO_RESOLVE}
+          "mfmaonly": PB_FLAG_ONE_LAUNCH | _lib.PB_FLAG_FORCE_MFMA | _lib.PB_FLAG_CERT_NO_RESOLVE,
+          "mfmacert": PB_FLAG_ONE_LAUNCH | _lib.PB_FLAG_FORCE_MFMA | PB_FLAG_FORCE_CERT,
+          "mfmacertonly": PB_FLAG_ONE_LAUNCH | _lib.PB_FLAG_FORCE_MFMA | PB_FLAG_FORCE_CERT | _lib.PB_FLAG_CERT_NO_RESOLVE}
 
 
 _warned = set()

@@ -57,7 +57,7 @@ def test_version_and_dispatch_table(lib):
     # single-row kernel for small ones and for the _loops_deconv rule
     assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 0, 6) == 4      # plain solves: both operators on the matrix pipe (round 3)
     assert lib.pb_fista_which_kernel(300, 30, 100000, 1, 0, 6) == 4      # cost trace: matrix-pipe form too
-    assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 2, 6) == 2      # window rule: certificate on the pair form
+    assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 2, 6) == 4      # window rule at wind = 6: no-fire certificate on the matrix-pipe form
     assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 1, 6) == 1      # _loops_deconv rule: single-row form
     assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 2, 4) == 1      # wind 4 / 8: full rule, single-row form
     assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 2, 8) == 1
@@ -69,7 +69,8 @@ def test_version_and_dispatch_table(lib):
     assert lib.pb_fista_which_kernel(300, 30, 8000, 0, 0, 6) == 2        # under half a round: the vector forms
     assert lib.pb_fista_which_kernel(240, 27, 50000, 0, 0, 6) == 4       # 129..320 scans, up to 33 taps
     assert lib.pb_fista_which_kernel(128, 16, 50000, 0, 0, 6) == 2       # shorter series: pair form
-    assert lib.pb_fista_which_kernel(300, 30, 8192, 1, 2, 6) == 2        # the deconv default call: pair form
+    assert lib.pb_fista_which_kernel(300, 30, 8192, 1, 2, 6) == 2        # the deconv default call, half a round: pair form
+    assert lib.pb_fista_which_kernel(300, 30, 50000, 1, 2, 6) == 4       # ... whole rounds: matrix-pipe form
     assert lib.pb_fista_which_kernel(300, 30, 8192, 1, 1, 6) == 1        # _loops_deconv rule: single-row kernel
     assert lib.pb_fista_which_kernel(300, 30, 3, 1, 2, 6) == 3           # ... or one problem per wave
     assert lib.pb_fista_which_kernel(600, 30, 100000, 0, 0, 6) == 2      # 600 scans: the halves of a series in the two slots of a row

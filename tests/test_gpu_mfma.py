@@ -161,3 +161,51 @@ def test_shared_hrf_z_step_on_the_matrix_pipe(solver):
     assert rel_rows(W.cpu().numpy()[idx], Wo) < EPS
     Wv, _ = solver.fista_solve_pp(Y, taps, stepc, 1.7, 60, force="valu")
     assert float(((W - Wv).norm(dim=1) / Wv.norm(dim=1)).max()) < 2e-6
+
+
+def test_window_rule_certificate_on_the_matrix_pipe(solver, golden):
+    """The reference-default deconv call (window rule, wind = 6, cost trace) on the matrix-pipe form:
+    (a) default tolerance, nothing fires: n_done = n_iter, iterate and trace equal the plain solve of
+    the same kernel form bit for bit; the golden default run (1000 iterations) is reproduced;
+    (b) a tolerance at which about half of the series stop early: stop iterations and iterates of the
+    float64 oracle (the uncleared problems are re-solved with the full rule);
+    (c) the certificate clears a realistic batch at the default tol = 1e-6 and all but a few problems at 2e-5."""
+    from pybold_amd import data
+    g = golden("early_stop")
+    hrf, lip = g["hrf"], float(g["lipschitz"])
+    assert "matrix pipe" in solver.which_kernel(300, 30, 40000, want_J=True, stop="window", wind=6)
+    Y, _, _ = data.gen_rnd_bloc_bold_batch(16384 + 700, dur=5.0, tr=1.0, hrf=hrf, nb_events=5, avg_dur=12.0, std_dur=1.0,
+                                           snr=1.0, seed=31)
+    W, J, nd = solver.fista_solve(Y, hrf, 1.0, 1.0 / lip, 200, want_J=True, stop="window", tol=1e-6, wind=6)
+    Wp, Jp, _ = solver.fista_solve(Y, hrf, 1.0, 1.0 / lip, 200, want_J=True)
+    assert int(nd.min()) == 200 and torch.equal(W[:16384], Wp[:16384]) and torch.equal(J[:16384], Jp[:16384])
+    Wg, _, ndg = solver.fista_solve(dev32(np.stack([g["y"]] * 20)), hrf, 1.0, 1.0 / lip, 1000, want_J=True,
+                                    stop="window", tol=1e-6, wind=6, force="mfma")
+    assert (ndg.cpu().numpy() == int(g["n_default"])).all()
+    assert rel_rows(Wg.cpu().numpy(), np.stack([g["dz_default"]] * 20)) < EPS
+    # (b)
+    Ys = Y[:43].clone()
+    Ys[20] = torch.from_numpy(g["y"]).float().cuda()
+    Yh = Ys.cpu().numpy().astype(np.float64)
+    tol = 0.01
+    n_fire = np.array([orc.deconv_fixed_lbda(Yh[v], hrf, 1.0, nb_iter=400, tol=tol, lipschitz=lip, dense=False)[4]
+                       for v in range(43)])
+    n_iter = int(np.median(n_fire))
+    out = [orc.deconv_fixed_lbda(Yh[v], hrf, 1.0, nb_iter=n_iter, tol=tol, lipschitz=lip, dense=False) for v in range(43)]
+    Wr, nr = np.stack([o[2] for o in out]), np.array([o[4] for o in out])
+    assert n_fire[20] == 191 and 10 <= (n_fire < n_iter).sum() <= 33
+    Wm, Jm, ndm = solver.fista_solve(Ys, hrf, 1.0, 1.0 / lip, n_iter, want_J=True, stop="window", tol=tol, wind=6,
+                                     force="mfmacert")
+    assert (ndm.cpu().numpy() == nr).all()
+    assert rel_rows(Wm.cpu().numpy(), Wr) < EPS
+    Jn = Jm.cpu().numpy()
+    for v in range(43):
+        assert np.isfinite(Jn[v, :nr[v]]).all() and np.isnan(Jn[v, nr[v]:]).all(), v
+    # (c) four tracked samples per problem: the bound clears a realistic batch up to tol ~ 2e-5 at 1000
+    # iterations (the library keeps closer calls, tol * n_iter >= 0.02, on the pair form's sixteen)
+    _, _, ndc = solver.fista_solve(Y[:2048], hrf, 1.0, 1.0 / lip, 1000, want_J=True, stop="window", tol=2e-5, wind=6,
+                                   force="mfmacertonly")
+    assert int((ndc < 0).sum()) <= 40                    # a few unlucky samples at most (2 %): re-solved
+    _, _, ndc = solver.fista_solve(Y[:2048], hrf, 1.0, 1.0 / lip, 1000, want_J=True, stop="window", tol=1e-6, wind=6,
+                                   force="mfmacertonly")
+    assert int((ndc < 0).sum()) == 0                     # the reference default: nothing handed back

@@ -120,10 +120,12 @@ def test_default_tolerance_runs_on_the_pair_form(solver, golden):
     rounds on the pair form, a remainder on other forms)."""
     g = golden("early_stop")
     hrf, lip = g["hrf"], float(g["lipschitz"])
-    assert "two problems per row" in solver.which_kernel(300, 30, 20000, stop="window", wind=6)
+    assert "matrix pipe" in solver.which_kernel(300, 30, 20000, stop="window", wind=6)
     Y, _ = synthetic(20000, seed=2)
     n_iter = 300
-    W, J, nd = solver.fista_solve(Y, hrf, 1.0, 1.0 / lip, n_iter, want_J=True, stop="window", tol=1e-6, wind=6)
+    # (force="valu": the vector forms -- whole rounds on the pair form with the certificate; the
+    # matrix-pipe form carries the same certificate: tests/test_gpu_mfma.py)
+    W, J, nd = solver.fista_solve(Y, hrf, 1.0, 1.0 / lip, n_iter, want_J=True, stop="window", tol=1e-6, wind=6, force="valu")
     assert int(nd.min()) == n_iter and int(nd.max()) == n_iter
     Wp, Jp, _ = solver.fista_solve(Y, hrf, 1.0, 1.0 / lip, n_iter, want_J=True, force="valu")   # same kernel form
     assert torch.equal(W, Wp) and torch.equal(J, Jp)
@@ -134,7 +136,7 @@ def test_default_tolerance_runs_on_the_pair_form(solver, golden):
     assert rel_rows(W[:4096].cpu().numpy(), Wn.cpu().numpy()) < 1e-6
     # the golden default run (1000 iterations, the rule never fires): pinned to the reference
     Wg, _, ndg = solver.fista_solve(dev32(np.stack([g["y"]] * 4)), hrf, 1.0, 1.0 / lip, 1000, want_J=True,
-                                    stop="window", tol=1e-6, wind=6)
+                                    stop="window", tol=1e-6, wind=6, force="valu")
     assert (ndg.cpu().numpy() == int(g["n_default"])).all()
     assert rel_rows(Wg.cpu().numpy(), np.stack([g["dz_default"]] * 4)) < EPS
 
