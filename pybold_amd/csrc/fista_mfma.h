@@ -41,8 +41,18 @@
 #ifndef PB_MFMA_CHECKS
 #define PB_MFMA_CHECKS 1
 #endif
+// Development switches (A/B builds, tools/r3_mfma_ab.py).  PB_MFMA_SB: a scheduling barrier behind
+// every PB_MFMA_SBK-th slot of the hand-pipelined loops.  Measured for 98 304 problems x 500
+// iterations: barrier per slot 10.85 ms, per block 10.54 ms, none 10.47 ms (the source order is
+// kept well enough by data dependences; the scheduler fills the wait states itself): none.
+#ifndef PB_MFMA_SBK
+#define PB_MFMA_SBK 15
+#endif
 #ifndef PB_MFMA_SB
-#define PB_MFMA_SB __builtin_amdgcn_sched_barrier(0)
+#define PB_MFMA_SB
+#endif
+#ifndef PB_MFMA_CHECKS
+#define PB_MFMA_CHECKS 1
 #endif
 
 namespace pb {
@@ -270,7 +280,7 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
 
   // The iteration is straight-line.  The matrix pipe takes one instruction per 16 cycles and holds
   // the vector issue port for 8 of them, so the source is software-pipelined BY HAND at that grain
-  // (sched_barrier after every slot keeps the order): every matrix instruction of block q is
+  // (data dependences keep the order; PB_MFMA_SB can pin it): every matrix instruction of block q is
   // followed by a slice of the vector work of its neighbours -- the float16 fragments of block
   // q+1, the residual (or the update) of the block before.
   auto mfma_part = [](const Frag& A, const Frag& B, f4 acc, int part) __attribute__((always_inline)) -> f4 {
@@ -359,7 +369,7 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
         } else if constexpr (sl == 10 || sl == 11) {
           if constexpr (q + 1 < NB) cinit(std::integral_constant<int, q + 1>{}, std::integral_constant<int, sl - 10>{}, cn);
         }
-        PB_MFMA_SB;
+        if constexpr ((sl % PB_MFMA_SBK) == PB_MFMA_SBK - 1) PB_MFMA_SB;
       });
       carry = cn;
     });
@@ -405,7 +415,7 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
         }
         if constexpr ((sl & 1) == 0 && q + 1 < NB)
           update(std::integral_constant<int, q + 1>{}, std::integral_constant<int, sl / 2>{});
-        PB_MFMA_SB;
+        if constexpr ((sl % PB_MFMA_SBK) == PB_MFMA_SBK - 1) PB_MFMA_SB;
       });
       carry = cn;
     });
