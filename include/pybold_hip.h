@@ -58,6 +58,10 @@ extern "C" {
                                      the no-fire certificate of the pair form + re-solve (see pb_fista_solve) */
 #define PB_FLAG_CERT_NO_RESOLVE 2048u /* diagnostic: certificate launch only; uncleared problems keep n_done = -1 */
 #define PB_FLAG_FORCE_MFMA 16384u  /* the matrix-pipe form also with per-problem lambdas (see pb_fista_solve) */
+#define PB_FLAG_NO_RHO_GUARD 32768u /* matrix-pipe form: keep sparse solutions (threshold / max|w| > 0.02) instead of handing them
+                                     back to the float32 operators.  For INTERMEDIATE solves of an outer loop (the z-steps
+                                     of the blind loop but the last): their errors, relative 1e-5..1e-4 of a still tiny
+                                     iterate, are forgotten by the warm-started solves that follow */
 #define PB_FLAG_NO_MFMA 8192u      /* plain solves: never the matrix-pipe form (fista_mfma_kernel), vector forms only */
 #define PB_FLAG_FORCE_CERT 1024u   /* PB_STOP_WINDOW, wind = 6: certificate path whatever tol * n_iter is */
 #define PB_FLAG_ONE_LAUNCH 32u    /* never split a plain solve into a full-rounds launch and a

@@ -680,6 +680,7 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
   a.y_rep = y_rep; a.P = P; a.N = N; a.n_iter = n_iter; a.stop_mode = stop_mode;
   a.taps_pp = nullptr; a.ldt = 0; a.step_vec = nullptr; a.step_shared = 0; a.K = K; a.p0 = 0;
   a.cold = (flags & PB_FLAG_COLD_START) ? 1 : 0;
+  a.rho_guard = (flags & PB_FLAG_NO_RHO_GUARD) ? 0 : 1;
   a.wind = wind;
   if (const char* yb = getenv("PB_MFMA_YBITS")) a.ybits = atoi(yb);     // development aid
 
@@ -904,6 +905,7 @@ int pb_fista_solve_d(const double* y_dev, int64_t ldy, int y_rep, double* w_dev,
   a.y_rep = y_rep; a.P = P; a.N = N; a.n_iter = n_iter; a.stop_mode = stop_mode;
   a.taps_pp = nullptr; a.ldt = 0; a.step_vec = nullptr; a.step_shared = 0; a.K = K; a.p0 = 0;
   a.cold = (flags & PB_FLAG_COLD_START) ? 1 : 0;
+  a.rho_guard = (flags & PB_FLAG_NO_RHO_GUARD) ? 0 : 1;
   if (ee) {
     if (ee->fn(a, taps_host, K, J_dev != nullptr, stop_mode, (hipStream_t)stream) != 0)
       return fail(PB_ERR_INVALID, "pb_fista_solve_d: launch rejected");
@@ -1179,6 +1181,7 @@ int pb_fista_solve_pp(const float* y_dev, int64_t ldy, double* w_dev, int64_t ld
   a.taps_pp = taps_dev; a.ldt = ldt; a.step_vec = step_dev; a.step_shared = (ldt == 0); a.K = K;
   a.p0 = 0;
   a.cold = (flags & PB_FLAG_COLD_START) ? 1 : 0;
+  a.rho_guard = (flags & PB_FLAG_NO_RHO_GUARD) ? 0 : 1;
 
   const FastEntry* fe = (flags & PB_FLAG_FORCE_GENERIC) ? nullptr : pick_fast(N, K);
   if (fe) {
@@ -1227,7 +1230,7 @@ int pb_fista_solve_pp(const float* y_dev, int64_t ldy, double* w_dev, int64_t ld
         const int rc = run(pl.tail_form, base + pl.n_main, P);
         if (rc != PB_OK) return rc;
       }
-      if (base > 0) {                              // problems the matrix-pipe form handed back (n_done = -1)
+      if (base > 0 && !(flags & PB_FLAG_CERT_NO_RESOLVE)) {   // problems the matrix-pipe form handed back (n_done = -1)
         pb::FistaArgs b = a;
         b.P = base;
         b.only_flagged = 1;

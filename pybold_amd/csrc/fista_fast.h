@@ -63,6 +63,7 @@ struct FistaArgs {
   int cold;               // 1: the iterate starts from 0, a.w is written only
   int wind = 6;           // window rule: stored iterates (register-resident forms: 4, 6 or 8)
   int ybits = 14;         // matrix-pipe form: every series is scaled so that max |y| lies in [2^(ybits-1), 2^ybits)
+  int rho_guard = 1;      // matrix-pipe form: hand sparse solutions (th / max|w| > MFMA_RHO_MAX) back to the vector forms
   int only_flagged = 0;   // 1: solve only the problems with n_done[p] < 0 (left by the certificate
                           //    form of the pair kernel, fista_pair_ffa.h), skip the others
 };

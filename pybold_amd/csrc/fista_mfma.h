@@ -129,9 +129,11 @@ __device__ __forceinline__ f4 mma3(const Frag& A, const Frag& B, f4 acc) {
 //   from the residual of the NEXT forward pass (the loop is rotated: one forward pass in front).
 // TAPS_DEV: the HRF and the step are read from device memory (a.taps_pp: K float64 shared by every
 //   problem, a.step_vec[0]): the shared-HRF blind step, whose taps never pass through the host.
-// A problem whose scaled operands came near the float16 range (checked every 8 iterations and at
-// the end; never seen on BOLD-like data: the margin is 2^8) is left untouched with n_done = -1
-// for the exact kernels (capi.hip re-solves it).
+// Scales: taps 2^a (max |c| in [4, 8)), series 2^a sigma with max |2^a sigma y| in [2^13, 2^14), so
+// that the residual fragments 2^a sigma (x - y) -- what float16 has to hold -- have a margin of
+// 2-4x the largest sample.  A problem whose residual hi parts reached 2^15 or whose |sigma w|
+// reached 60000 (checked every 8 iterations and at the end) is left untouched with n_done = -1
+// for the exact kernels (capi.hip re-solves it); between checks the conversions saturate.
 // CERT: the deconv window rule (wind = 6) as the per-iteration NO-FIRE CERTIFICATE of
 //   fista_pair_ffa.h: numerator bounded from below by ONE tracked sample per lane (four per problem,
 //   in four different blocks), denominator from above by ||w_k|| + 2 ||w_{k+1}|| + 4 th sqrt(N);
@@ -230,8 +232,10 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
     if (m > 0.0f && m < 3.0e38f) {
       int e;
       (void)frexpf(m, &e);                       // m = f 2^e, f in [0.5, 1)
-      sigma = ldexpf(1.0f, a.ybits - e);
-      inv_sigma = ldexpf(1.0f, e - a.ybits);
+      // max |2^a sigma y| in [2^(ybits-1), 2^ybits): the residual fragments 2^a sigma (x - y) are
+      // what float16 has to hold (hi part below 2^15), so the tap scale 2^a belongs in sigma
+      sigma = ldexpf(1.0f, a.ybits - e) / y_scale;
+      inv_sigma = ldexpf(1.0f, e - a.ybits) * y_scale;
     }
     const float ys = -sigma * y_scale;
     const double* wrow = a.w + (int64_t)p * a.ldw;
@@ -508,7 +512,7 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
   // Problems above MFMA_RHO_MAX (sparse solutions, lambda near lambda_max) go back to the float32
   // operators like those that left the float16 range.
   const bool bad = !(guard < 60000.0f) ||        // NaN-safe (float16: 65504)
-                   (wlast > 0.0f && (float)th > MFMA_RHO_MAX * wlast) || (CERT && cflag);
+                   (a.rho_guard && wlast > 0.0f && (float)th > MFMA_RHO_MAX * wlast) || (CERT && cflag);
   if (live && !bad) {
     double* wrow = a.w + (int64_t)p * a.ldw;
 #pragma unroll

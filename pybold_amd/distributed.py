@@ -126,10 +126,14 @@ class HipOps:
     def hrf(self, theta):                       # (1,) -> (K,)
         return self.s.spm_hrf_batch(theta, self.t_r, self.hrf_dur)[0]
 
-    def z_step(self, Y, taps, lbda, nb_inner, W, step=None):
+    def z_step(self, Y, taps, lbda, nb_inner, W, step=None, last=True):
+        """``last=False``: an intermediate z-step of the outer loop -- the matrix-pipe kernel keeps its
+        result also where the iterate is still tiny against the threshold (its accuracy guard would
+        send those voxels to the vector kernels; the next, warm-started z-step forgets such errors)."""
         if step is None:
             step = 1.0 / self.s.gram_frobenius_batch(taps.reshape(1, -1), self.n)    # (1,)
-        W, _ = self.s.fista_solve_pp(Y, taps, step, lbda, nb_inner, W0=W, inplace=True)
+        W, _ = self.s.fista_solve_pp(Y, taps, step, lbda, nb_inner, W0=W, inplace=True,
+                                     force=None if last else "intermediate")
         return W
 
     def normal_eq(self, W, Y, K):
@@ -190,7 +194,7 @@ def bd_shared(Y, t_r, lbda=1.0, theta_0=None, hrf_dur=20.0, bounds=None, nb_iter
     fused = bool(getattr(ops, "fused", False))
     step = None                                  # fused: 1 / ||A^T A||_F comes out of the theta step
     for it in range(nb_iter + 1):
-        W = ops.z_step(Y, taps, lbda, nb_inner, W, step) if fused else ops.z_step(Y, taps, lbda, nb_inner, W)
+        W = ops.z_step(Y, taps, lbda, nb_inner, W, step, last=(it == nb_iter)) if fused else ops.z_step(Y, taps, lbda, nb_inner, W)
         if fused:
             ops.normal_eq_msg(W, Y, K, msg)      # cumulative sum and ||w||_1 inside the one pass
         else:

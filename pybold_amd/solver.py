@@ -34,6 +34,9 @@ _FORCE = {None: 0, "generic": PB_FLAG_FORCE_GENERIC, "fast": PB_FLAG_FORCE_FAST,
           # "valu": library dispatch without the matrix-pipe form; "mfma": everything on it, one launch
           "valu": _lib.PB_FLAG_NO_MFMA, "valuseq": _lib.PB_FLAG_NO_MFMA | PB_FLAG_ONE_STREAM,
           "mfma": PB_FLAG_ONE_LAUNCH | _lib.PB_FLAG_FORCE_MFMA,
+          # intermediate solve of an outer loop: the matrix-pipe form keeps sparse iterates (no accuracy guard)
+          "intermediate": _lib.PB_FLAG_NO_RHO_GUARD,
+          "intermediate_noresolve": _lib.PB_FLAG_NO_RHO_GUARD | _lib.PB_FLAG_CERT_NO_RESOLVE,   # measurement aid
           # diagnostic: no re-solve of the problems a guard handed back (they keep n_done = -1)
           "mfmaonly": PB_FLAG_ONE_LAUNCH | _lib.PB_FLAG_FORCE_MFMA | _lib.PB_FLAG_CERT_NO_RESOLVE,
           "mfmacert": PB_FLAG_ONE_LAUNCH | _lib.PB_FLAG_FORCE_MFMA | PB_FLAG_FORCE_CERT,

@@ -163,6 +163,31 @@ def test_shared_hrf_z_step_on_the_matrix_pipe(solver):
     assert float(((W - Wv).norm(dim=1) / Wv.norm(dim=1)).max()) < 2e-6
 
 
+@pytest.mark.parametrize("theta", [0.5, 0.7, 1.08, 1.3, 2.0])
+def test_tap_scale_does_not_eat_the_float16_range(solver, theta):
+    """HRFs of different gain (dilations 0.5 .. 2.0 of the reference's model: max |cumsum h| from 2.5
+    down to 0.63, tap scales 2^1 .. 2^3): the series' scale accounts for the tap scale, so ordinary
+    data fitted with a WRONG HRF (the first z-steps of the blind loop: residuals as large as the
+    series) stays on the matrix-pipe form -- nothing handed back -- for the plain solve and for the
+    shared-HRF z-step, both equal to the oracle."""
+    from pybold_amd import data
+    t_r, dur, n = 0.75, 20.0, 300
+    h_true = orc.spm_hrf(0.7, t_r, dur, False)[0]
+    h = orc.spm_hrf(theta, t_r, dur, False)[0]
+    lip = orc.gram_lipschitz(h, n)
+    Y, _, _ = data.gen_rnd_bloc_bold_batch(16384 + 48, dur=n * t_r / 60.0, tr=t_r, hrf=h_true, nb_events=5, avg_dur=12.0,
+                                           std_dur=1.0, snr=10.0, seed=41)
+    _, _, nd = solver.fista_solve(Y, h, 1.7, 1.0 / lip, 100, force="mfmaonly")
+    assert int((nd < 0).sum()) == 0
+    taps, stepc = dev64(h), dev64(np.array([1.0 / lip]))
+    W, nd = solver.fista_solve_pp(Y, taps, stepc, 1.7, 100, force="intermediate_noresolve")
+    assert int((nd < 0).sum()) == 0 and int(nd.min()) == 100
+    rng = np.random.RandomState(2)
+    idx = np.r_[0, 16383, 16384, 16431, rng.choice(16384, 12, replace=False)]
+    Wo = orc.fista_batch(Y.cpu().numpy()[idx].astype(np.float64), h, 1.7, 1.0 / lip, 100)
+    assert rel_rows(W.cpu().numpy()[idx], Wo) < EPS
+
+
 def test_window_rule_certificate_on_the_matrix_pipe(solver, golden):
     """The reference-default deconv call (window rule, wind = 6, cost trace) on the matrix-pipe form:
     (a) default tolerance, nothing fires: n_done = n_iter, iterate and trace equal the plain solve of
