@@ -314,6 +314,255 @@ __global__ __launch_bounds__(NE_THREADS) void normal_eq_sum_kernel(const double*
   }
 }
 
+// The same sums with ONE WAVE PER VOXEL (K <= 32): normal_eq_sum_kernel stages one voxel per
+// workgroup behind three workgroup barriers for ~64 multiply-adds per thread -- barrier latency,
+// not arithmetic, LDS or HBM, set its 0.39 ms per 100 k voxels (5x the time of its HBM traffic).
+// Here every wave owns a voxel from staging to the last product: no workgroup barrier inside the
+// voxel loop, next voxel's loads in flight during the sums, two waves per SIMD (190-240 registers)
+// hiding each other's LDS latency: 0.25 ms per 100 k voxels (profiles/r3_config4_kernel_stats.csv).  Roles inside the wave: lane = (lag block of 8 lags, of z.z or z.y) x (slice of
+// the sample axis), the register blocking of normal_eq_sum_kernel; tail products K^2 / 64 per lane
+// in registers.  The four waves of a workgroup fold their sums once, at the end, in wave order;
+// part[blockIdx.x] as before (normal_eq_reduce_kernel adds the workgroups in a fixed order).
+// FROM_W: z = cumsum(w) inside the wave (chunk per lane, wave scan) + ||w||_1.
+// LDS per wave: z[N + pad] y[N + K + pad]; per workgroup: fold[K^2 + 2K + 2].
+// NEW_PE: tail entries per lane (K^2 <= 64 NEW_PE); NEW_PF: samples per lane prefetched in
+// registers (N <= 64 NEW_PF; longer series are loaded in place).  The (12, 5) instance -- K <= 27,
+// N <= 320: the shared-HRF loop of BASELINE config 4 -- is the leanest (forcing three waves per SIMD
+// on it spills and measured slower: 0.40 ms).
+
+__host__ __device__ inline int ne_wave_doubles(int N, int K) {      // one wave's staging area
+  return ne_sk(N + NE_LB + NE_JB) + 1 + ne_sk(N + K + NE_LB + NE_JB) + 1;
+}
+__host__ __device__ inline int ne_wave_lds_doubles(int N, int K) {
+  return GEN_WAVES * ne_wave_doubles(N, K) + K * K + 2 * K + 2;
+}
+
+template <typename TY, bool FROM_W, int NEW_PE = 16, int NEW_PF = 8>
+__global__ __launch_bounds__(NE_THREADS) void normal_eq_wave_kernel(const double* z, int64_t ldz,
+                                                                    const TY* y, int64_t ldy, int V,
+                                                                    int N, int K, double* part_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int ne = ne_len(K);
+  const int ne_out = ne + (FROM_W ? 1 : 0);
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int nz = N + NE_LB + NE_JB, ny = N + K + NE_LB + NE_JB;
+  double* lz = reinterpret_cast<double*>(smem) + wv * ne_wave_doubles(N, K);
+  double* ly = lz + ne_sk(nz) + 1;
+  double* fold = reinterpret_cast<double*>(smem) + GEN_WAVES * ne_wave_doubles(N, K);   // [2K] bulk, [K^2] P, yy, l1
+  auto wave_sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  for (int i = lane; i <= ne_sk(nz); i += 64) lz[i] = 0.0;           // padding stays zero
+  for (int i = lane; i <= ne_sk(ny); i += 64) ly[i] = 0.0;
+  const int jb = N > K ? N - K : 0;
+  const int nlb = (K + NE_LB - 1) / NE_LB;                           // <= 4
+  int slices = 1;
+  while (2 * slices * 2 * nlb <= 64) slices *= 2;
+  const int role = lane / slices, slice = lane % slices;
+  const bool worker = role < 2 * nlb;
+  const bool cross = role >= nlb;
+  const int d0 = (cross ? role - nlb : role) * NE_LB;
+  const int jrange = cross ? N : jb;
+  const double* src = cross ? ly : lz;
+  double acc[NE_LB];
+#pragma unroll
+  for (int l = 0; l < NE_LB; ++l) acc[l] = 0.0;
+  double yy = 0.0, l1 = 0.0;
+  // this lane's tail entries (d, jj): LDS offsets of the two factors, 16 bits each; entries that do
+  // not exist multiply the last padding slot (zero) by itself
+  const unsigned zero_slot = (unsigned)ne_sk(nz) | ((unsigned)ne_sk(nz) << 16);
+  unsigned te[NEW_PE];
+  double P[NEW_PE];
+#pragma unroll
+  for (int q = 0; q < NEW_PE; ++q) {
+    const int e = lane + q * 64;
+    const int d = e / K, jj = e - d * K;
+    const bool ok = e < K * K && jb + jj + d < N;
+    te[q] = ok ? ((unsigned)ne_sk(jb + jj) | ((unsigned)ne_sk(jb + jj + d) << 16)) : zero_slot;
+    P[q] = 0.0;
+  }
+  const bool prefetch = N <= NEW_PF * 64;
+  double pz[NEW_PF];
+  TY py[NEW_PF];
+  auto fetch = [&](int v) {
+    const double* zr = z + (int64_t)v * ldz;
+    const TY* yr = y + (int64_t)v * ldy;
+#pragma unroll
+    for (int q = 0; q < NEW_PF; ++q) {
+      const int i = lane + q * 64;
+      if (i < N) { pz[q] = zr[i]; py[q] = yr[i]; }
+    }
+  };
+  const int v0 = blockIdx.x * GEN_WAVES + wv, vstride = gridDim.x * GEN_WAVES;
+  if (prefetch && v0 < V) fetch(v0);
+  const int chunk = (N + NE_THREADS - 1) / NE_THREADS;
+  for (int v = v0; v < V; v += vstride) {
+    wave_sync();                                 // previous voxel fully consumed
+    if (prefetch) {
+#pragma unroll
+      for (int q = 0; q < NEW_PF; ++q) {
+        const int i = lane + q * 64;
+        if (i < N) {
+          const double yv = (double)py[q];
+          lz[ne_sk(i)] = pz[q];
+          ly[ne_sk(i)] = yv;
+          yy = fma(yv, yv, yy);
+        }
+      }
+      if (v + vstride < V) fetch(v + vstride);   // in flight during the sums below
+    } else {
+      const double* zr = z + (int64_t)v * ldz;
+      const TY* yr = y + (int64_t)v * ldy;
+      for (int i = lane; i < N; i += 64) {
+        const double yv = (double)yr[i];
+        lz[ne_sk(i)] = zr[i];
+        ly[ne_sk(i)] = yv;
+        yy = fma(yv, yv, yy);
+      }
+    }
+    wave_sync();
+    if constexpr (FROM_W) {
+      // z = cumsum(w) with the summation tree of block_cumsum (generic.h) -- chunks of
+      // ceil(N / 256), a 64-wide scan per group of 64 chunks, group offsets added in order -- so
+      // that z equals pb_integ_op's bit for bit; this wave plays the four waves one after another
+      // (the four scans are independent until the offsets are added: written side by side so
+      // that their shuffle latencies overlap)
+      constexpr int CH = (NEW_PF * 64 + NE_THREADS - 1) / NE_THREADS;   // chunk <= CH while the prefetch form applies
+      double local[GEN_WAVES], incl[GEN_WAVES], x[GEN_WAVES][CH];
+      const bool inreg = chunk <= CH;              // chunk elements in registers: ONE LDS round trip
+#pragma unroll
+      for (int g4 = 0; g4 < GEN_WAVES; ++g4) {
+        const int lo = (g4 * 64 + lane) * chunk, hi2 = min(lo + chunk, N);
+        local[g4] = 0.0;
+        if (inreg) {
+#pragma unroll
+          for (int c = 0; c < CH; ++c) x[g4][c] = (c < chunk && lo + c < N) ? lz[ne_sk(lo + c)] : 0.0;
+        } else {
+          for (int i = lo; i < hi2; ++i) {
+            const double wvv = lz[ne_sk(i)];
+            local[g4] += wvv;
+            l1 += fabs(wvv);
+          }
+        }
+      }
+      if (inreg) {
+#pragma unroll
+        for (int g4 = 0; g4 < GEN_WAVES; ++g4)
+#pragma unroll
+          for (int c = 0; c < CH; ++c) {
+            local[g4] += x[g4][c];                 // (an absent element adds +0.0)
+            l1 += fabs(x[g4][c]);
+          }
+      }
+#pragma unroll
+      for (int g4 = 0; g4 < GEN_WAVES; ++g4) incl[g4] = local[g4];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+        for (int g4 = 0; g4 < GEN_WAVES; ++g4) {
+          const double up = __shfl_up(incl[g4], o, 64);
+          if (lane >= o) incl[g4] += up;
+        }
+      }
+      double woff = 0.0;
+#pragma unroll
+      for (int g4 = 0; g4 < GEN_WAVES; ++g4) {
+        const int lo = (g4 * 64 + lane) * chunk, hi2 = min(lo + chunk, N);
+        double run = woff + incl[g4] - local[g4];
+        if (inreg) {
+#pragma unroll
+          for (int c = 0; c < CH; ++c) {
+            run += x[g4][c];
+            if (c < chunk && lo + c < N) lz[ne_sk(lo + c)] = run;
+          }
+        } else {
+          for (int i = lo; i < hi2; ++i) {
+            run += lz[ne_sk(i)];
+            lz[ne_sk(i)] = run;
+          }
+        }
+        woff += __shfl(incl[g4], 63, 64);
+      }
+      wave_sync();
+    }
+    if (worker) {
+      for (int j0 = slice * NE_JB; j0 < jrange; j0 += slices * NE_JB) {
+        double a[NE_JB], b[NE_JB + NE_LB - 1];
+        const double* pa = lz + ne_sk(j0);
+        const double* pb = src + ne_sk(j0 + d0);
+#pragma unroll
+        for (int q = 0; q < NE_JB; ++q) a[q] = (j0 + q < jrange) ? pa[q] : 0.0;
+#pragma unroll
+        for (int q = 0; q < NE_JB + NE_LB - 1; ++q) b[q] = pb[q + (q >> 3)];
+#pragma unroll
+        for (int q = 0; q < NE_JB; ++q)
+#pragma unroll
+          for (int l = 0; l < NE_LB; ++l) acc[l] = fma(a[q], b[q + l], acc[l]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NEW_PE; ++q)
+      P[q] = fma(lz[te[q] & 0xffffu], lz[te[q] >> 16], P[q]);
+  }
+  // ---- fold: slices of a role (adjacent lanes, fixed order), then the four waves in wave order ----
+  for (int o = slices >> 1; o >= 1; o >>= 1) {
+#pragma unroll
+    for (int l = 0; l < NE_LB; ++l) acc[l] += __shfl_xor(acc[l], o, 64);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    yy += __shfl_xor(yy, o, 64);
+    l1 += __shfl_xor(l1, o, 64);
+  }
+  for (int w = 0; w < GEN_WAVES; ++w) {
+    __syncthreads();
+    if (wv == w) {
+      if (worker && slice == 0) {
+#pragma unroll
+        for (int l = 0; l < NE_LB; ++l)
+          if (d0 + l < K) {
+            double* dst = fold + (cross ? K : 0) + d0 + l;
+            *dst = (w == 0 ? 0.0 : *dst) + acc[l];
+          }
+      }
+#pragma unroll
+      for (int q = 0; q < NEW_PE; ++q) {
+        const int e = lane + q * 64;
+        if (e < K * K) fold[2 * K + e] = (w == 0 ? 0.0 : fold[2 * K + e]) + P[q];
+      }
+      if (lane == 0) {
+        fold[2 * K + K * K] = (w == 0 ? 0.0 : fold[2 * K + K * K]) + yy;
+        fold[2 * K + K * K + 1] = (w == 0 ? 0.0 : fold[2 * K + K * K + 1]) + l1;
+      }
+    }
+  }
+  __syncthreads();
+  const double* bulk = fold;
+  const double* Pf = fold + 2 * K;
+  double* part = part_out + (int64_t)blockIdx.x * ne_out;
+  for (int e = t; e < ne; e += NE_THREADS) part[e] = 0.0;            // entries with no sample
+  if (FROM_W && t == 0) part[ne] = fold[2 * K + K * K + 1];
+  __syncthreads();
+  if (t < K) {
+    const int d = t;
+    const int tail = (N - d > jb) ? N - d - jb : 0;
+    double r = bulk[d];
+    for (int jj = 0; jj < tail; ++jj) {
+      r += Pf[d * K + jj];
+      const int mp = N - 1 - (jb + jj);
+      const int m = mp - d;
+      part[m * K + mp] = r;
+      part[mp * K + m] = r;
+    }
+  } else if (t < 2 * K) {
+    part[K * K + (t - K)] = bulk[t];
+  } else if (t == 2 * K) {
+    part[K * K + K] = fold[2 * K + K * K];
+  }
+}
+
 // out[e] = sum_b part[b][e]: one workgroup per entry e, the blocks dealt over its threads
 // (stride NE_THREADS) and folded by the fixed tree of block_sum -- the summation order
 // depends on nblocks only, never on timing (nblocks may be 0: an empty shard gives zeros).

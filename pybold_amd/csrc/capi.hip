@@ -497,6 +497,17 @@ int lambda_max_impl(const TY* y_dev, int64_t ldy, int V, int N, const double* ta
 }
 
 constexpr int NE_MAX_BLOCKS = 2048;
+constexpr int NE_WAVE_BLOCKS = 1024;           // one-voxel-per-wave form: one resident pass (4 workgroups per CU)
+
+// the one-voxel-per-wave form serves K <= 32 (tail entries in registers) while four staging areas fit
+inline bool ne_wave_form(int N, int K) {
+  return K <= 32 && (int64_t)pb::ne_wave_lds_doubles(N, K) <= LDS_DOUBLES_MAX && !getenv("PB_NE_BLOCK_FORM");
+}
+inline int ne_wave_blocks(int V, int cap) {
+  int b = (V + pb::GEN_WAVES - 1) / pb::GEN_WAVES;
+  if (b > NE_WAVE_BLOCKS) b = NE_WAVE_BLOCKS;
+  return b < cap ? b : cap;
+}
 
 template <typename TY>
 int normal_eq_impl(const double* z_dev, int64_t ldz, const TY* y_dev, int64_t ldy, int V, int N,
@@ -527,9 +538,16 @@ int normal_eq_impl(const double* z_dev, int64_t ldz, const TY* y_dev, int64_t ld
     if (blocks < 1 || !work_dev)
       return fail(PB_ERR_INVALID, "%s: work buffer must hold at least %d doubles", name, ne);
     if (!z_dev || !y_dev) return fail(PB_ERR_INVALID, "%s: NULL pointer", name);
-    hipLaunchKernelGGL((pb::normal_eq_sum_kernel<TY>), dim3(blocks), dim3(pb::NE_THREADS),
-                       (size_t)pb::ne_sum_lds_doubles(N, K) * sizeof(double), (hipStream_t)stream, z_dev,
-                       ldz, y_dev, ldy, V, N, K, work_dev);
+    if (ne_wave_form(N, K)) {                  // one voxel per wave (blind.h)
+      blocks = ne_wave_blocks(V, blocks);
+      hipLaunchKernelGGL((pb::normal_eq_wave_kernel<TY, false>), dim3(blocks), dim3(pb::NE_THREADS),
+                         (size_t)pb::ne_wave_lds_doubles(N, K) * sizeof(double), (hipStream_t)stream, z_dev,
+                         ldz, y_dev, ldy, V, N, K, work_dev);
+    } else {
+      hipLaunchKernelGGL((pb::normal_eq_sum_kernel<TY>), dim3(blocks), dim3(pb::NE_THREADS),
+                         (size_t)pb::ne_sum_lds_doubles(N, K) * sizeof(double), (hipStream_t)stream, z_dev,
+                         ldz, y_dev, ldy, V, N, K, work_dev);
+    }
   } else {
     blocks = 0;
   }
@@ -1146,9 +1164,20 @@ int pb_hrf_normal_eq_w(const double* w_dev, int64_t ldw, const float* y_dev, int
     if (blocks < 1 || !work_dev)
       return fail(PB_ERR_INVALID, "pb_hrf_normal_eq_w: work buffer must hold at least %d doubles", ne);
     if (!w_dev || !y_dev) return fail(PB_ERR_INVALID, "pb_hrf_normal_eq_w: NULL pointer");
-    hipLaunchKernelGGL((pb::normal_eq_sum_kernel<float, true>), dim3(blocks), dim3(pb::NE_THREADS),
-                       (size_t)nd * sizeof(double), (hipStream_t)stream, w_dev, ldw, y_dev, ldy, V, N, K,
-                       work_dev);
+    if (ne_wave_form(N, K)) {
+      blocks = ne_wave_blocks(V, blocks);
+      const size_t lds = (size_t)pb::ne_wave_lds_doubles(N, K) * sizeof(double);
+      if (K * K <= 64 * 12 && N <= 64 * 5)
+        hipLaunchKernelGGL((pb::normal_eq_wave_kernel<float, true, 12, 5>), dim3(blocks), dim3(pb::NE_THREADS), lds,
+                           (hipStream_t)stream, w_dev, ldw, y_dev, ldy, V, N, K, work_dev);
+      else
+        hipLaunchKernelGGL((pb::normal_eq_wave_kernel<float, true>), dim3(blocks), dim3(pb::NE_THREADS), lds,
+                           (hipStream_t)stream, w_dev, ldw, y_dev, ldy, V, N, K, work_dev);
+    } else {
+      hipLaunchKernelGGL((pb::normal_eq_sum_kernel<float, true>), dim3(blocks), dim3(pb::NE_THREADS),
+                         (size_t)nd * sizeof(double), (hipStream_t)stream, w_dev, ldw, y_dev, ldy, V, N, K,
+                         work_dev);
+    }
   } else {
     blocks = 0;
   }
