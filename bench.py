@@ -285,7 +285,8 @@ def run(args):
         lam = args.lbda
     P = V * y_rep                                               # problems of this rank
     plan = solver.FistaPlan(Y, hrf, lam, step, n_iter, y_rep=y_rep, force=force)
-    kernel_name = (solver.which_kernel(N, K, max(P, 1)) if args.kernel in ("auto", "seq") else
+    plan0 = solver.launch_plan(N, K, max(P, 1), force="valu" if torch.is_tensor(lam) else None)
+    kernel_name = ((plan0[1] if plan0[0] > 0 else plan0[2]) if args.kernel in ("auto", "seq") else
                    {"fast1": solver.KERNEL_NAMES[1], "generic": solver.KERNEL_NAMES[0]}[args.kernel])
 
     def one_step():
@@ -299,7 +300,10 @@ def run(args):
     # dominant kernel is timed on its own here (same grid, same data, a few launches after
     # the timed region, THIS RANK ONLY: no collective, ranks may differ in their plans) so that
     # its duration can be set against its rocprofv3 average.
-    n_main, main_kernel, tail_kernel = solver.launch_plan(N, K, max(P, 1))
+    # (per-problem lambdas -- config 5's regularisation path, sparse solutions by construction -- stay
+    # on the vector forms: the library does not put them on the matrix pipe)
+    plan_force = "valu" if torch.is_tensor(lam) else None
+    n_main, main_kernel, tail_kernel = solver.launch_plan(N, K, max(P, 1), force=plan_force)
     P_dom = n_main if (args.kernel in ("auto", "seq") and n_main > 0) else P
     matrix_pipe = "matrix pipe" in (main_kernel if n_main else tail_kernel)
     if P_dom != P and P_dom % y_rep == 0:

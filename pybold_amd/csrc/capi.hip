@@ -416,6 +416,9 @@ int plan_pieces_mfma(int P, bool has_pair, bool has_wide, bool one_launch, bool 
     out[n++] = Piece{FORM_MFMA, 0, P, false, false};
     return n;
   }
+  // (the remainder as one-problem waves on the side stream from the START -- an 84-register wave
+  // fits beside a matrix-pipe wave's 416 -- measured slower: 12.67 against 11.88 ms per step of
+  // config 3, profiles/r3_remainder_beside_mfma_ab.txt: it goes behind the whole rounds)
   if (whole > 0) out[n++] = Piece{FORM_MFMA, 0, whole, false, false};
   Piece sub[4];
   const int m = plan_pieces(R, has_pair, has_wide, false, one_stream, sub);

@@ -100,17 +100,27 @@ __device__ __forceinline__ unsigned pk_rne(float x0, float x1) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f2v{x0, x1}, h2));
 }
 
+// (x0, x1) -> packed hi = RTZ(x) and packed lo = RNE(x - hi); x - hi is exact in float32.
+// (v_fma_mixlo_f16 + v_fma_mixhi_f16 would write the rounded differences straight into the two
+// halves -- one instruction less per pair, 96 fewer per iteration -- and measured 4.5 % SLOWER:
+// profiles/r3_mfma_split_mixlo_ab.txt; the partial-register writes serialise.)
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
+  hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+  float l0, l1;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi), "v"(x0));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi), "v"(x1));
+  lo = pk_rne(l0, l1);
+}
+
 // eight float32 -> float16 hi / lo parts (hi = RTZ(x), lo = RNE(x - hi): 22 bits, unbiased)
 __device__ __forceinline__ Frag split8(const float (&x)[8]) {
   u4 ph, pl;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x[2 * p], x[2 * p + 1]));
-    float l0, l1;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(h2), "v"(x[2 * p]));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(h2), "v"(x[2 * p + 1]));
+    unsigned h2, l2;
+    split_pair(x[2 * p], x[2 * p + 1], h2, l2);
     ph[p] = h2;
-    pl[p] = pk_rne(l0, l1);
+    pl[p] = l2;
   }
   return Frag{__builtin_bit_cast(h8, ph), __builtin_bit_cast(h8, pl)};
 }
@@ -312,12 +322,7 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
       asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(x1) : "v"(w[q][2 * pp + 1]));
       if constexpr (WITH_J) jl1 += fabsf(x0) + fabsf(x1);
       if constexpr (CERT) jw2 = fmaf(x1, x1, fmaf(x0, x0, jw2));
-      const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
-      float l0, l1;
-      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(h2), "v"(x0));
-      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(h2), "v"(x1));
-      ph[q][pp] = h2;
-      pl[q][pp] = pk_rne(l0, l1);
+      split_pair(x0, x1, ph[q][pp], pl[q][pp]);
       if constexpr (pp == 3) {
         wf[q].hi = __builtin_bit_cast(h8, u4{ph[q][0], ph[q][1], ph[q][2], ph[q][3]});
         wf[q].lo = __builtin_bit_cast(h8, u4{pl[q][0], pl[q][1], pl[q][2], pl[q][3]});
@@ -336,12 +341,7 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
         x1 = (32 * q + tb + 2 * pp + 1 < a.N) ? x1 : 0.0f;
       }
       if constexpr (WITH_J) jsq = fmaf(x1, x1, fmaf(x0, x0, jsq));
-      const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
-      float l0, l1;
-      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(h2), "v"(x0));
-      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(h2), "v"(x1));
-      rh[q][pp] = h2;
-      rl[q][pp] = pk_rne(l0, l1);
+      split_pair(x0, x1, rh[q][pp], rl[q][pp]);
       if constexpr (pp == 3) {
         // the residual fragments wait in LDS for the adjoint pass (each lane reads back only what
         // it wrote: no barrier); in registers they would cost 80 accumulator-file copies per iteration

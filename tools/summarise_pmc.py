@@ -2,7 +2,7 @@
 kept under profiles/ (development aid).
 
     python tools/summarise_pmc.py traffic <fetch_dir> <write_dir> <out.json> [--update-traffic]
-    python tools/summarise_pmc.py sq <sq_dir> <out.json>
+    python tools/summarise_pmc.py sq <sq_dir> <out.json>        (any SQ_* pass)
 
 Only dispatches of the dominant kernel (name contains KERNEL, default 'fista_pair') with the
 largest grid are kept (the bench also launches it on fewer problems)."""
@@ -87,7 +87,9 @@ def main():
         d = {}
         if waves:
             d["valu_insts_per_wave_per_iteration"] = m["SQ_INSTS_VALU"] / waves / iters
-            d["valu_simd_cycles_per_voxel_iteration"] = m["SQ_INSTS_VALU"] / waves / iters / 2.0   # 8 voxels/wave, 4 cyc/inst
+            vpw = float(os.environ.get("PB_VOXELS_PER_WAVE", "8"))        # pair form 8, matrix-pipe form 16
+            d["voxels_per_wave"] = vpw
+            d["valu_simd_cycles_per_voxel_iteration"] = m["SQ_INSTS_VALU"] / waves / iters * 4.0 / vpw   # 4 cycles per instruction
             d["active_inst_valu_over_wave_cycles"] = m["SQ_ACTIVE_INST_VALU"] / m["SQ_WAVE_CYCLES"]
             secs = info["mean_dispatch_ms"] * 1e-3
             d["sustained_clock_GHz_from_SQ_BUSY_CYCLES_over_32_SE"] = m["SQ_BUSY_CYCLES"] / 32.0 / secs / 1e9
@@ -96,9 +98,8 @@ def main():
             d["simd_valu_utilisation"] = busy_per_simd / (m["SQ_BUSY_CYCLES"] / 32.0)
             d["note_units"] = ("SQ_WAVE_CYCLES and SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md); one "
                                "wave64 VALU instruction = 1 quad-cycle = 4 cycles")
-        out = {"command": "rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU "
-                          "SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY --output-format csv -- python3 bench.py "
-                          "--steps 3 --warmup 1 --cpu-seconds 0",
+        counters = " ".join(sorted(m))
+        out = {"command": "rocprofv3 --pmc %s --output-format csv -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0" % counters,
                **info, "mean_per_dispatch": m, "derived": d}
         json.dump(out, open(sys.argv[3], "w"), indent=1)
         print(json.dumps(out)[:600])
