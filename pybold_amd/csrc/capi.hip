@@ -412,7 +412,11 @@ int plan_pieces_mfma(int P, bool has_pair, bool has_wide, bool one_launch, bool 
   const int whole = (P / round) * round;
   const int R = P - whole;
   int n = 0;
-  if (one_launch || R == 0 || R > round / 2) {
+  // a remainder costs one matrix-pipe pass (1.74 ms per 500 iterations at N = 300) whatever its size; the
+  // vector plan closes up to half a round of pair waves + one one-problem wave per SIMD beside them in
+  // 1.55 ms, so it keeps remainders up to round/2 + round/16
+  const bool has_side = has_pair && has_wide && !one_stream;
+  if (one_launch || R == 0 || R > round / 2 + (has_side ? round / 16 : 0)) {
     out[n++] = Piece{FORM_MFMA, 0, P, false, false};
     return n;
   }

@@ -162,11 +162,14 @@ def test_launch_plan_of_a_plain_solve():
     for P, want in expect.items():
         assert solver.launch_plan(300, 30, P, force="valu") == want, P
     # with the matrix-pipe form (round 3; 129..320 scans, up to 33 taps): whole rounds of 16 384 problems
-    # and any remainder above half a round on it, a smaller remainder on the vector forms' plan
+    # and any remainder above half a round + 1 024 on it (what half a round of pair waves with one
+    # one-problem wave per SIMD beside them closes faster than a matrix-pipe pass), a smaller remainder
+    # on the vector forms' plan
     mm = solver.KERNEL_NAMES[4]
-    expect = {1: (0, None, wave), 4096: (0, None, row), 8192: (0, None, pair), 8193: (0, None, mm), 10000: (0, None, mm),
-              12500: (0, None, mm), 16384: (0, None, mm), 21000: (16384, mm, row), 25000: (0, None, mm),
-              50000: (49152, mm, wave), 100000: (98304, mm, wave)}
+    expect = {1: (0, None, wave), 4096: (0, None, row), 8192: (0, None, pair), 8193: (8192, pair, wave),
+              9216: (8192, pair, wave), 9217: (0, None, mm), 10000: (0, None, mm),
+              12500: (0, None, mm), 16384: (0, None, mm), 21000: (16384, mm, row), 25000: (16384, mm, pair),
+              25601: (0, None, mm), 50000: (49152, mm, wave), 100000: (98304, mm, wave)}
     for P, want in expect.items():
         assert solver.launch_plan(300, 30, P) == want, P
     assert solver.launch_plan(128, 16, 100000)[1] == pair and row in solver.launch_plan(300, 40, 100000)[1:]
