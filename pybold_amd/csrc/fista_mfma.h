@@ -15,8 +15,8 @@
 //
 // T_c is lower triangular Toeplitz with a CONSTANT far field, so per block of 32 samples
 //   x_q = C0 w_q + C1 w_{q-1} + S 1 1^T (w_0 + ... + w_{q-2})
-// two near tiles and a running "carry" accumulated by one more tile product per block; the
-// adjoint mirrors it.  No cross-lane instruction is left in the loop: the cumulative sums ride in
+// two near tiles (three for 34..65 taps) and a running "carry" accumulated by one more tile product
+// per block; the adjoint mirrors it.  No cross-lane instruction is left in the loop: the cumulative sums ride in
 // the matrix accumulators.
 //
 // Precision: operands are split in two float16 parts (x = hi + lo, 22 bits; three products
@@ -64,15 +64,15 @@ typedef unsigned u4 __attribute__((ext_vector_type(4)));
 constexpr float MFMA_RHO_MAX = 0.02f;
 
 struct MfmaTaps {
-  float c[64];      // 2^a * cumsum(h)[m], m < 64 (constant from m = K-1 on)
+  float c[96];      // 2^a * cumsum(h)[m], m < 96 (constant from m = K-1 on; K <= 33 uses 64 of them)
   double g_scale;   // 2^(-2a): the gradient comes out scaled by 2^(2a)
   float y_scale;    // 2^a
 };
 
 inline MfmaTaps make_mfma_taps(const double* taps, int K) {
   MfmaTaps t;
-  double c[64], run = 0.0, cmax = 0.0;
-  for (int m = 0; m < 64; ++m) {
+  double c[96], run = 0.0, cmax = 0.0;
+  for (int m = 0; m < 96; ++m) {
     if (m < K) run += (double)(float)taps[m];
     c[m] = run;
     cmax = fabs(run) > cmax ? fabs(run) : cmax;
@@ -80,7 +80,7 @@ inline MfmaTaps make_mfma_taps(const double* taps, int K) {
   int e = 0;
   if (cmax > 0.0) frexp(cmax, &e);          // cmax = f 2^e, f in [0.5, 1)
   const int a = 3 - e;                       // max |c| 2^a in [4, 8)
-  for (int m = 0; m < 64; ++m) t.c[m] = (float)ldexp(c[m], a);
+  for (int m = 0; m < 96; ++m) t.c[m] = (float)ldexp(c[m], a);
   t.g_scale = ldexp(1.0, -2 * a);
   t.y_scale = (float)ldexp(1.0, a);
   return t;
@@ -134,7 +134,8 @@ __device__ __forceinline__ f4 mma3(const Frag& A, const Frag& B, f4 acc) {
 }
 
 // NB blocks of 32 samples per series, 32 (NB - 1) < N <= 32 NB (only the last block can hold
-// padding), HRFs of up to 33 taps.  No stop rule.
+// padding), HRFs of up to 33 taps (NT = 2 near tiles) or 65 taps (NT = 3: one more near tile per block and
+// pass, the far field starts one block further away; plain solves and TAPS_DEV only).  No stop rule.
 // WITH_J: cost trace, J[it] = 0.5 ||T_c w_{it+1} - y||^2 + lbda ||w_{it+1}||_1 (pybold/bold_signal.py:74-77)
 //   from the residual of the NEXT forward pass (the loop is rotated: one forward pass in front).
 // TAPS_DEV: the HRF and the step are read from device memory (a.taps_pp: K float64 shared by every
@@ -148,8 +149,10 @@ __device__ __forceinline__ f4 mma3(const Frag& A, const Frag& B, f4 acc) {
 //   fista_pair_ffa.h: numerator bounded from below by ONE tracked sample per lane (four per problem,
 //   in four different blocks), denominator from above by ||w_k|| + 2 ||w_{k+1}|| + 4 th sqrt(N);
 //   a problem that cannot be cleared is handed back (n_done = -1) for the exact rule.  Implies WITH_J.
-template <int NB, bool WITH_J = false, bool TAPS_DEV = false, bool CERT = false>
+template <int NB, bool WITH_J = false, bool TAPS_DEV = false, bool CERT = false, int NT = 2>
 __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps tp) {
+  static_assert(NT == 2 || NT == 3, "two near tiles (K <= 33) or three (K <= 65)");
+  constexpr int LCW = NT == 2 ? 64 : 96;           // cumulative taps kept per wave: lags 0 .. 32 NT - 1
   static_assert(!CERT || (WITH_J && !TAPS_DEV), "the certificate runs in the rotated (cost trace) loop");
   const int lane = threadIdx.x & 63;
   const int v = lane & 15, g = lane >> 4;
@@ -161,10 +164,10 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
 
   extern __shared__ __attribute__((aligned(16))) char mf_smem[];
   u4* lrf = reinterpret_cast<u4*>(mf_smem) + ((threadIdx.x >> 6) * NB * 2 * 64 + lane);
-  float* lc = reinterpret_cast<float*>(mf_smem + (size_t)4 * NB * 2 * 64 * sizeof(u4)) + (threadIdx.x >> 6) * 64;
+  float* lc = reinterpret_cast<float*>(mf_smem + (size_t)4 * NB * 2 * 64 * sizeof(u4)) + (threadIdx.x >> 6) * LCW;
   // CERT: per-lane words behind the taps (slot-major: conflict-free): [0..3] ring of the tracked
   // sample's last four increments, [4,5] its u_{k-1} (float64 halves), [6] this lane's ||w_k||^2 part
-  float* lt = reinterpret_cast<float*>(mf_smem + (size_t)4 * NB * 2 * 64 * sizeof(u4)) + 4 * 64 + threadIdx.x;
+  float* lt = reinterpret_cast<float*>(mf_smem + (size_t)4 * NB * 2 * 64 * sizeof(u4)) + 4 * LCW + threadIdx.x;
   if constexpr (CERT) {
 #pragma unroll
     for (int q = 0; q < 7; ++q) lt[q * 256] = 0.0f;
@@ -179,32 +182,39 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
   double step = a.step, g_scale = tp.g_scale;
   float y_scale = tp.y_scale;
   if constexpr (TAPS_DEV) {
-    double run = 0.0;
+    double run = 0.0, run2 = 0.0;
     for (int k = 0; k <= lane && k < a.K; ++k) run += (double)(float)a.taps_pp[k];
     float cm = fabsf((float)run);
+    if constexpr (NT == 3) {                       // lags 64 .. 95 (K <= 65: sum of the first lane + 65 taps)
+      run2 = run;
+      for (int k = lane + 1; k <= lane + 64 && k < a.K; ++k) run2 += (double)(float)a.taps_pp[k];
+      cm = fmaxf(cm, fabsf((float)run2));
+    }
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) cm = fmaxf(cm, __shfl_xor(cm, o, 64));
     int e = 0;
     if (cm > 0.0f) (void)frexpf(cm, &e);
     const int sa = 3 - e;
     lc[lane] = (float)ldexp(run, sa);
+    if constexpr (NT == 3) { if (lane < 32) lc[64 + lane] = (float)ldexp(run2, sa); }
     g_scale = ldexp(1.0, -2 * sa);
     y_scale = ldexpf(1.0f, sa);
     step = a.step_vec[0];
   } else {
     lc[lane] = tp.c[lane];
+    if constexpr (NT == 3) { if (lane < 32) lc[64 + lane] = tp.c[64 + lane]; }
   }
   wave_sync();
 
   // ---- operator tiles (A operands): lane holds row rho = lane & 15, k = 8 (lane >> 4) + j ----
-  Frag An[2][2], Bn[2][2], Ff;                   // forward near [r][o], adjoint near [r][o], far field
+  Frag An[2][NT], Bn[2][NT], Ff;                 // forward near [r][o], adjoint near [r][o], far field
   {
     const int rho = lane & 15, kg = lane >> 4, gp = rho >> 2, i = rho & 3;
-    auto cval = [&](int lag) -> float { return lag < 0 ? 0.0f : lc[lag > 63 ? 63 : lag]; };
+    auto cval = [&](int lag) -> float { return lag < 0 ? 0.0f : lc[lag > LCW - 1 ? LCW - 1 : lag]; };
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
-      for (int o = 0; o < 2; ++o) {
+      for (int o = 0; o < NT; ++o) {
         float fa[8], fb[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -216,7 +226,7 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
       }
     float ff[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ff[j] = lc[63];
+    for (int j = 0; j < 8; ++j) ff[j] = lc[LCW - 1];
     Ff = split8(ff);
   }
 
@@ -284,7 +294,7 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
 #pragma unroll
   for (int r = 0; r < 2; ++r)
 #pragma unroll
-    for (int o = 0; o < 2; ++o)
+    for (int o = 0; o < NT; ++o)
       asm volatile("" : "+a"(An[r][o].hi), "+a"(An[r][o].lo), "+a"(Bn[r][o].hi), "+a"(Bn[r][o].lo));
   asm volatile("" : "+a"(Ff.hi), "+a"(Ff.lo));
 #pragma unroll
@@ -355,15 +365,14 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
     static_for<0, NB>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
       f4 cn = carry;                              // carry of block q+1
-      static_for<0, 15>([&](auto sc) {
+      static_for<0, 3 + 6 * NT>([&](auto sc) {
         constexpr int sl = decltype(sc)::value;
         // -- the matrix instruction of this slot
-        if constexpr (sl < 3) {
-          if constexpr (q >= 1 && q + 1 < NB) cn = mfma_part(Ff, wf[q - 1], cn, sl);
+        if constexpr (sl < 3) {                     // carry of block q+1: + S (sum of block q+1-NT)
+          if constexpr (q >= NT - 1 && q + 1 < NB) cn = mfma_part(Ff, wf[q >= NT - 1 ? q - (NT - 1) : 0], cn, sl);
         } else {
-          constexpr int c = sl - 3, r = c & 1, k = c >> 1;
-          if constexpr (k < 3) acc[q][r] = mfma_part(An[r][0], wf[q], acc[q][r], k);
-          else if constexpr (q >= 1) acc[q][r] = mfma_part(An[r][1], wf[q - 1], acc[q][r], k - 3);
+          constexpr int c = sl - 3, r = c & 1, k = c >> 1, o = k / 3;      // near tile o: block q-o
+          if constexpr (q >= o) acc[q][r] = mfma_part(An[r][o], wf[q >= o ? q - o : 0], acc[q][r], k - 3 * o);
         }
         // -- a slice of the neighbours' vector work
         if constexpr (sl < 4) {
@@ -407,17 +416,16 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
       constexpr int q = NB - 1 - decltype(qq)::value;
       f4 cn = carry;                              // carry of block q-1
       if constexpr (q >= 1) fetch(std::integral_constant<int, q - 1>{});   // one block ahead
-      static_for<0, 15>([&](auto sc) {
+      static_for<0, 3 + 6 * NT>([&](auto sc) {
         constexpr int sl = decltype(sc)::value;
-        if constexpr (sl < 3) {
-          if constexpr (q >= 1 && q + 1 < NB) cn = mfma_part(Ff, rf[q + 1], cn, sl);
+        if constexpr (sl < 3) {                     // carry of block q-1: + S (sum of block q-1+NT)
+          if constexpr (q >= 1 && q - 1 + NT < NB) cn = mfma_part(Ff, rf[q - 1 + NT < NB ? q - 1 + NT : 0], cn, sl);
         } else {
-          constexpr int c = sl - 3, r = c & 1, k = c >> 1;
+          constexpr int c = sl - 3, r = c & 1, k = c >> 1, o = k / 3;      // near tile o: block q+o
           if constexpr (k == 0) acc[q][r] = mfma_part(Bn[r][0], rf[q], carry, 0);
-          else if constexpr (k < 3) acc[q][r] = mfma_part(Bn[r][0], rf[q], acc[q][r], k);
-          else if constexpr (q + 1 < NB) acc[q][r] = mfma_part(Bn[r][1], rf[q + 1], acc[q][r], k - 3);
+          else if constexpr (q + o < NB) acc[q][r] = mfma_part(Bn[r][o], rf[q + o < NB ? q + o : 0], acc[q][r], k - 3 * o);
         }
-        if constexpr ((sl & 1) == 0 && q + 1 < NB)
+        if constexpr ((sl & 1) == 0 && sl < 16 && q + 1 < NB)
           update(std::integral_constant<int, q + 1>{}, std::integral_constant<int, sl / 2>{});
         if constexpr ((sl % PB_MFMA_SBK) == PB_MFMA_SBK - 1) PB_MFMA_SB;
       });
@@ -526,26 +534,45 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
   if (live && a.n_done && g == 0) a.n_done[p] = bad ? -1 : a.n_iter;
 }
 
-// 16 problems per wave, 4 waves per workgroup, one wave per SIMD
-template <int NB>
-int launch_mfma(const FistaArgs& a, const double* taps, int K, bool with_j, hipStream_t st) {
-  if (a.N > 32 * NB || a.N <= 32 * (NB - 1) || K > 33 || K < 1) return 1;
+// 16 problems per wave, 4 waves per workgroup, one wave per SIMD.  NT near tiles: 2 for K <= 33, 3 for
+// K <= 65 (PB_MFMA_NT3; plain solves and the shared-HRF z-step: the cost-trace and certificate variants
+// would need 259 accumulator registers).
+#ifndef PB_MFMA_NT3
+#define PB_MFMA_NT3 1
+#endif
+template <int NB, int NT>
+int launch_mfma_nt(const FistaArgs& a, const double* taps, int K, bool with_j, hipStream_t st) {
   const int64_t waves = ((int64_t)(a.P - a.p0) + 15) / 16;
   const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
   const bool cert = a.stop_mode == PB_STOP_WINDOW;
   if (cert && (!a.n_done || a.taps_pp)) return 1;
-  const size_t lds = (size_t)4 * NB * 2 * 64 * sizeof(u4) + 4 * 64 * sizeof(float) +    // residual fragments (8 KB per block of 32 samples), taps
+  if (NT == 3 && (cert || with_j)) return 1;
+  const size_t lds = (size_t)4 * NB * 2 * 64 * sizeof(u4) + 4 * (NT == 2 ? 64 : 96) * sizeof(float) +    // residual fragments (8 KB per block of 32 samples), taps
                      (cert ? 7 * 256 * sizeof(float) : 0);                                // certificate state
   if (a.taps_pp) {                              // shared HRF and step in device memory; no cost trace
     const MfmaTaps none{};
-    hipLaunchKernelGGL((fista_mfma_kernel<NB, false, true>), grid, block, lds, st, a, none);
+    hipLaunchKernelGGL((fista_mfma_kernel<NB, false, true, false, NT>), grid, block, lds, st, a, none);
     return 0;
   }
   const MfmaTaps tp = make_mfma_taps(taps, K);
-  if (cert) hipLaunchKernelGGL((fista_mfma_kernel<NB, true, false, true>), grid, block, lds, st, a, tp);
-  else if (with_j) hipLaunchKernelGGL((fista_mfma_kernel<NB, true, false>), grid, block, lds, st, a, tp);
-  else hipLaunchKernelGGL((fista_mfma_kernel<NB, false, false>), grid, block, lds, st, a, tp);
+  if constexpr (NT == 2) {
+    if (cert) hipLaunchKernelGGL((fista_mfma_kernel<NB, true, false, true>), grid, block, lds, st, a, tp);
+    else if (with_j) hipLaunchKernelGGL((fista_mfma_kernel<NB, true, false>), grid, block, lds, st, a, tp);
+    else hipLaunchKernelGGL((fista_mfma_kernel<NB, false, false>), grid, block, lds, st, a, tp);
+  } else {
+    hipLaunchKernelGGL((fista_mfma_kernel<NB, false, false, false, NT>), grid, block, lds, st, a, tp);
+  }
   return 0;
+}
+
+template <int NB>
+int launch_mfma(const FistaArgs& a, const double* taps, int K, bool with_j, hipStream_t st) {
+  if (a.N > 32 * NB || a.N <= 32 * (NB - 1) || K < 1) return 1;
+  if (K <= 33) return launch_mfma_nt<NB, 2>(a, taps, K, with_j, st);
+#if PB_MFMA_NT3
+  if (K <= 65) return launch_mfma_nt<NB, 3>(a, taps, K, with_j, st);
+#endif
+  return 1;
 }
 
 }  // namespace pb

@@ -1,5 +1,6 @@
 // The matrix-pipe form of the fused FISTA kernel (fista_mfma.h): series of 129..320 scans
-// (NB blocks of 32 samples; only the last block may hold padding), HRFs of up to 33 taps.
+// (NB blocks of 32 samples; only the last block may hold padding), HRFs of up to 33 taps (two near
+// tiles) or 65 taps (three).
 #include "fista_mfma.h"
 #ifndef PB_NB
 #error "compile with -DPB_NB=<blocks of 32 samples>"
