@@ -111,6 +111,11 @@ int main() {
     T(12, 0, 0, 2, "12 mixed (f64 fma/max, cvt, pkrtz, f32 fma/add) / group");
     T(12, 2, 1, 2, "12 mixed + 2 mfma f16 16x16x32");
     T(12, 1, 2, 2, "12 mixed + 1 mfma f16 32x32x16");
+    T(6, 0, 0, 2, "6 mixed / group");
+    T(6, 1, 2, 2, "6 mixed + 1 mfma f16 32x32x16      (the ratio of a 32x32x16 form of fista_mfma_kernel)");
+    T(3, 0, 0, 2, "3 mixed / group");
+    T(3, 1, 1, 2, "3 mixed + 1 mfma f16 16x16x32      (~ the ratio of fista_mfma_kernel: 3.6 vector per matrix instruction)");
+    T(4, 1, 1, 2, "4 mixed + 1 mfma f16 16x16x32");
     T(18, 2, 1, 2, "18 mixed + 2 mfma f16 16x16x32");
     T(18, 1, 2, 2, "18 mixed + 1 mfma f16 32x32x16");
   }
