@@ -314,3 +314,37 @@ def test_bd_shared_fused_equals_unfused():
     assert np.array_equal(d1["theta"], d0["theta"])
     np.testing.assert_allclose(d1["J"], d0["J"], rtol=1e-13)
     assert torch.equal(W1, W0) and np.array_equal(h1, h0)
+
+
+# ---- normal equations, one voxel per wave: every code path of normal_eq_wave_kernel ------------------
+@pytest.mark.parametrize("n,k", [(300, 27), (5, 8), (1, 1), (33, 32), (64, 3), (513, 20), (1000, 30), (2000, 16),
+                                 (2400, 16), (300, 33)])
+def test_normal_equations_wave_form_shapes(solver, n, k):
+    """Series shorter than the HRF, one sample, K = 32 (the form's limit; 33 taps and series whose four
+    staging areas exceed the LDS fall back to the workgroup-per-voxel kernel), lengths beyond the
+    register prefetch (> 512) and beyond the in-register cumulative sum (chunks of more than two
+    samples), voxel counts below / across the number of waves; float32 and float64 series; the
+    fused form (innovation in, cumulative sum inside) -- all against the float64 oracle."""
+    rng = np.random.RandomState(1000 * n + k)
+    for V in (1, 3, 9, 1030):
+        if V * n > 600000:
+            continue
+        Wn = (rng.rand(V, n) < 0.1) * rng.randn(V, n)
+        Z = np.cumsum(Wn, axis=1)
+        Y = rng.randn(V, n)
+        Y32 = Y.astype(np.float32).astype(np.float64)
+        G, b, yy = orc.hrf_normal_eq(Z, Y, k)
+        ref = np.concatenate([G.ravel(), b, [yy]])
+        tol = dict(rtol=1e-11, atol=1e-11 * max(np.abs(ref).max(), 1e-300))
+        ne = solver.hrf_normal_eq(dev64(Z), dev64(Y), k).cpu().numpy()
+        np.testing.assert_allclose(ne, ref, **tol)
+        G32, b32, yy32 = orc.hrf_normal_eq(Z, Y32, k)
+        ref32 = np.concatenate([G32.ravel(), b32, [yy32]])
+        ne32 = solver.hrf_normal_eq(dev64(Z), dev32(Y), k).cpu().numpy()
+        np.testing.assert_allclose(ne32, ref32, **tol)
+        msg = solver.hrf_normal_eq_w(dev64(Wn), dev32(Y), k).cpu().numpy()
+        np.testing.assert_allclose(msg[:-1], ref32, **tol)
+        np.testing.assert_allclose(msg[-1], np.abs(Wn).sum(), rtol=1e-12)
+        # the fused form integrates with pb_integ_op's summation tree: bit-identical normal equations
+        ne_unfused = solver.hrf_normal_eq(solver.integ_op(dev64(Wn)), dev32(Y), k)
+        assert torch.equal(torch.from_numpy(msg[:-1]).cuda(), ne_unfused)
