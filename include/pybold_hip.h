@@ -93,8 +93,8 @@ int pb_fista_has_fast_path(int N, int K);
  * LDS kernel, 1 = register-resident, one problem per 16-lane row (fista_fast_kernel),
  * 2 = register-resident, two problems per row (fista_pair_kernel), 3 = register-resident,
  * one problem per wave (long series), 4 = register-resident, 16 problems per wave, both operators
- * on the matrix pipe (fista_mfma_kernel: 129..320 scans; HRFs of up to 33 taps, 34..48 taps for plain
- * solves without cost trace; one lambda for the batch; assumes n_done_dev is given).  Host-only query. */
+ * on the matrix pipe (fista_mfma_kernel: 129..320 scans; HRFs of up to 48 taps, the window-rule certificate up to
+ * 33; one lambda for the batch; assumes n_done_dev is given).  Host-only query. */
 int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mode, int wind);
 
 /* How pb_fista_solve (no flags) lays P problems out: problems [0, *n_main) in one launch of

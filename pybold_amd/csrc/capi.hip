@@ -83,8 +83,8 @@ PB_MFMA(5) PB_MFMA(6) PB_MFMA(7) PB_MFMA(8) PB_MFMA(9) PB_MFMA(10)
 namespace {
 typedef int (*mfma_launch_fn)(const pb::FistaArgs&, const double*, int, bool, hipStream_t);
 // the matrix-pipe form (fista_mfma.h): NB = ceil(N / 32) blocks of 32 samples, 129 <= N <= 320; K <= 33
-// with two near tiles (every variant), 34 <= K <= 65 with three (`extras` = cost trace or window-rule
-// certificate: not built for those)
+// with two near tiles (every variant), 34 <= K <= 65 with three (`extras` = window-rule certificate:
+// not built for those)
 constexpr int MFMA_K2 = 33, MFMA_K3 = 65;
 mfma_launch_fn pick_mfma(int N, int K, bool extras = false) {
   static const mfma_launch_fn tab[] = {&pb::launch_mfma<5>, &pb::launch_mfma<6>, &pb::launch_mfma<7>,
@@ -601,13 +601,14 @@ static bool pair_carries(const FastEntry* fe, int stop_mode, int wind) {
 }
 
 int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mode, int wind) {
+  (void)with_cost_trace;
   if (N < 1 || K < 1 || P < 1) return 0;
   if (const FastEntry* se = pick_split(N, K))
     if (P >= SPLIT_MIN_P && pair_carries(se, stop_mode, wind) && (stop_mode == PB_STOP_NONE || pick_wide(N, K)))
       return FORM_PAIR;
   const FastEntry* fe = pick_fast(N, K);
   if (fe && (pair_carries(fe, stop_mode, wind) || stop_mode == PB_STOP_NONE) &&
-      pick_mfma(N, K, with_cost_trace != 0 || stop_mode != PB_STOP_NONE)) {   // plain solves and the window-rule certificate
+      pick_mfma(N, K, stop_mode != PB_STOP_NONE)) {   // plain solves and the window-rule certificate
     Piece pc[6];
     plan_pieces_mfma(P, fe->fn_pair != nullptr, pick_wide_small(N, K) != nullptr, false, false, pc);
     return pc[0].form;
@@ -748,7 +749,7 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
   const bool cert = fe && stop_mode == PB_STOP_WINDOW && wind == 6 && fe->fn_pair_cert && n_done_dev &&
                     P >= 2 && !(flags & (PB_FLAG_NO_PAIR | PB_FLAG_NO_CERT | PB_FLAG_DIRECT_FIR)) &&
                     ((flags & PB_FLAG_FORCE_CERT) || tol * (double)n_iter < 0.5);
-  // plain solves (cost trace or not) of 129..320 scans, HRFs up to 33 taps (34..65: without cost trace): both operators on the
+  // plain solves (cost trace or not) of 129..320 scans, HRFs up to 33 taps (34..65: no certificate): both operators on the
   // matrix pipe (fista_mfma.h).  Needs n_done_dev: a problem whose scaled operands left the float16
   // range comes back with n_done = -1 and is re-solved on the single-row form.
   // Not with one lambda per problem, unless asked for (PB_FLAG_FORCE_MFMA): along a regularisation
@@ -761,7 +762,7 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
   const mfma_launch_fn mfma = (fe && (stop_mode == PB_STOP_NONE || mfma_cert) && n_done_dev &&
                                (!lbda_dev || (flags & PB_FLAG_FORCE_MFMA)) &&
                                !(flags & (PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_DIRECT_FIR | PB_FLAG_NO_MFMA)))
-                                  ? pick_mfma(N, K, J_dev != nullptr || stop_mode != PB_STOP_NONE) : nullptr;
+                                  ? pick_mfma(N, K, stop_mode != PB_STOP_NONE) : nullptr;
   if (fe) {
     auto run = [&](int form, int p0, int p1) -> int {
       pb::FistaArgs b = a;

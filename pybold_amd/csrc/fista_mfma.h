@@ -135,7 +135,7 @@ __device__ __forceinline__ f4 mma3(const Frag& A, const Frag& B, f4 acc) {
 
 // NB blocks of 32 samples per series, 32 (NB - 1) < N <= 32 NB (only the last block can hold
 // padding), HRFs of up to 33 taps (NT = 2 near tiles) or 65 taps (NT = 3: one more near tile per block and
-// pass, the far field starts one block further away; plain solves and TAPS_DEV only).  No stop rule.
+// pass, the far field starts one block further away; every variant but CERT).  No stop rule.
 // WITH_J: cost trace, J[it] = 0.5 ||T_c w_{it+1} - y||^2 + lbda ||w_{it+1}||_1 (pybold/bold_signal.py:74-77)
 //   from the residual of the NEXT forward pass (the loop is rotated: one forward pass in front).
 // TAPS_DEV: the HRF and the step are read from device memory (a.taps_pp: K float64 shared by every
@@ -535,8 +535,8 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
 }
 
 // 16 problems per wave, 4 waves per workgroup, one wave per SIMD.  NT near tiles: 2 for K <= 33, 3 for
-// K <= 65 (PB_MFMA_NT3; plain solves and the shared-HRF z-step: the cost-trace and certificate variants
-// would need 259 accumulator registers).
+// K <= 65 (PB_MFMA_NT3; plain solves with or without cost trace and the shared-HRF z-step; not the
+// window-rule certificate).
 #ifndef PB_MFMA_NT3
 #define PB_MFMA_NT3 1
 #endif
@@ -546,7 +546,7 @@ int launch_mfma_nt(const FistaArgs& a, const double* taps, int K, bool with_j, h
   const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
   const bool cert = a.stop_mode == PB_STOP_WINDOW;
   if (cert && (!a.n_done || a.taps_pp)) return 1;
-  if (NT == 3 && (cert || with_j)) return 1;
+  if (NT == 3 && cert) return 1;               // (the certificate's state spills beside three near tiles: 260 B per lane)
   const size_t lds = (size_t)4 * NB * 2 * 64 * sizeof(u4) + 4 * (NT == 2 ? 64 : 96) * sizeof(float) +    // residual fragments (8 KB per block of 32 samples), taps
                      (cert ? 7 * 256 * sizeof(float) : 0);                                // certificate state
   if (a.taps_pp) {                              // shared HRF and step in device memory; no cost trace
@@ -560,7 +560,8 @@ int launch_mfma_nt(const FistaArgs& a, const double* taps, int K, bool with_j, h
     else if (with_j) hipLaunchKernelGGL((fista_mfma_kernel<NB, true, false>), grid, block, lds, st, a, tp);
     else hipLaunchKernelGGL((fista_mfma_kernel<NB, false, false>), grid, block, lds, st, a, tp);
   } else {
-    hipLaunchKernelGGL((fista_mfma_kernel<NB, false, false, false, NT>), grid, block, lds, st, a, tp);
+    if (with_j) hipLaunchKernelGGL((fista_mfma_kernel<NB, true, false, false, NT>), grid, block, lds, st, a, tp);
+    else hipLaunchKernelGGL((fista_mfma_kernel<NB, false, false, false, NT>), grid, block, lds, st, a, tp);
   }
   return 0;
 }

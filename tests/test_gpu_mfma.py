@@ -87,27 +87,32 @@ def test_series_lengths_and_tap_counts(solver, n, k):
 @pytest.mark.parametrize("n,k", [(300, 34), (300, 40), (300, 48), (225, 41), (160, 34), (129, 48), (304, 47)])
 def test_three_near_tiles_for_hrfs_of_34_to_48_taps(solver, n, k):
     """HRFs of 34..48 taps (short TR): the matrix-pipe form with a third near tile (lags up to 95, far
-    field from lag 65 on); plain solves -- the cost trace of such shapes stays on the single-row form.
-    Every problem is solved there (none handed back on ordinary data), equal to the float64 C oracle
+    field from lag 65 on); plain solves and the cost trace (the window-rule certificate of such
+    shapes stays on the single-row form).  Every problem is solved there (none handed back on ordinary data), equal to the float64 C oracle
     and to the vector forms; the library's own dispatch (whole rounds + remainder) too."""
     rng = np.random.RandomState(n + k)
     hrf = orc.spm_hrf(1.0, 30.0 / k, 30.0, False)[0][:k]
     assert len(hrf) == k
     lip = orc.gram_lipschitz(hrf, n)
     assert solver.which_kernel(n, k, 100000).startswith("fista_mfma")
-    assert not solver.which_kernel(n, k, 100000, want_J=True).startswith("fista_mfma")
+    assert solver.which_kernel(n, k, 100000, want_J=True).startswith("fista_mfma")
+    assert not solver.which_kernel(n, k, 100000, want_J=True, stop="window").startswith("fista_mfma")
     Yv = rng.randn(40, n)
     W0 = 0.01 * rng.randn(40, n)
     Yh = Yv.astype(np.float32).astype(np.float64)
-    Wo, _, _ = c_oracle.fista_batch(Yh, hrf, 0.3, 1.0 / lip, 200, W0=W0, threads=4)
+    Wo, Jo, _ = c_oracle.fista_batch(Yh, hrf, 0.3, 1.0 / lip, 200, W0=W0, want_J=True, threads=4)
     W, _, nd = solver.fista_solve(dev32(Yv), hrf, 0.3, 1.0 / lip, 200, W0=dev64(W0), force="mfmaonly")
     assert int(nd.min()) == 200                                     # nothing handed back
     assert rel_rows(W.cpu().numpy(), Wo) < 3e-6
     Wv, _, _ = solver.fista_solve(dev32(Yv), hrf, 0.3, 1.0 / lip, 200, W0=dev64(W0), force="valu")
     assert rel_rows(W.cpu().numpy(), Wv.cpu().numpy()) < 3e-6
-    # cost trace requested: vector form, same iterate
-    Wj, J, _ = solver.fista_solve(dev32(Yv), hrf, 0.3, 1.0 / lip, 200, W0=dev64(W0), want_J=True)
-    assert rel_rows(Wj.cpu().numpy(), Wo) < EPS and J.shape == (40, 200)
+    # with the cost trace (rotated loop), on the matrix pipe too
+    Wj, J, ndj = solver.fista_solve(dev32(Yv), hrf, 0.3, 1.0 / lip, 200, W0=dev64(W0), want_J=True, force="mfmaonly")
+    assert int(ndj.min()) == 200 and rel_rows(Wj.cpu().numpy(), Wo) < 3e-6
+    np.testing.assert_allclose(J.cpu().numpy(), Jo, rtol=3e-5)
+    # the default deconv call (window rule + cost trace): exact rule on the single-row form
+    Ww, Jw, ndw = solver.fista_solve(dev32(Yv), hrf, 0.3, 1.0 / lip, 200, W0=dev64(W0), want_J=True, stop="window", tol=1e-6)
+    assert int(ndw.min()) == 200 and rel_rows(Ww.cpu().numpy(), Wo) < EPS
     if (n, k) == (300, 48):                                         # whole round + remainder, cold start
         Y = dev32(rng.randn(16384 + 300, n))
         Wl, _, ndl = solver.fista_solve(Y, hrf, 1.0, 1.0 / lip, 60)
