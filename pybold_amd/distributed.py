@@ -122,7 +122,6 @@ class HipOps:
         from . import solver
         self.s, self.t_r, self.hrf_dur, self.n = solver, t_r, hrf_dur, n
         self.work = None
-        self.side, self.msg2, self.overlap = None, None, True
 
     def hrf(self, theta):                       # (1,) -> (K,)
         return self.s.spm_hrf_batch(theta, self.t_r, self.hrf_dur)[0]
@@ -147,46 +146,6 @@ class HipOps:
         if self.work is None:
             self.work = torch.empty((2048 * (K * K + K + 2),), dtype=torch.float64, device=Y.device)
         return self.s.hrf_normal_eq_w(W, Y, K, work=self.work, out=out)
-
-    def _split(self, V, K):
-        """Where ``pb_fista_solve_pp`` cuts a shared-HRF z-step: whole rounds of the matrix-pipe kernel
-        in front, a remainder of at most half a round on the vector forms behind (0 or V: no cut)."""
-        name = self.s.launch_plan(self.n, K, 1 << 22)[1]
-        if name != self.s.KERNEL_NAMES[4] or K > 32:
-            return V
-        rnd = self.s.round_size(self.n, K)
-        base = (V // rnd) * rnd
-        return V if V - base > rnd // 2 else base
-
-    def z_step_and_normal_eq(self, Y, taps, lbda, nb_inner, W, step, last, K, out):
-        """z-step + ``normal_eq_msg``.  The remainder of the z-step (one-problem waves, latency-bound)
-        runs on a side stream BESIDE the normal equations of the whole rounds -- both kernels leave room
-        for each other on a SIMD, which the matrix-pipe kernel does not -- and its own (small) normal
-        equations are added afterwards: 0.11 ms less per outer iteration of BASELINE config 4."""
-        V = Y.shape[0]
-        base = self._split(V, K)
-        if base <= 0 or base >= V or not self.overlap:
-            W = self.z_step(Y, taps, lbda, nb_inner, W, step, last=last)
-            self.normal_eq_msg(W, Y, K, out)
-            return W
-        dev = Y.device
-        cur = torch.cuda.current_stream(dev)
-        if self.side is None:
-            self.side = torch.cuda.Stream(device=dev)
-            self.msg2 = torch.empty_like(out)
-        self.z_step(Y[:base], taps, lbda, nb_inner, W[:base], step, last=last)
-        ev_main = torch.cuda.Event()
-        ev_main.record(cur)
-        self.side.wait_event(ev_main)
-        with torch.cuda.stream(self.side):
-            self.z_step(Y[base:], taps, lbda, nb_inner, W[base:], step, last=last)
-            ev_rem = torch.cuda.Event()
-            ev_rem.record(self.side)
-        self.normal_eq_msg(W[:base], Y[:base], K, out)
-        cur.wait_event(ev_rem)
-        self.normal_eq_msg(W[base:], Y[base:], K, self.msg2)
-        out += self.msg2
-        return W
 
     def theta_fit(self, ne, bounds):            # -> theta (1,), F(theta) (1,), taps (K,)
         theta, f, taps = self.s.theta_fit(ne, self.t_r, self.hrf_dur, bounds)
@@ -235,14 +194,10 @@ def bd_shared(Y, t_r, lbda=1.0, theta_0=None, hrf_dur=20.0, bounds=None, nb_iter
     fused = bool(getattr(ops, "fused", False))
     step = None                                  # fused: 1 / ||A^T A||_F comes out of the theta step
     for it in range(nb_iter + 1):
-        if fused and hasattr(ops, "z_step_and_normal_eq"):
-            W = ops.z_step_and_normal_eq(Y, taps, lbda, nb_inner, W, step, it == nb_iter, K, msg)
-        elif fused:
-            W = ops.z_step(Y, taps, lbda, nb_inner, W, step, last=(it == nb_iter))
+        W = ops.z_step(Y, taps, lbda, nb_inner, W, step, last=(it == nb_iter)) if fused else ops.z_step(Y, taps, lbda, nb_inner, W)
+        if fused:
             ops.normal_eq_msg(W, Y, K, msg)      # cumulative sum and ||w||_1 inside the one pass
         else:
-            W = ops.z_step(Y, taps, lbda, nb_inner, W)
-        if not fused:
             msg[:ne_len] = ops.normal_eq(W, Y, K)
             msg[ne_len] = W.abs().sum()
         comm.allreduce_(msg)                     # the ONE collective of the outer iteration
