@@ -48,6 +48,16 @@
 #ifndef PB_MFMA_SBK
 #define PB_MFMA_SBK 15
 #endif
+// PB_MFMA_YMAT (off): -y enters the residual through the matrix pipe (identity tile x float16 hi/lo
+// fragments of -2^a sigma y, kept in the accumulator file and read by the matrix instructions directly)
+// instead of 80 accumulator-file reads + 80 additions per iteration on the vector pipe, and the carry
+// becomes the C operand of the first product of a block: 4 more matrix instructions per block for 145
+// fewer vector instructions per iteration (no scratch, parity tests green, y held to 22 bits).
+// Measured 2.5 % SLOWER (profiles/r3_mfma_y_through_matrix_pipe_ab.txt): one more matrix instruction
+// costs this kernel ~23 cycles, one vector instruction less saves ~5.
+#ifndef PB_MFMA_YMAT
+#define PB_MFMA_YMAT 0
+#endif
 #ifndef PB_MFMA_SB
 #define PB_MFMA_SB
 #endif
@@ -208,6 +218,7 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
 
   // ---- operator tiles (A operands): lane holds row rho = lane & 15, k = 8 (lane >> 4) + j ----
   Frag An[2][NT], Bn[2][NT], Ff;                 // forward near [r][o], adjoint near [r][o], far field
+  h8 Eh[2];                                      // PB_MFMA_YMAT: identity tile of row half r
   {
     const int rho = lane & 15, kg = lane >> 4, gp = rho >> 2, i = rho & 3;
     auto cval = [&](int lag) -> float { return lag < 0 ? 0.0f : lc[lag > LCW - 1 ? LCW - 1 : lag]; };
@@ -228,6 +239,15 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
 #pragma unroll
     for (int j = 0; j < 8; ++j) ff[j] = lc[LCW - 1];
     Ff = split8(ff);
+#if PB_MFMA_YMAT
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {                  // identity (in the permuted row order): lag 0 only
+      float fe[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) fe[j] = (8 * (gp - kg) + 4 * r + i - j == 0) ? 1.0f : 0.0f;
+      Eh[r] = split8(fe).hi;
+    }
+#endif
   }
 
   // ---- load the problem, scale it into the float16 range ---------------------------------
@@ -268,6 +288,11 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
         w[q][j] = (t < a.N && !a.cold) ? wrow[t] * (double)sigma : 0.0;
       }
   }
+#if PB_MFMA_YMAT
+  Frag yf[NB];                                   // -2^a sigma y as float16 hi / lo fragments (B operands)
+#pragma unroll
+  for (int q = 0; q < NB; ++q) yf[q] = split8(ysn[q]);
+#endif
   const double th = lb * step * (double)sigma;
   const double nstep = -step * g_scale;
   float guard = 0.0f;                            // largest |operand| seen by the range checks
@@ -297,10 +322,16 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
     for (int o = 0; o < NT; ++o)
       asm volatile("" : "+a"(An[r][o].hi), "+a"(An[r][o].lo), "+a"(Bn[r][o].hi), "+a"(Bn[r][o].lo));
   asm volatile("" : "+a"(Ff.hi), "+a"(Ff.lo));
+#if PB_MFMA_YMAT
+  asm volatile("" : "+a"(Eh[0]), "+a"(Eh[1]));
+#pragma unroll
+  for (int q = 0; q < NB; ++q) asm volatile("" : "+a"(yf[q].hi), "+a"(yf[q].lo));
+#else
 #pragma unroll
   for (int q = 0; q < NB; ++q)
 #pragma unroll
     for (int j = 0; j < 8; ++j) asm volatile("" : "+a"(ysn[q][j]));
+#endif
 
   // The iteration is straight-line.  The matrix pipe takes one instruction per 16 cycles and holds
   // the vector issue port for 8 of them, so the source is software-pipelined BY HAND at that grain
@@ -340,8 +371,12 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
     };
     auto cinit = [&](auto qc, auto rc, const f4& cy) {   // accumulators of block q start from carry - y
       constexpr int q = decltype(qc)::value, r = decltype(rc)::value;
+#if PB_MFMA_YMAT
+      acc[q][r] = cy;                               // (-y follows through the matrix pipe, slots 3 + 6 NT ...)
+#else
       acc[q][r] = f4{cy[0] + ysn[q][4 * r + 0], cy[1] + ysn[q][4 * r + 1], cy[2] + ysn[q][4 * r + 2],
                      cy[3] + ysn[q][4 * r + 3]};
+#endif
     };
     auto finish_pair = [&](auto qc, auto pc) {    // residual samples 2p, 2p+1 of block q -> fragment
       constexpr int q = decltype(qc)::value, pp = decltype(pc)::value;
@@ -365,11 +400,16 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
     static_for<0, NB>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
       f4 cn = carry;                              // carry of block q+1
-      static_for<0, 3 + 6 * NT>([&](auto sc) {
+      static_for<0, 3 + 6 * NT + (PB_MFMA_YMAT ? 4 : 0)>([&](auto sc) {
         constexpr int sl = decltype(sc)::value;
         // -- the matrix instruction of this slot
         if constexpr (sl < 3) {                     // carry of block q+1: + S (sum of block q+1-NT)
           if constexpr (q >= NT - 1 && q + 1 < NB) cn = mfma_part(Ff, wf[q >= NT - 1 ? q - (NT - 1) : 0], cn, sl);
+        } else if constexpr (sl >= 3 + 6 * NT) {    // PB_MFMA_YMAT: - 2^a sigma y of block q (hi, then lo part)
+#if PB_MFMA_YMAT
+          constexpr int e = sl - (3 + 6 * NT), r = e & 1;
+          acc[q][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Eh[r], (e >> 1) == 0 ? yf[q].hi : yf[q].lo, acc[q][r], 0, 0, 0);
+#endif
         } else {
           constexpr int c = sl - 3, r = c & 1, k = c >> 1, o = k / 3;      // near tile o: block q-o
           if constexpr (q >= o) acc[q][r] = mfma_part(An[r][o], wf[q >= o ? q - o : 0], acc[q][r], k - 3 * o);
