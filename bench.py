@@ -398,6 +398,18 @@ def run(args):
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "hbm_traffic_GBps": (traffic / (dom_ms * 1e-3) / 1e9) if traffic else None,
                      **({"matrix_pipe": mfma_block} if mfma_block else {}),
+                     # the two forms the measurement contract names, side by side (ALGORITHMIC work / duration):
+                     "contract_forms": {
+                         "hbm": {"bound": "hbm", "achieved": hbm_alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": hbm_alg_gbs / HBM_PEAK_GBS, "traffic": traffic},
+                         **({"mfma": {"bound": "mfma", "achieved": valu_tflops, "peak": MFMA_F16_PEAK_TFLOPS,
+                                      "unit": "TFLOP/s", "frac": valu_tflops / MFMA_F16_PEAK_TFLOPS,
+                                      "frac_executed": mfma_block["frac_of_dense_f16_peak"], "traffic": traffic,
+                                      "dtype": "f16 operands (3 split products), f32 accumulation"}} if mfma_block else {})},
+                     "binding": ("issue of ONE wave per SIMD: 993 vector + 276 matrix instructions per 16 voxel-iterations "
+                                 "(profiles/r3_pmc_sq.json: 0.63 of the cycles issuing, 0.20 waiting on matrix results; matrix "
+                                 "pipe busy 0.55) -- neither HBM nor the MFMA peak" if mfma_block else
+                                 "vector issue (VALU busy 98 %, profiles/r2_pmc_sq_valu_utilisation.json)"),
                      "note": "dominant kernel of the step (kernel_problems of the problems; the rest "
                              "runs in a second, short launch: config.launches_per_step; "
                              "step_kernels_ms = both). Register-resident multi-iteration kernel, "
@@ -511,8 +523,9 @@ def run_config4(args, world, rank, dev, dist, V, V_total, lo, timed, timed_local
     V_dom = n_main if n_main > 0 else V
     Wd = torch.zeros((V_dom, N), dtype=torch.float64, device=dev)
     Yd = Y[:V_dom]
+    matrix_pipe = "matrix pipe" in (main_kernel if n_main else tail_kernel)
     _, dom_ms = timed_local(lambda: solver.fista_solve_pp(Yd, taps, stepc, lbda, nb_inner, W0=Wd, inplace=True,
-                                                          force="fast2"), 10, 2, 0.05)
+                                                          force="intermediate" if matrix_pipe else "fast2"), 10, 2, 0.05)
     flops_launch = flops_per_voxel_iter(N, K) * float(V_dom) * nb_inner
     exec_launch = executed_flops_per_voxel_iter(N, K) * float(V_dom) * nb_inner
     alg_bytes = BYTES_PER_VOXEL_ITER_PER_SCAN * N * float(V_dom) * nb_inner
@@ -558,9 +571,13 @@ def run_config4(args, world, rank, dev, dist, V, V_total, lo, timed, timed_local
                      "hbm_algorithmic_frac": alg_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "whole_job_valu_frac": flops_per_voxel_iter(N, K) * float(V) * n_z * nb_inner /
                                             (step_ms * 1e-3) / 1e12 / VALU_FP32_PEAK_TFLOPS,
+                     "kernel": main_kernel if n_main else tail_kernel,
                      "note": "dominant kernel = one z-step launch (100 iterations, warm start read from and written "
-                             "to HBM) of the pair form with the HRF in device memory; whole_job_valu_frac prices the "
-                             "whole bd_shared call (theta-steps, all-reduce and launch gaps included) the same way"},
+                             "to HBM) on the whole rounds of the batch, HRF and step read from device memory (matrix-pipe "
+                             "form where the shape allows, else the pair form; incl. the 6 us re-solve launch); "
+                             "whole_job_valu_frac prices the whole bd_shared call (theta-steps, all-reduce and launch "
+                             "gaps included) the same way; `frac` > 1 is possible on the matrix-pipe form for the reason "
+                             "given in the config-3 line (roofline.binding there)"},
     }
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         # parity of the WHOLE loop on a sub-batch: GPU vs the float64 NumPy oracle, same 48 voxels, 3 outer iterations
