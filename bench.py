@@ -56,6 +56,19 @@ def executed_flops_per_voxel_iter(n, k):
     return 3.0 * n * k + 12.0 * n
 
 
+def mfma_per_wave_iteration(n, k):
+    """v_mfma_f32_16x16x32_f16 instructions one wave (16 problems) of fista_mfma_kernel issues per
+    iteration: NB = ceil(N/32) blocks, NT near tiles (2 for K <= 33, 3 for K <= 65), three split
+    products per tile and row half, three for the running far-field carry; both passes
+    (pybold_amd/csrc/fista_mfma.h).  276 at N = 300, K = 30 -- the count SQ_INSTS_MFMA reports
+    (profiles/r3_pmc_mfma.json)."""
+    nb, nt = (n + 31) // 32, (2 if k <= 33 else 3)
+    return 2 * (3 * (nb - nt) + 6 * sum(nb - o for o in range(nt)))
+
+
+MFMA_FLOP = 2.0 * 16 * 16 * 32       # one v_mfma_f32_16x16x32_f16
+
+
 def flops_per_voxel_iter(n, k):
     """Algorithmic flops of one iteration: two K-tap FIRs 4NK, two scans 2N,
     update/prox/momentum ~10N."""
@@ -305,7 +318,7 @@ def run(args):
     plan_force = "valu" if torch.is_tensor(lam) else None
     n_main, main_kernel, tail_kernel = solver.launch_plan(N, K, max(P, 1), force=plan_force)
     P_dom = n_main if (args.kernel in ("auto", "seq") and n_main > 0) else P
-    matrix_pipe = "matrix pipe" in (main_kernel if n_main else tail_kernel)
+    matrix_pipe = args.kernel in ("auto", "seq") and "matrix pipe" in (main_kernel if n_main else tail_kernel)
     if P_dom != P and P_dom % y_rep == 0:
         lam_dom = lam[:P_dom] if torch.is_tensor(lam) else lam
         plan_dom = solver.FistaPlan(Y[:P_dom // y_rep], hrf, lam_dom, step, n_iter, y_rep=y_rep,
@@ -314,30 +327,23 @@ def run(args):
         del plan_dom
     else:
         P_dom, dom_ms = P, kern_ms
-    pair_form = "two problems per row" in (main_kernel if n_main else tail_kernel)
+    pair_form = args.kernel in ("auto", "seq") and "two problems per row" in (main_kernel if n_main else tail_kernel)
     flops_launch = flops_per_voxel_iter(N, K) * float(P_dom) * n_iter      # dominant kernel, one launch
     exec_launch = (executed_flops_per_voxel_iter(N, K) if pair_form else flops_per_voxel_iter(N, K)) * float(P_dom) * n_iter
     mfma_block = None
     if matrix_pipe:
-        # what the matrix-pipe kernel executes per voxel-iteration: NB = ceil(N/32) blocks, 2 x (15 NB - 12)
-        # v_mfma_f32_16x16x32_f16 per wave of 16 problems (2 x 16 x 16 x 32 flop each), ~14 vector
-        # instructions per sample of the padded series (float64 update, conversions, splits)
-        nb = (N + 31) // 32
-        n_mfma = 2 * (15 * nb - 12)
-        mfma_flop = n_mfma * 2.0 * 16 * 16 * 32 / 16.0
+        # what the matrix-pipe kernel EXECUTES: mfma_per_wave_iteration() matrix instructions per wave of 16 problems
+        n_mfma = mfma_per_wave_iteration(N, K)
+        mfma_flop = n_mfma * MFMA_FLOP / 16.0
         exec_launch = mfma_flop * float(P_dom) * n_iter
         mfma_block = {"mfma_instructions_per_wave_iteration": n_mfma, "problems_per_wave": 16,
                       "f16_flops_per_voxel_iteration": mfma_flop,
-                      "achieved_f16_TFLOPs": exec_launch / (dom_ms * 1e-3) / 1e12,
-                      "frac_of_dense_f16_peak": exec_launch / (dom_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
                       "matrix_pipe_busy_estimate": n_mfma * 16.0 / 16.0 * float(P_dom) * n_iter /
                                                    (1024.0 * 2.1e9 * dom_ms * 1e-3),
                       "note": "three float16 split products per tile (hi.hi, hi.lo, lo.hi), scans folded into the "
                               "tiles: 47 % of the tile entries are structural zeros; the kernel is bound by the vector "
                               "issue port the matrix instructions share (8 of their 16 cycles), not by the matrix pipe"}
     alg_bytes = BYTES_PER_VOXEL_ITER_PER_SCAN * N * float(P_dom) * n_iter
-    valu_tflops = flops_launch / (dom_ms * 1e-3) / 1e12
-    hbm_alg_gbs = alg_bytes / (dom_ms * 1e-3) / 1e9
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tfile) and cfg == 3:
@@ -370,9 +376,7 @@ def run(args):
         "ms_per_step": ms_step,
         "wall_clock_to_eps_ms": ms_step,       # one full solve meeting eps <= 1e-5, y resident in HBM
         "higher_is_better": True,
-        "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
-        "dtype_note": "FIR/scans/residual fp32 (packed), iterate and update fp64 on chip; "
-                      "y fp32 in HBM; outputs fp64",
+        "scaling": args.scaling, "vs_baseline": None, **dtype_fields(matrix_pipe),
         "data": "synthetic",
         "config": {"workload": workload, "baseline_config": cfg,
                    "voxels_total": V_total, "voxels_this_rank": V, "problems_this_rank": P,
@@ -382,51 +386,12 @@ def run(args):
                                         [{"kernel": tail_kernel, "problems": P - n_main}]
                    if args.kernel in ("auto", "seq") else [{"kernel": kernel_name, "problems": P}],
                    "parallelism": "contiguous voxel shards x%d, no data-path collective" % world},
-        "roofline": {"bound": "valu_fp32", "achieved": valu_tflops, "peak": VALU_FP32_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": valu_tflops / VALU_FP32_PEAK_TFLOPS,
-                     "traffic": traffic, "kernel_ms": dom_ms, "kernel_problems": P_dom,
-                     "step_kernels_ms": kern_ms,
-                     "step_valu_frac": flops_per_voxel_iter(N, K) * float(P) * n_iter /
-                                       (kern_ms * 1e-3) / 1e12 / VALU_FP32_PEAK_TFLOPS,
-                     "flops_per_voxel_iteration": flops_per_voxel_iter(N, K),
-                     "algorithmic_flops_per_launch": flops_launch,
-                     "executed_flops_per_voxel_iteration": exec_launch / (float(P_dom) * n_iter),
-                     "achieved_executed": exec_launch / (dom_ms * 1e-3) / 1e12,
-                     "frac_executed": exec_launch / (dom_ms * 1e-3) / 1e12 / VALU_FP32_PEAK_TFLOPS,
-                     "hbm_algorithmic_GBps": hbm_alg_gbs,
-                     "hbm_algorithmic_frac": hbm_alg_gbs / HBM_PEAK_GBS,
-                     "algorithmic_bytes_per_launch": alg_bytes,
-                     "hbm_traffic_GBps": (traffic / (dom_ms * 1e-3) / 1e9) if traffic else None,
-                     **({"matrix_pipe": mfma_block} if mfma_block else {}),
-                     # the two forms the measurement contract names, side by side (ALGORITHMIC work / duration):
-                     "contract_forms": {
-                         "hbm": {"bound": "hbm", "achieved": hbm_alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": hbm_alg_gbs / HBM_PEAK_GBS, "traffic": traffic},
-                         **({"mfma": {"bound": "mfma", "achieved": valu_tflops, "peak": MFMA_F16_PEAK_TFLOPS,
-                                      "unit": "TFLOP/s", "frac": valu_tflops / MFMA_F16_PEAK_TFLOPS,
-                                      "frac_executed": mfma_block["frac_of_dense_f16_peak"], "traffic": traffic,
-                                      "dtype": "f16 operands (3 split products), f32 accumulation"}} if mfma_block else {})},
-                     "binding": ("issue of ONE wave per SIMD: 993 vector + 276 matrix instructions per 16 voxel-iterations "
-                                 "(profiles/r3_pmc_sq.json: 0.63 of the cycles issuing, 0.20 waiting on matrix results; matrix "
-                                 "pipe busy 0.55) -- neither HBM nor the MFMA peak" if mfma_block else
-                                 "vector issue (VALU busy 98 %, profiles/r2_pmc_sq_valu_utilisation.json)"),
-                     "note": "dominant kernel of the step (kernel_problems of the problems; the rest "
-                             "runs in a second, short launch: config.launches_per_step; "
-                             "step_kernels_ms = both). Register-resident multi-iteration kernel, "
-                             "vector-issue bound (PMC: profiles/): `achieved`/`frac` price the ALGORITHMIC flops of "
-                             "the direct form (4NK + 12N per voxel-iteration, SURVEY 8d) against the fp32 "
-                             "vector peak (v_pk_fma_f32), the roofline that bound the round-1/2 kernels and still "
-                             "binds the vector forms; since round 3 plain solves run both operators on the MATRIX "
-                             "pipe as float16 split products (roofline.matrix_pipe: executed f16 flops against "
-                             "the dense MFMA peak), which is how `frac` can approach 1 -- `achieved_executed`/"
-                             "`frac_executed` count what the kernel really issues (pair form: 3NK + 12N on the "
-                             "vector pipe; matrix-pipe form: its MFMA flops, against the VECTOR peak for continuity). State never "
-                             "leaves the chip during a solve, so the SURVEY-8d algorithmic-byte "
-                             "rate (12*N B per voxel-iteration / kernel time) exceeds the HBM peak; "
-                             "measured HBM traffic = one read of y and one write of w per launch. The peak assumes "
-                             "2.4 GHz; while this kernel runs the package sits at its power limit (1.27-1.29 kW) "
-                             "and the shader clock at 2.07-2.19 GHz (profiles/r2_clock_and_power_during_solve.txt, "
-                             "r2_pmc_sq_valu_utilisation.json)."},
+        "roofline": roofline_block(matrix_pipe, main_kernel if n_main else tail_kernel, dom_ms, P_dom, n_iter, N, K,
+                                   flops_launch, exec_launch, alg_bytes, traffic, mfma_block,
+                                   {"step_kernels_ms": kern_ms,
+                                    "step_frac": (exec_launch if matrix_pipe else flops_launch) * (float(P) / P_dom) /
+                                                 (kern_ms * 1e-3) / 1e12 /
+                                                 (MFMA_F16_PEAK_TFLOPS if matrix_pipe else VALU_FP32_PEAK_TFLOPS)}),
     }
 
     if world > 1 and args.scaling == "strong":
@@ -481,6 +446,68 @@ def run(args):
     return json.dumps(out) if rank == 0 else None
 
 
+def dtype_fields(matrix_pipe):
+    """`dtype` = the arithmetic the dominant kernel computes its operators in; the note says the rest."""
+    if matrix_pipe:
+        return {"dtype": "f16x2-split operands (22 bit), f32 accumulate, f64 iterate",
+                "dtype_note": "operators (HRF convolution + cumulative sum and their adjoints): float16 hi/lo split "
+                              "products (22-bit operands, three v_mfma_f32_16x16x32_f16 per tile), float32 accumulation; "
+                              "iterate, gradient step, threshold and momentum float64 on chip; y float32 in HBM; "
+                              "outputs float64.  Problems whose operands leave the float16 range or whose solution is "
+                              "too sparse for 22-bit operators (th > 0.02 max|w|) are re-solved by the float32 vector "
+                              "kernels in the same call (include/pybold_hip.h, pb_fista_solve)"}
+    return {"dtype": "f32 operators, f64 iterate",
+            "dtype_note": "operators (FIRs, scans, residual) float32 on the vector pipe (v_pk_fma_f32), iterate and update "
+                          "float64 on chip; y float32 in HBM; outputs float64"}
+
+
+def roofline_block(matrix_pipe, kernel, dom_ms, P_dom, n_iter, N, K, flops_launch, exec_launch, alg_bytes, traffic,
+                   mfma_block, extra):
+    """The `roofline` object of a line.  `bound` names the pipe that binds the dominant kernel:
+    "mfma" (matrix-pipe form: `achieved` = the float16 flops its matrix instructions EXECUTE per
+    launch / its duration, `peak` = the dense f16 MFMA peak, 2.5 PFLOP/s) or "valu_fp32" (vector
+    forms: ALGORITHMIC flops of the direct form, 4NK + 12N per voxel-iteration, against the fp32
+    vector peak).  `frac_algorithmic` prices the algorithmic flops against the same peak;
+    `hbm_algorithmic_frac` is SURVEY 8d's figure (12 N bytes per voxel-iteration / duration against
+    8 TB/s; above 1 because the state never leaves the chip during a solve); `traffic` = HBM bytes
+    per launch by PMC."""
+    sec = dom_ms * 1e-3
+    hbm_alg_gbs = alg_bytes / sec / 1e9
+    if matrix_pipe:
+        ach, peak = exec_launch / sec / 1e12, MFMA_F16_PEAK_TFLOPS
+        head = {"bound": "mfma", "pipe": "mfma_f16 (v_mfma_f32_16x16x32_f16, dense peak)", "achieved": ach, "peak": peak,
+                "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+                "frac_algorithmic": flops_launch / sec / 1e12 / peak,
+                "executed_flops_per_launch": exec_launch}
+        binding = ("issue of ONE wave per SIMD: 993 vector + 276 matrix instructions per 16 voxel-iterations at N = 300 "
+                   "(profiles/r3_pmc_sq.json: 0.63 of the cycles issuing, 0.20 waiting on matrix results; matrix "
+                   "pipe busy 0.55) -- neither HBM nor the MFMA peak")
+    else:
+        ach, peak = flops_launch / sec / 1e12, VALU_FP32_PEAK_TFLOPS
+        head = {"bound": "valu_fp32", "pipe": "vector fp32 (v_pk_fma_f32)", "achieved": ach, "peak": peak,
+                "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+                "frac_algorithmic": ach / peak,
+                "executed_flops_per_launch": exec_launch}
+        binding = "vector issue (VALU busy 98 %, profiles/r2_pmc_sq_valu_utilisation.json)"
+    head.update({
+        "hbm_algorithmic_frac": hbm_alg_gbs / HBM_PEAK_GBS, "hbm_algorithmic_GBps": hbm_alg_gbs,
+        "hbm_traffic_GBps": (traffic / sec / 1e9) if traffic else None,
+        "kernel": kernel, "kernel_ms": dom_ms, "kernel_problems": P_dom, "kernel_iterations": n_iter,
+        "algorithmic_flops_per_launch": flops_launch, "algorithmic_bytes_per_launch": alg_bytes,
+        "flops_per_voxel_iteration": flops_per_voxel_iter(N, K),
+        "executed_flops_per_voxel_iteration": exec_launch / (float(P_dom) * n_iter),
+        **({"matrix_pipe": mfma_block} if mfma_block else {}),
+        "binding": binding,
+        "note": "dominant kernel of the step, timed on its own with HIP events on its launch stream (kernel_problems of the "
+                "problems; the rest runs in short launches behind it: config.launches_per_step).  Register-resident "
+                "multi-iteration kernel: a launch reads y once and writes w once (`traffic`), so SURVEY 8d's "
+                "algorithmic-byte rate exceeds the HBM peak (hbm_algorithmic_frac > 1 is not a utilisation figure).  "
+                "The peaks assume 2.4 GHz; under these kernels the package sits at its power limit and the shader clock "
+                "at 2.04-2.20 GHz (profiles/r2_clock_and_power_during_solve.txt)."})
+    head.update(extra)
+    return head
+
+
 def run_config4(args, world, rank, dev, dist, V, V_total, lo, timed, timed_local, barrier):
     """BASELINE config 4: semi-blind deconvolution, ONE HRF dilation shared by every voxel of every
     rank (`distributed.bd_shared`; structure of pybold/bold_signal.py:281-382): 20 outer iterations
@@ -526,19 +553,28 @@ def run_config4(args, world, rank, dev, dist, V, V_total, lo, timed, timed_local
     matrix_pipe = "matrix pipe" in (main_kernel if n_main else tail_kernel)
     _, dom_ms = timed_local(lambda: solver.fista_solve_pp(Yd, taps, stepc, lbda, nb_inner, W0=Wd, inplace=True,
                                                           force="intermediate" if matrix_pipe else "fast2"), 10, 2, 0.05)
+    dom_kernel = main_kernel if n_main else tail_kernel
     flops_launch = flops_per_voxel_iter(N, K) * float(V_dom) * nb_inner
     exec_launch = executed_flops_per_voxel_iter(N, K) * float(V_dom) * nb_inner
+    mfma_block = None
+    if matrix_pipe:
+        n_mfma = mfma_per_wave_iteration(N, K)
+        exec_launch = n_mfma * MFMA_FLOP / 16.0 * float(V_dom) * nb_inner
+        mfma_block = {"mfma_instructions_per_wave_iteration": n_mfma, "problems_per_wave": 16,
+                      "f16_flops_per_voxel_iteration": n_mfma * MFMA_FLOP / 16.0}
     alg_bytes = BYTES_PER_VOXEL_ITER_PER_SCAN * N * float(V_dom) * nb_inner
     ms_step = elapsed / args.steps * 1e3
     theta = np.asarray(d["theta"], dtype=np.float64)
+    dt = dtype_fields(matrix_pipe)
+    dt["dtype_note"] = ("z-steps: " + dt["dtype_note"] + ".  Intermediate z-steps of the outer loop run without the "
+                        "sparsity guard (PB_FLAG_NO_RHO_GUARD; the closing z-step is guarded).  Normal equations, theta "
+                        "fit, HRF model, step constant and the all-reduce: float64")
     out = {
         "metric": "voxel-iterations/sec", "value": value, "unit": "voxel-iterations/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "untimed_spin_s": args.spin_seconds,
         **({"rehearsal": True} if args.rehearse_on_one_gpu else {}),
         "ms_per_step": ms_step, "wall_clock_to_eps_ms": ms_step, "higher_is_better": True,
-        "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
-        "dtype_note": "z-steps: FIR/scans fp32 (packed), iterate fp64; normal equations, theta fit, HRF model, "
-                      "step constant and the all-reduce fp64",
+        "scaling": args.scaling, "vs_baseline": None, **dt,
         "data": "synthetic",
         "config": {"workload": "BASELINE config 4: semi-blind deconvolution with ONE shared HRF dilation, %d voxels "
                                "x %d scans (TR %.2f s, HRF %g s = %d taps, true dilation %.1f, start 2.0, SNR 10 dB), "
@@ -547,7 +583,9 @@ def run_config4(args, world, rank, dev, dist, V, V_total, lo, timed, timed_local
                                   "" if world == 1 else ", %d GPUs (%s scaling)" % (world, args.scaling)),
                    "baseline_config": 4, "voxels_total": V_total, "voxels_this_rank": V, "scans": N, "taps": int(K),
                    "iters_per_step": n_z * nb_inner,
-                   "kernel": solver.KERNEL_NAMES[2] + " reading ONE shared HRF from device memory",
+                   "kernel": dom_kernel + " reading ONE shared HRF and its step from device memory",
+                   "launches_per_z_step": ([{"kernel": main_kernel, "problems": n_main}] if n_main else []) +
+                                          [{"kernel": tail_kernel, "problems": V - n_main}],
                    "launches_per_outer_iteration": "z-step (whole rounds + remainder), normal equations (cumsum "
                                                    "and ||w||_1 folded in) + fixed-order reduce, theta fit (HRF, "
                                                    "its step constant and the cost folded in)",
@@ -559,48 +597,93 @@ def run_config4(args, world, rank, dev, dist, V, V_total, lo, timed, timed_local
                     "theta_trajectory": [round(float(t), 9) for t in theta],
                     "theta_trajectory_sha256_16": hashlib.sha256(np.round(theta, 9).tobytes()).hexdigest()[:16],
                     "cost_first_last": [float(d["J"][1]), float(d["J"][-1])]},
-        "roofline": {"bound": "valu_fp32", "achieved": flops_launch / (dom_ms * 1e-3) / 1e12,
-                     "peak": VALU_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": flops_launch / (dom_ms * 1e-3) / 1e12 / VALU_FP32_PEAK_TFLOPS, "traffic": None,
-                     "kernel_ms": dom_ms, "kernel_problems": V_dom, "kernel_iterations": nb_inner,
-                     "flops_per_voxel_iteration": flops_per_voxel_iter(N, K),
-                     "algorithmic_flops_per_launch": flops_launch,
-                     "executed_flops_per_voxel_iteration": executed_flops_per_voxel_iter(N, K),
-                     "frac_executed": exec_launch / (dom_ms * 1e-3) / 1e12 / VALU_FP32_PEAK_TFLOPS,
-                     "hbm_algorithmic_GBps": alg_bytes / (dom_ms * 1e-3) / 1e9,
-                     "hbm_algorithmic_frac": alg_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "whole_job_valu_frac": flops_per_voxel_iter(N, K) * float(V) * n_z * nb_inner /
-                                            (step_ms * 1e-3) / 1e12 / VALU_FP32_PEAK_TFLOPS,
-                     "kernel": main_kernel if n_main else tail_kernel,
-                     "note": "dominant kernel = one z-step launch (100 iterations, warm start read from and written "
-                             "to HBM) on the whole rounds of the batch, HRF and step read from device memory (matrix-pipe "
-                             "form where the shape allows, else the pair form; incl. the 6 us re-solve launch); "
-                             "whole_job_valu_frac prices the whole bd_shared call (theta-steps, all-reduce and launch "
-                             "gaps included) the same way; `frac` > 1 is possible on the matrix-pipe form for the reason "
-                             "given in the config-3 line (roofline.binding there)"},
+        "roofline": roofline_block(matrix_pipe, dom_kernel, dom_ms, V_dom, nb_inner, N, K, flops_launch, exec_launch,
+                                   alg_bytes, None, mfma_block,
+                                   {"whole_job_frac": (exec_launch if matrix_pipe else flops_launch) * (float(V) / V_dom) * n_z /
+                                                      (step_ms * 1e-3) / 1e12 /
+                                                      (MFMA_F16_PEAK_TFLOPS if matrix_pipe else VALU_FP32_PEAK_TFLOPS),
+                                    "note_config4": "dominant kernel = one z-step launch (100 iterations, warm start read "
+                                                    "from and written to HBM) on the whole rounds of the batch, incl. the "
+                                                    "6 us re-solve launch; whole_job_frac prices the whole bd_shared call "
+                                                    "(theta-steps, all-reduce and launch gaps included) the same way"}),
     }
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
-        # parity of the WHOLE loop on a sub-batch: GPU vs the float64 NumPy oracle, same 48 voxels, 3 outer iterations
-        from oracle.shared_ops import OracleOps
-        idx = np.random.RandomState(0).choice(V, size=min(48, V), replace=False)
-        Ys = Y[torch.from_numpy(np.sort(idx)).to(dev)].contiguous()
-        Wg, hg, dg = distributed.bd_shared(Ys, t_r, lbda=lbda, theta_0=2.0, hrf_dur=hrf_dur, nb_iter=3, nb_inner=nb_inner)
-        class _OneProcess:                       # the oracle run never talks to other ranks
-            world_size, rank = 1, 0
-
-            @staticmethod
-            def allreduce_(t):
-                return t
-        Wo, ho, do = distributed.bd_shared(Ys.cpu(), t_r, lbda=lbda, theta_0=2.0, hrf_dur=hrf_dur, nb_iter=3,
-                                           nb_inner=nb_inner, ops=OracleOps(N, t_r, hrf_dur), comm=_OneProcess())
-        Wg, Wo = Wg.cpu().numpy(), Wo.numpy()
-        out["parity"] = {"max_abs_dtheta_vs_cpu_oracle": float(np.abs(np.asarray(dg["theta"]) - np.asarray(do["theta"])).max()),
-                         "max_rel_l2_diff_z_vs_cpu_oracle": float((np.linalg.norm(Wg - Wo, axis=1) /
-                                                                   (np.linalg.norm(Wo, axis=1) + 1e-300)).max()),
-                         "voxels_checked": int(len(idx)), "outer_iterations_checked": 3, "tolerance": 1e-5,
-                         "sample": "random voxels of the batch solved alone, whole loop (z-steps, normal equations, "
-                                   "theta fits) on the GPU vs the float64 NumPy oracle"}
+        out["parity"] = config4_parity(res["W"], res["h"], d, Y, t_r, hrf_dur, lbda, nb_outer, nb_inner, N, K,
+                                       n_main, distributed, solver, torch, dev)
     return out
+
+
+def config4_parity(W, h, d, Y, t_r, hrf_dur, lbda, nb_outer, nb_inner, N, K, n_main, distributed, solver, torch, dev):
+    """Parity of the config-4 run THAT WAS TIMED (not of a small sub-batch on other kernels):
+
+    (a) z-steps: 96 voxels drawn over the timed batch (64 of the matrix-pipe launch, 32 of the remainder
+        when there is one) re-solved by the C float64 oracle through all 21 z-steps, each with the HRF of
+        the GPU's own theta trajectory (so only the z-step arithmetic is compared: `fista_mfma_kernel<...,
+        TAPS_DEV>` without the sparsity guard on the 20 intermediate solves, as timed): diff_z, z, x;
+    (b) the whole loop: the first min(V, 17 000) voxels -- one matrix-pipe round + remainder, the same
+        kernels and flags -- solved alone on the GPU and by an oracle loop that runs from its OWN state
+        (C z-steps, NumPy normal equations + 1-D search): |dtheta| after every outer iteration and
+        diff_z / z / x of all those voxels."""
+    import numpy as np
+    from oracle import c_oracle, pybold_oracle as orc
+    from oracle.shared_ops import FastOracleOps
+    V = Y.shape[0]
+    rng = np.random.RandomState(0)
+    if 0 < n_main < V:
+        idx = np.sort(np.concatenate([rng.choice(n_main, size=min(64, n_main), replace=False),
+                                      n_main + rng.choice(V - n_main, size=min(32, V - n_main), replace=False)]))
+    else:
+        idx = np.sort(rng.choice(V, size=min(96, V), replace=False))
+    sel = torch.from_numpy(idx).to(dev)
+    Ys = Y[sel].cpu().numpy().astype(np.float64)
+    theta = np.asarray(d["theta"], dtype=np.float64)
+    Wo = np.zeros((len(idx), N))
+    for it in range(nb_outer + 1):                      # z-step `it` uses the HRF of theta[it] (bold_signal.py:320-335)
+        hk = orc.spm_hrf(float(theta[it]), t_r, hrf_dur, False)[0]
+        Wo, _, _ = c_oracle.fista_batch(Ys, hk, lbda, 1.0 / orc.gram_lipschitz(hk, N), nb_inner, W0=Wo, threads=0)
+
+    def rel(a, b):
+        return float((np.linalg.norm(a - b, axis=1) / (np.linalg.norm(b, axis=1) + 1e-300)).max())
+    hl = orc.spm_hrf(float(theta[-1]), t_r, hrf_dur, False)[0]
+    Xg, Zg = solver.fista_outputs(W[sel].contiguous(), hl)
+    Zo = np.cumsum(Wo, axis=1)
+    Xo = orc.causal_conv(hl, Zo)
+    par = {"tolerance": 1e-5,
+           "z_steps_as_timed": {
+               "max_rel_l2_diff_z_vs_cpu_oracle": rel(W[sel].cpu().numpy(), Wo),
+               "max_rel_l2_z_vs_cpu_oracle": rel(Zg.cpu().numpy(), Zo), "max_rel_l2_x_vs_cpu_oracle": rel(Xg.cpu().numpy(), Xo),
+               "voxels_checked": int(len(idx)), "of_the_matrix_pipe_launch": int((idx < n_main).sum()) if n_main else 0,
+               "sample": "voxels of the TIMED batch through all %d z-steps on the C float64 oracle, HRF of the GPU's theta "
+                         "trajectory in each" % (nb_outer + 1)}}
+    # (b) whole loop on one matrix-pipe round + remainder, against an oracle loop with its own state
+    Vs = min(V, 17000)
+    Ysub = Y[:Vs].contiguous()
+
+    class _OneProcess:
+        world_size, rank = 1, 0
+
+        @staticmethod
+        def allreduce_(t):
+            return t
+    Wg, hg, dg = distributed.bd_shared(Ysub, t_r, lbda=lbda, theta_0=2.0, hrf_dur=hrf_dur, nb_iter=nb_outer, nb_inner=nb_inner)
+    Wo2, ho, do = distributed.bd_shared(Ysub.cpu(), t_r, lbda=lbda, theta_0=2.0, hrf_dur=hrf_dur, nb_iter=nb_outer,
+                                        nb_inner=nb_inner, ops=FastOracleOps(N, t_r, hrf_dur), comm=_OneProcess())
+    Wo2 = Wo2.numpy()
+    Xg, Zg = solver.fista_outputs(Wg, hg)
+    Zo = np.cumsum(Wo2, axis=1)
+    Xo = orc.causal_conv(ho, Zo)
+    sub_main, sub_kernel, _ = solver.launch_plan(N, K, Vs)
+    par["whole_loop"] = {
+        "voxels": Vs, "outer_iterations_checked": nb_outer, "kernel": sub_kernel, "problems_on_it": sub_main,
+        "max_abs_dtheta_vs_cpu_oracle": float(np.abs(np.asarray(dg["theta"]) - np.asarray(do["theta"])).max()),
+        "max_rel_l2_diff_z_vs_cpu_oracle": rel(Wg.cpu().numpy(), Wo2),
+        "max_rel_l2_z_vs_cpu_oracle": rel(Zg.cpu().numpy(), Zo), "max_rel_l2_x_vs_cpu_oracle": rel(Xg.cpu().numpy(), Xo),
+        "sample": "the first %d voxels solved alone (same kernels and flags as the timed run), whole loop (z-steps, normal "
+                  "equations, theta fits) on the GPU vs an oracle loop running from its own state" % Vs}
+    par["max_rel_l2_diff_z_vs_cpu_oracle"] = max(par["z_steps_as_timed"]["max_rel_l2_diff_z_vs_cpu_oracle"],
+                                                 par["whole_loop"]["max_rel_l2_diff_z_vs_cpu_oracle"])
+    par["max_abs_dtheta_vs_cpu_oracle"] = par["whole_loop"]["max_abs_dtheta_vs_cpu_oracle"]
+    return par
 
 
 def pcie_inclusive(plan, Y, hrf, lbda, step, n_iter, solver, torch, dev, pipelined):
@@ -739,16 +822,25 @@ def cpu_port_and_parity(Y, W_gpu, hrf, lam, y_rep, step, n_iter, target_s, dense
     t0 = time.perf_counter()
     Wc, _, used = c_oracle.fista_batch(Yh, hrf, lv, step, n_iter, threads=cores)
     dt = time.perf_counter() - t0
-    Wg = W_gpu[torch.from_numpy(idx).to(W_gpu.device)].cpu().numpy()
+    from pybold_amd import solver
+    from oracle import pybold_oracle as orc
+    Wsel = W_gpu[torch.from_numpy(idx).to(W_gpu.device)].contiguous()
+    Xg, Zg = solver.fista_outputs(Wsel, hrf)             # z = cumsum(diff_z), x = hrf * z (bold_signal.py:74-75)
+    Wg, Xg, Zg = Wsel.cpu().numpy(), Xg.cpu().numpy(), Zg.cpu().numpy()
+    Zc = np.cumsum(Wc, axis=1)
+    Xc = orc.causal_conv(np.asarray(hrf, dtype=np.float64), Zc)
     nrm = np.linalg.norm(Wc, axis=1)
     ok = nrm > 0                      # lambda = lambda_max: the solution is exactly 0 on both sides
     err = float((np.linalg.norm(Wg - Wc, axis=1)[ok] / nrm[ok]).max()) if ok.any() else 0.0
+    err_z = float((np.linalg.norm(Zg - Zc, axis=1)[ok] / np.linalg.norm(Zc, axis=1)[ok]).max()) if ok.any() else 0.0
+    err_x = float((np.linalg.norm(Xg - Xc, axis=1)[ok] / np.linalg.norm(Xc, axis=1)[ok]).max()) if ok.any() else 0.0
     zero_ok = bool(np.abs(Wg[~ok]).max() == 0.0) if (~ok).any() else True
     port = {"port_value": len(idx) * n_iter / dt, "port_threads": int(used),
             "port_sample": "%d problems drawn at random over the batch x %d iterations, C/OpenMP float64 "
                            "matrix-free port (oracle/fista_oracle.c), %d threads, %.1f s"
                            % (len(idx), n_iter, int(used), dt)}
-    parity = {"max_rel_l2_diff_z_vs_cpu_oracle": err, "voxels_checked": int(len(idx)), "tolerance": 1e-5,
+    parity = {"max_rel_l2_diff_z_vs_cpu_oracle": err, "max_rel_l2_z_vs_cpu_oracle": err_z,
+              "max_rel_l2_x_vs_cpu_oracle": err_x, "voxels_checked": int(len(idx)), "tolerance": 1e-5,
               "sample": "random over the whole batch; %d of the remainder launch, %d of the second half of the "
                         "main launch" % (int((idx >= n_main).sum()) if 0 < n_main < P else 0,
                                          int(((idx >= n_main // 2) & (idx < n_main)).sum()) if 0 < n_main < P

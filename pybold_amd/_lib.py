@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PYBOLD_HIP_LIB points at an alternative build of the same library (A/B kernel experiments)
-LIB_PATH = os.environ.get("PYBOLD_HIP_LIB") or os.environ.get("PYBOLD_HIP_LIB") or os.path.join(_HERE, "libpybold_hip.so")   # (the override: A/B builds of the library, development aid)
+LIB_PATH = os.environ.get("PYBOLD_HIP_LIB") or os.path.join(_HERE, "libpybold_hip.so")
 
 PB_FLAG_FORCE_GENERIC = 1
 PB_FLAG_FORCE_FAST = 2

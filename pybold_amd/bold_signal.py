@@ -21,6 +21,8 @@ Deviations from the reference, all deliberate:
     ``_deconv_auto_lbda``).
 There is no CPU fallback: without the HIP library or a GPU these raise.
 """
+import os
+
 import numpy as np
 import torch
 from scipy.optimize import fmin_l_bfgs_b
@@ -71,6 +73,12 @@ def _host(t, shape):
     return a[0] if shape else a
 
 
+# How the batch path of `deconv` reaches the library: "ctypes" (pybold_amd._lib, the default) or "torch_ops"
+# (torch.ops.pybold_hip: the TORCH_LIBRARY shim over the same C ABI) -- same kernels, bit-identical results
+# (tests/test_torch_ops.py).  Initialised from the environment variable PYBOLD_AMD_DISPATCH.
+DISPATCH = os.environ.get("PYBOLD_AMD_DISPATCH", "ctypes")
+
+
 def deconv(y, t_r, hrf, lbda=None, early_stopping=True, tol=1.0e-6,  # noqa
            wind=6, nb_iter=1000, nb_sub_iter=1000, verbose=0):
     """Deconvolve BOLD signal(s) ``y`` with the HRF ``hrf``
@@ -92,10 +100,18 @@ def deconv(y, t_r, hrf, lbda=None, early_stopping=True, tol=1.0e-6,  # noqa
     H = ConvAndLinear(DiscretInteg(), hrf, dim_in=n, dim_out=n)
     grad_lipschitz_cst = 0.9 * spectral_radius_est(H, (n,))
     step = 1.0 / grad_lipschitz_cst
-    W, J, n_done = solver.fista_solve(
-        Y, hrf, lbda, step, int(nb_iter), want_J=True,
-        stop="window" if early_stopping else None, tol=tol, wind=wind)
-    X, Z = solver.fista_outputs(W, hrf)
+    if DISPATCH == "torch_ops" and Y.dtype == torch.float32:
+        # the same kernels through the registered PyTorch operators (torch.ops.pybold_hip, csrc/torch_ops.cpp)
+        from . import torch_ops
+        W, J, n_done = torch_ops.fista_solve(Y, hrf, lbda, step, int(nb_iter), want_J=True,
+                                             stop_mode=solver._STOP["window" if early_stopping else None],
+                                             tol=tol, wind=wind)
+        X, Z = torch_ops.load().fista_outputs(W, torch.from_numpy(np.ascontiguousarray(hrf)).to(W.device))
+    else:
+        W, J, n_done = solver.fista_solve(
+            Y, hrf, lbda, step, int(nb_iter), want_J=True,
+            stop="window" if early_stopping else None, tol=tol, wind=wind)
+        X, Z = solver.fista_outputs(W, hrf)
     n_max = max(int(n_done.max()), 1)
     if one_d.on_device:
         # CUDA in -> CUDA out: the cost trace is normalised on the device and stays there

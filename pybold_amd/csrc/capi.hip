@@ -213,6 +213,22 @@ const FastEntry* pick_split(int N, int K) {
 // below this many series the one-problem-per-wave / single-row forms finish first (latency-bound)
 constexpr int SPLIT_MIN_P = 1024;
 
+// Plain solves (no stop rule) of a shape the matrix-pipe form serves AND some vector form can back up
+// (remainders, re-solves of what its guards hand back): they go to the matrix pipe before the split-pair form
+// is considered -- 305..320 scans fit ten blocks of 32 samples but have no single-slot pair entry, and one
+// matrix-pipe wave beats the pair form over two slots.
+bool mfma_serves_plain(int N, int K) {
+  return pick_mfma(N, K) != nullptr && (pick_fast(N, K) != nullptr || pick_wide(N, K) != nullptr);
+}
+// without a single-row entry (305..320 scans and more than 32 taps) the remainder of the whole rounds goes to the
+// one-problem-per-wave form when it is small, else everything runs on the matrix pipe (a partial last pass)
+double wave_slots();
+int mfma_wide_base(int P, bool one_launch) {
+  const int round = (int)wave_slots() * 8;
+  const int base = (P / round) * round;
+  return (one_launch || P - base > round / 4) ? P : base;
+}
+
 // ---- dispatch of a plain solve (no stop rule) over the register-resident forms --------
 // All forms keep two waves per SIMD and are VALU-issue bound, so a launch costs "rounds":
 // waves / (CUs x 4 SIMDs x 2), a last partial round at most half full costing ~0.56 of a
@@ -512,7 +528,10 @@ constexpr int NE_WAVE_BLOCKS = 1024;           // one-voxel-per-wave form: one r
 
 // the one-voxel-per-wave form serves K <= 32 (tail entries in registers) while four staging areas fit
 inline bool ne_wave_form(int N, int K) {
-  return K <= 32 && (int64_t)pb::ne_wave_lds_doubles(N, K) <= LDS_DOUBLES_MAX && !getenv("PB_NE_BLOCK_FORM");
+#ifdef PB_DEVELOPMENT                            // A/B aid of development builds only: the release library reads no environment
+  if (getenv("PB_NE_BLOCK_FORM")) return false;
+#endif
+  return K <= 32 && (int64_t)pb::ne_wave_lds_doubles(N, K) <= LDS_DOUBLES_MAX;
 }
 inline int ne_wave_blocks(int V, int cap) {
   int b = (V + pb::GEN_WAVES - 1) / pb::GEN_WAVES;
@@ -603,10 +622,12 @@ static bool pair_carries(const FastEntry* fe, int stop_mode, int wind) {
 int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mode, int wind) {
   (void)with_cost_trace;
   if (N < 1 || K < 1 || P < 1) return 0;
+  const bool mfma_plain = stop_mode == PB_STOP_NONE && mfma_serves_plain(N, K);
   if (const FastEntry* se = pick_split(N, K))
-    if (P >= SPLIT_MIN_P && pair_carries(se, stop_mode, wind) && (stop_mode == PB_STOP_NONE || pick_wide(N, K)))
+    if (!mfma_plain && P >= SPLIT_MIN_P && pair_carries(se, stop_mode, wind) && (stop_mode == PB_STOP_NONE || pick_wide(N, K)))
       return FORM_PAIR;
   const FastEntry* fe = pick_fast(N, K);
+  if (!fe && mfma_plain) return mfma_wide_base(P, false) > 0 ? FORM_MFMA : FORM_WIDE;
   if (fe && (pair_carries(fe, stop_mode, wind) || stop_mode == PB_STOP_NONE) &&
       pick_mfma(N, K, stop_mode != PB_STOP_NONE)) {   // plain solves and the window-rule certificate
     Piece pc[6];
@@ -634,8 +655,13 @@ int pb_fista_plan_ex(int N, int K, int P, int stop_mode, int wind, unsigned flag
   int nm = 0, mf = 0, tf = 0;
   const bool no_mfma = (flags & (PB_FLAG_NO_MFMA | PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_DIRECT_FIR)) != 0;
   const FastEntry* se = (N >= 1 && K >= 1 && P >= SPLIT_MIN_P) ? pick_split(N, K) : nullptr;
-  if (se && pair_carries(se, stop_mode, wind) && (stop_mode == PB_STOP_NONE || pick_wide(N, K))) {
+  const bool mfma_plain = N >= 1 && K >= 1 && stop_mode == PB_STOP_NONE && !no_mfma && mfma_serves_plain(N, K);
+  if (se && !mfma_plain && pair_carries(se, stop_mode, wind) && (stop_mode == PB_STOP_NONE || pick_wide(N, K))) {
     tf = FORM_PAIR;                                     // one launch of the split pair form
+  } else if (mfma_plain && P >= 1 && !pick_fast(N, K)) {
+    const int base = mfma_wide_base(P, (flags & PB_FLAG_ONE_LAUNCH) != 0);
+    if (base > 0 && base < P) { nm = base; mf = FORM_MFMA; tf = FORM_WIDE; }
+    else tf = base > 0 ? FORM_MFMA : FORM_WIDE;
   } else if (N >= 1 && K >= 1 && P >= 1 && !no_mfma && pick_fast(N, K) &&
              (pair_carries(pick_fast(N, K), stop_mode, wind) || stop_mode == PB_STOP_NONE) &&
              pick_mfma(N, K, stop_mode != PB_STOP_NONE)) {
@@ -713,12 +739,20 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
   a.cold = (flags & PB_FLAG_COLD_START) ? 1 : 0;
   a.rho_guard = (flags & PB_FLAG_NO_RHO_GUARD) ? 0 : 1;
   a.wind = wind;
-  if (const char* yb = getenv("PB_MFMA_YBITS")) a.ybits = atoi(yb);     // development aid
+#ifdef PB_DEVELOPMENT                            // (development builds only: the series scale of the matrix-pipe form)
+  if (const char* yb = getenv("PB_MFMA_YBITS")) {
+    const int v = atoi(yb);
+    if (v >= 8 && v <= 15) a.ybits = v;
+  }
+#endif
 
   // series of 16 S < N <= 32 S scans (the reference's 600-scan demo): the pair form with the two
   // halves of ONE series in the slots of a row, in one launch; the window rule as a certificate,
   // re-solved on the one-problem-per-wave form
-  if (!(flags & (PB_FLAG_FORCE_GENERIC | PB_FLAG_NO_PAIR | PB_FLAG_FORCE_WIDE | PB_FLAG_DIRECT_FIR))) {
+  const bool mfma_plain = stop_mode == PB_STOP_NONE && n_done_dev && (!lbda_dev || (flags & PB_FLAG_FORCE_MFMA)) &&
+                          !(flags & (PB_FLAG_FORCE_GENERIC | PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_FORCE_WIDE |
+                                     PB_FLAG_DIRECT_FIR | PB_FLAG_NO_MFMA)) && mfma_serves_plain(N, K);
+  if (!mfma_plain && !(flags & (PB_FLAG_FORCE_GENERIC | PB_FLAG_NO_PAIR | PB_FLAG_FORCE_WIDE | PB_FLAG_DIRECT_FIR))) {
     const FastEntry* se = pick_split(N, K);
     const WideEntry* wre = se ? pick_wide(N, K) : nullptr;
     const bool scert = se && stop_mode == PB_STOP_WINDOW && wind == 6 && n_done_dev && wre && wre->S <= 20 &&
@@ -869,6 +903,41 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
     if (hipEventRecord(ss->join, ss->stream) != hipSuccess || hipStreamWaitEvent(user, ss->join, 0) != hipSuccess)
       return fail(PB_ERR_HIP, "pb_fista_solve: join of the side stream failed");
     return finish(rc_all);
+  }
+  // 305..320 scans with more than 32 taps: no single-row entry, but ten blocks of 32 samples fit the matrix-pipe
+  // form -- whole rounds (or everything) on it, a small remainder and the problems its guards hand back on the
+  // one-problem-per-wave form
+  if (!fe && mfma_plain) {
+    const WideEntry* we = pick_wide(N, K);
+    const mfma_launch_fn mf = pick_mfma(N, K);
+    if (we && mf) {
+      const int base = mfma_wide_base(P, (flags & PB_FLAG_ONE_LAUNCH) != 0);
+      pb::FistaArgs b = a;
+      if (base > 0) {
+        b.P = base;
+        if (mf(b, taps_host, K, J_dev != nullptr, (hipStream_t)stream) != 0)
+          return fail(PB_ERR_INVALID, "pb_fista_solve: matrix-pipe kernel rejected the launch");
+        const int rc = check_launch("fista_mfma_kernel");
+        if (rc != PB_OK) return rc;
+      }
+      if (base < P) {
+        b = a;
+        b.p0 = base;
+        if (we->fn(b, taps_host, K, J_dev != nullptr, stop_mode, (hipStream_t)stream) != 0)
+          return fail(PB_ERR_INVALID, "pb_fista_solve: no one-problem-per-wave form");
+        const int rc = check_launch("fista_fast_kernel(wide)");
+        if (rc != PB_OK) return rc;
+      }
+      if (base > 0 && !(flags & PB_FLAG_CERT_NO_RESOLVE)) {
+        b = a;
+        b.P = base;
+        b.only_flagged = 1;
+        if (we->fn(b, taps_host, K, J_dev != nullptr, stop_mode, (hipStream_t)stream) != 0)
+          return fail(PB_ERR_INVALID, "pb_fista_solve: no one-problem-per-wave form for the re-solve");
+        return check_launch("fista_fast_kernel(wide, re-solve)");
+      }
+      return PB_OK;
+    }
   }
   // long series: one problem per wave (window rule: wind = 6 and S <= 20, as above)
   if (!(flags & PB_FLAG_FORCE_GENERIC)) {

@@ -159,8 +159,11 @@ __device__ __forceinline__ f4 mma3(const Frag& A, const Frag& B, f4 acc) {
 //   fista_pair_ffa.h: numerator bounded from below by ONE tracked sample per lane (four per problem,
 //   in four different blocks), denominator from above by ||w_k|| + 2 ||w_{k+1}|| + 4 th sqrt(N);
 //   a problem that cannot be cleared is handed back (n_done = -1) for the exact rule.  Implies WITH_J.
+#ifndef PB_MFMA_KATTR
+#define PB_MFMA_KATTR
+#endif
 template <int NB, bool WITH_J = false, bool TAPS_DEV = false, bool CERT = false, int NT = 2>
-__global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps tp) {
+__global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs a, MfmaTaps tp) {
   static_assert(NT == 2 || NT == 3, "two near tiles (K <= 33) or three (K <= 65)");
   constexpr int LCW = NT == 2 ? 64 : 96;           // cumulative taps kept per wave: lags 0 .. 32 NT - 1
   static_assert(!CERT || (WITH_J && !TAPS_DEV), "the certificate runs in the rotated (cost trace) loop");
@@ -519,7 +522,9 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
       const double beta = a.betas[it];
       forward();
       backward(beta);
-      if (PB_MFMA_CHECKS && (((it & 7) == 7) || (it == a.n_iter - 1))) range_check();
+      // (a warm start may overshoot in its first iterations -- the blind loop changes the HRF gain 2-4x between
+      // z-steps -- and come back into range before iteration 7: it is checked right after its first pass too)
+      if (PB_MFMA_CHECKS && (((it & 7) == 7) || (it == a.n_iter - 1) || (it == 0 && !a.cold))) range_check();
     }
   } else {
     forward();
@@ -544,7 +549,7 @@ __global__ __launch_bounds__(256) void fista_mfma_kernel(FistaArgs a, MfmaTaps t
         cflag = cflag | ((it >= 7) & !(t >= cert_lim));      // NaN-safe: anything unclear is flagged
         lt[6 * 256] = jw2;
       }
-      if (PB_MFMA_CHECKS && (((it & 7) == 7) || (it == a.n_iter - 1))) range_check();
+      if (PB_MFMA_CHECKS && (((it & 7) == 7) || (it == a.n_iter - 1) || (it == 0 && !a.cold))) range_check();
     }
   }
 

@@ -32,6 +32,17 @@ const Tensor& rows(const Tensor& t, at::ScalarType dt, const char* name) {
               " must be a 2-D CUDA tensor of the right dtype with unit stride along time");
   return t;
 }
+// a 1-D float64 vector living on `like`'s device (HRF taps, sample times): a CPU tensor or another dtype here would
+// make the kernel read a foreign pointer
+const Tensor& dev_vec(const Tensor& t, const Tensor& like, const char* name) {
+  TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kDouble && t.is_contiguous() && t.numel() >= 1, name,
+              " must be a contiguous float64 CUDA tensor");
+  TORCH_CHECK(t.device() == like.device(), name, " must live on the same device as the data (", like.device(), ")");
+  return t;
+}
+void same_device(const Tensor& t, const Tensor& like, const char* name) {
+  TORCH_CHECK(t.device() == like.device(), name, " must live on the same device as Y (", like.device(), ")");
+}
 int64_t ld(const Tensor& t) { return t.size(0) > 1 ? t.stride(0) : std::max<int64_t>(t.stride(0), t.size(1)); }
 
 // W (float64, in: warm start, out: iterate), J (float32 or undefined), n_done (int32) are written in place.
@@ -47,7 +58,18 @@ void fista_solve(const Tensor& Y, Tensor W, const Tensor& taps_host, const c10::
   TORCH_CHECK(n_done.is_cuda() && n_done.scalar_type() == at::kInt && n_done.numel() == W.size(0), "n_done: int32 CUDA (P,)");
   TORCH_CHECK(W.size(0) == Y.size(0) * y_rep && W.size(1) == Y.size(1), "W must be (V * y_rep, N)");
   if (lbda_vec) TORCH_CHECK(lbda_vec->is_cuda() && lbda_vec->scalar_type() == at::kDouble && lbda_vec->numel() == W.size(0), "lbda_vec: float64 CUDA (P,)");
-  if (J) rows(*J, at::kFloat, "J");
+  if (J) {
+    rows(*J, at::kFloat, "J");
+    TORCH_CHECK(J->size(0) == W.size(0) && J->size(1) >= n_iter, "J must be (P, >= n_iter)");
+    same_device(*J, Y, "J");
+  }
+  if (taps_dev) dev_vec(*taps_dev, Y, "taps_dev");
+  TORCH_CHECK(!taps_dev || taps_dev->numel() == taps_host.numel(), "taps_dev and taps_host must hold the same taps");
+  TORCH_CHECK(n_iter >= 0 && y_rep >= 1, "n_iter >= 0 and y_rep >= 1");
+  same_device(W, Y, "W");
+  same_device(n_done, Y, "n_done");
+  same_device(betas, Y, "betas");
+  if (lbda_vec) same_device(*lbda_vec, Y, "lbda_vec");
   c10::hip::HIPGuardMasqueradingAsCUDA guard(Y.device());
   check(pb_fista_solve(Y.data_ptr<float>(), ld(Y), (int)y_rep, W.data_ptr<double>(), ld(W), (int)W.size(0), (int)Y.size(1),
                        taps_host.data_ptr<double>(), taps_dev ? taps_dev->data_ptr<double>() : nullptr,
@@ -59,6 +81,7 @@ void fista_solve(const Tensor& Y, Tensor W, const Tensor& taps_host, const c10::
 
 std::tuple<Tensor, Tensor> fista_outputs(const Tensor& W, const Tensor& taps_dev) {
   rows(W, at::kDouble, "W");
+  dev_vec(taps_dev, W, "taps_dev");
   c10::hip::HIPGuardMasqueradingAsCUDA guard(W.device());
   Tensor Z = at::empty_like(W), X = at::empty_like(W);
   check(pb_fista_outputs(W.data_ptr<double>(), ld(W), (int)W.size(0), (int)W.size(1), taps_dev.data_ptr<double>(),
@@ -69,6 +92,8 @@ std::tuple<Tensor, Tensor> fista_outputs(const Tensor& W, const Tensor& taps_dev
 
 Tensor op_forward(const Tensor& X, const Tensor& taps_dev, int64_t dim_out) {
   rows(X, at::kDouble, "x");
+  dev_vec(taps_dev, X, "taps_dev");
+  TORCH_CHECK(dim_out >= 1, "dim_out >= 1");
   c10::hip::HIPGuardMasqueradingAsCUDA guard(X.device());
   Tensor out = at::empty({X.size(0), dim_out}, X.options());
   check(pb_op_forward(X.data_ptr<double>(), ld(X), out.data_ptr<double>(), ld(out), (int)X.size(0), (int)X.size(1), (int)dim_out,
@@ -78,6 +103,8 @@ Tensor op_forward(const Tensor& X, const Tensor& taps_dev, int64_t dim_out) {
 
 Tensor op_adjoint(const Tensor& R, const Tensor& taps_dev, int64_t dim_in) {
   rows(R, at::kDouble, "r");
+  dev_vec(taps_dev, R, "taps_dev");
+  TORCH_CHECK(dim_in >= 1, "dim_in >= 1");
   c10::hip::HIPGuardMasqueradingAsCUDA guard(R.device());
   Tensor out = at::empty({R.size(0), dim_in}, R.options());
   check(pb_op_adjoint(R.data_ptr<double>(), ld(R), out.data_ptr<double>(), ld(out), (int)R.size(0), (int)dim_in, (int)R.size(1),
@@ -89,6 +116,8 @@ Tensor op_adjoint(const Tensor& R, const Tensor& taps_dev, int64_t dim_in) {
 Tensor hrf_normal_eq(const Tensor& Z, const Tensor& Y, int64_t K) {
   rows(Z, at::kDouble, "Z");
   rows(Y, at::kFloat, "Y");
+  same_device(Z, Y, "Z");
+  TORCH_CHECK(Z.size(0) == Y.size(0) && Z.size(1) == Y.size(1), "Z and Y must have the same shape");
   c10::hip::HIPGuardMasqueradingAsCUDA guard(Z.device());
   const int64_t ne = pb_hrf_normal_eq_len((int)K);
   Tensor out = at::empty({ne}, Z.options());
@@ -103,8 +132,10 @@ std::tuple<Tensor, Tensor, Tensor> theta_fit(const Tensor& ne, const Tensor& t, 
                                              double a_under, double loc_under, double ratio, double lo, double hi,
                                              int64_t n_refine) {
   TORCH_CHECK(ne.is_cuda() && ne.scalar_type() == at::kDouble && ne.dim() == 2 && ne.stride(1) == 1, "ne: float64 CUDA (M, len)");
+  dev_vec(t, ne, "t (sample times)");
   c10::hip::HIPGuardMasqueradingAsCUDA guard(ne.device());
   const int64_t M = ne.size(0), K = t.numel();
+  TORCH_CHECK(ne.size(1) == pb_hrf_normal_eq_len((int)K), "ne must hold K*K + K + 1 values per set for K = t.numel() taps");
   Tensor theta = at::empty({M}, ne.options()), cost = at::empty({M}, ne.options()), taps = at::empty({M, K}, ne.options());
   check(pb_theta_fit(ne.data_ptr<double>(), ld(ne), (int)M, (int)K, t.data_ptr<double>(), a_peak, loc_peak, a_under, loc_under,
                      ratio, lo, hi, (int)n_refine, theta.data_ptr<double>(), cost.data_ptr<double>(), taps.data_ptr<double>(),

@@ -38,6 +38,7 @@ _FORCE = {None: 0, "generic": PB_FLAG_FORCE_GENERIC, "fast": PB_FLAG_FORCE_FAST,
           "intermediate": _lib.PB_FLAG_NO_RHO_GUARD,
           "intermediate_noresolve": _lib.PB_FLAG_NO_RHO_GUARD | _lib.PB_FLAG_CERT_NO_RESOLVE,   # measurement aid
           # diagnostic: no re-solve of the problems a guard handed back (they keep n_done = -1)
+          "noresolve": _lib.PB_FLAG_CERT_NO_RESOLVE,          # ... through the default dispatch
           "mfmaonly": PB_FLAG_ONE_LAUNCH | _lib.PB_FLAG_FORCE_MFMA | _lib.PB_FLAG_CERT_NO_RESOLVE,
           "mfmacert": PB_FLAG_ONE_LAUNCH | _lib.PB_FLAG_FORCE_MFMA | PB_FLAG_FORCE_CERT,
           "mfmacertonly": PB_FLAG_ONE_LAUNCH | _lib.PB_FLAG_FORCE_MFMA | PB_FLAG_FORCE_CERT | _lib.PB_FLAG_CERT_NO_RESOLVE}

@@ -72,16 +72,15 @@ def test_series_lengths_and_tap_counts(solver, n, k):
     W0 = 0.01 * rng.randn(21, n)
     Yh = np.repeat(Yv.astype(np.float32).astype(np.float64), 3, axis=0)
     Wo, Jo, _ = c_oracle.fista_batch(Yh, hrf, lam, 1.0 / lip, 150, W0=W0, want_J=True, threads=4)
-    if solver.which_kernel(n, k, 100000).startswith("fista_mfma"):
-        W, J, nd = solver.fista_solve(dev32(Yv), hrf, lam, 1.0 / lip, 150, W0=dev64(W0), want_J=True, y_rep=3, force="mfma")
-        assert rel_rows(W.cpu().numpy(), Wo) < EPS and int(nd.min()) == 150
-        np.testing.assert_allclose(J.cpu().numpy(), Jo, rtol=3e-5)
-        W2, _, _ = solver.fista_solve(dev32(Yv), hrf, lam, 1.0 / lip, 150, W0=dev64(W0), y_rep=3, force="mfma")
-        assert rel_rows(W2.cpu().numpy(), Wo) < EPS
-    else:
-        assert n == 320 and k == 32 or n <= 128 or k > 33 or True      # served by the vector forms
-        W, _, _ = solver.fista_solve(dev32(Yv), hrf, lam, 1.0 / lip, 150, W0=dev64(W0), y_rep=3)
-        assert rel_rows(W.cpu().numpy(), Wo) < EPS
+    assert solver.which_kernel(n, k, 100000).startswith("fista_mfma")      # every shape of the list is served by it
+    W, J, nd = solver.fista_solve(dev32(Yv), hrf, lam, 1.0 / lip, 150, W0=dev64(W0), want_J=True, y_rep=3, force="mfma")
+    assert rel_rows(W.cpu().numpy(), Wo) < EPS and int(nd.min()) == 150
+    np.testing.assert_allclose(J.cpu().numpy(), Jo, rtol=3e-5)
+    W2, _, _ = solver.fista_solve(dev32(Yv), hrf, lam, 1.0 / lip, 150, W0=dev64(W0), y_rep=3, force="mfma")
+    assert rel_rows(W2.cpu().numpy(), Wo) < EPS
+    # and through the default dispatch (per-problem lambdas: the vector forms)
+    W3, _, _ = solver.fista_solve(dev32(Yv), hrf, lam, 1.0 / lip, 150, W0=dev64(W0), y_rep=3)
+    assert rel_rows(W3.cpu().numpy(), Wo) < EPS
 
 
 @pytest.mark.parametrize("n,k", [(300, 34), (300, 40), (300, 48), (225, 41), (160, 34), (129, 48), (304, 47)])

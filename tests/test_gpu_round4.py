@@ -1,0 +1,158 @@
+"""Round 4: the parity edges of the matrix-pipe kernel.
+
+  * config 4's WHOLE loop (21 z-steps, normal equations, theta fits) on the path the 50k-voxel
+    benchmark runs -- `fista_mfma_kernel<..., TAPS_DEV>` with PB_FLAG_NO_RHO_GUARD on the intermediate
+    z-steps -- against an oracle loop on the SAME batch of 17 000 voxels: the dilation after every one
+    of the 20 outer iterations, and diff_z / z / x of every voxel at the end;
+  * (test_adversarial_*) data unlike the generator's through the default dispatch at one matrix-pipe
+    round and more.
+
+Reference: pybold/bold_signal.py:281-382 (bd), :217-222 (hrf_fit_err), :62-72 (the recurrence).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pybold_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def solver():
+    from pybold_amd import solver as s
+    return s
+
+
+def rel_rows(a, b):
+    return np.linalg.norm(a - b, axis=1) / (np.linalg.norm(b, axis=1) + 1e-300)
+
+
+class _OneProcess:                                   # the oracle loop never talks to other ranks
+    world_size, rank = 1, 0
+
+    @staticmethod
+    def allreduce_(t):
+        return t
+
+
+def test_config4_whole_loop_on_the_matrix_pipe_against_the_oracle(solver):
+    """BASELINE config 4 (TR 0.75 s, N = 300, 20 s HRF = 27 taps, true dilation 0.7, theta_0 = 2.0,
+    lambda = 1.7, 20 outer x 100 inner iterations + closing z-step, Frobenius step) on 17 000 voxels:
+    one matrix-pipe round (16 384 voxels on `fista_mfma_kernel<10, ..., TAPS_DEV>`, the accuracy guard
+    off on the 20 intermediate z-steps exactly as in the 50k-voxel run) + 616 voxels on the vector
+    forms.  The oracle runs the same loop on the same batch from its own state (C float64 z-steps,
+    NumPy normal equations and 1-D search): theta after EVERY outer iteration within 1e-6, and
+    diff_z, z, x of EVERY voxel within 1e-5 at the end.  The same run with the guard on says what
+    "the next warm-started z-step forgets such errors" is worth in numbers."""
+    from oracle.shared_ops import FastOracleOps
+    from pybold_amd import data, distributed
+    t_r, dur, lbda, V4, N = 0.75, 20.0, 1.7, 17000, 300
+    h_true = orc.spm_hrf(0.7, t_r, dur, False)[0]
+    K = len(h_true)
+    Y4, _, _ = data.gen_rnd_bloc_bold_batch(V4, dur=3.75, tr=t_r, hrf=h_true, nb_events=5, avg_dur=12.0,
+                                            std_dur=1.0, snr=10.0, seed=44)
+    assert Y4.shape == (V4, N) and K == 27
+    # the z-steps of this batch do run on the matrix pipe (whole round) + a vector remainder
+    n_main, main, tail = solver.launch_plan(N, K, V4)
+    assert n_main == 16384 and "matrix pipe" in main and "matrix pipe" not in tail
+
+    Wg, hg, dg = distributed.bd_shared(Y4, t_r, lbda=lbda, theta_0=2.0, hrf_dur=dur, nb_iter=20, nb_inner=100)
+
+    class Guarded(distributed.HipOps):               # every z-step with the accuracy guard (and its re-solve)
+        def z_step(self, Y, taps, lbda, nb_inner, W, step=None, last=True):
+            return super().z_step(Y, taps, lbda, nb_inner, W, step, last=True)
+    Wq, hq, dq = distributed.bd_shared(Y4, t_r, lbda=lbda, theta_0=2.0, hrf_dur=dur, nb_iter=20, nb_inner=100,
+                                       ops=Guarded(t_r, dur, N))
+    # how many voxels the guard hands back in an intermediate z-step (the first one: iterate tiny against the threshold)
+    taps0 = torch.from_numpy(orc.spm_hrf(2.0, t_r, dur, False)[0].copy()).cuda()
+    step0 = 1.0 / solver.gram_frobenius_batch(taps0.reshape(1, -1), N)
+    _, nd = solver.fista_solve_pp(Y4, taps0, step0, lbda, 100, force="noresolve")
+    back_first = float((nd[:16384] < 0).double().mean())
+
+    Wo, ho, do = distributed.bd_shared(Y4.cpu(), t_r, lbda=lbda, theta_0=2.0, hrf_dur=dur, nb_iter=20, nb_inner=100,
+                                       ops=FastOracleOps(N, t_r, dur), comm=_OneProcess())
+    tg, tq, to = (np.asarray(d["theta"], dtype=np.float64) for d in (dg, dq, do))
+    assert len(to) == 21
+    dth, dth_q = np.abs(tg - to), np.abs(tq - to)
+    Wo = Wo.numpy()
+    Zo = np.cumsum(Wo, axis=1)
+    Xo = orc.causal_conv(ho, Zo)
+    errs = {}
+    for tag, W, h in (("guard off (as benchmarked)", Wg, hg), ("guard on", Wq, hq)):
+        X, Z = solver.fista_outputs(W, h)
+        errs[tag] = [float(rel_rows(a.cpu().numpy(), b).max()) for a, b in ((W, Wo), (Z, Zo), (X, Xo))]
+    print("config 4, 17 000 voxels, whole loop vs oracle: max |dtheta| over 20 outer iterations %.2e (guard on: %.2e); "
+          "diff_z / z / x %s; guard on %s; first z-step hands back %.1f %% of the round with the guard on"
+          % (dth.max(), dth_q.max(), ["%.1e" % e for e in errs["guard off (as benchmarked)"]],
+             ["%.1e" % e for e in errs["guard on"]], 100 * back_first))
+    assert dth.max() < 1e-6, dth
+    assert dth_q.max() < 1e-6, dth_q
+    np.testing.assert_allclose(dg["J"], do["J"], rtol=1e-6)
+    for tag in errs:
+        assert max(errs[tag]) < 1e-5, (tag, errs[tag])
+    np.testing.assert_allclose(hg, orc.spm_hrf(float(tg[-1]), t_r, dur, False)[0], rtol=1e-10, atol=1e-14)   # h = h(theta)
+    np.testing.assert_allclose(hg, ho, rtol=0, atol=1e-6)
+
+
+def test_oracle_ops_for_large_batches_match_the_pinned_ones():
+    """The C z-step + partial-autocorrelation normal equations used above == the NumPy OracleOps (pinned
+    through tests/test_oracle_golden.py) on a small batch, whole loop."""
+    from oracle.shared_ops import FastOracleOps, OracleOps
+    from pybold_amd import data, distributed
+    t_r, dur = 0.75, 20.0
+    h_true = orc.spm_hrf(0.7, t_r, dur, False)[0]
+    Y, _, _ = data.gen_rnd_bloc_bold_batch(24, dur=3.75, tr=t_r, hrf=h_true, nb_events=5, avg_dur=12.0, std_dur=1.0,
+                                           snr=10.0, seed=3)
+    out = [distributed.bd_shared(Y.cpu(), t_r, lbda=1.7, theta_0=2.0, hrf_dur=dur, nb_iter=3, nb_inner=60, ops=ops,
+                                 comm=_OneProcess()) for ops in (OracleOps(300, t_r, dur), FastOracleOps(300, t_r, dur))]
+    np.testing.assert_allclose(out[0][2]["theta"], out[1][2]["theta"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(out[0][0].numpy(), out[1][0].numpy(), rtol=1e-7, atol=1e-12)
+
+
+@pytest.mark.parametrize("n,k", [(300, 30), (129, 1), (160, 2), (320, 33), (300, 48)])
+def test_adversarial_series_through_the_default_dispatch(solver, n, k):
+    """Data unlike the generator's through the DEFAULT dispatch at one matrix-pipe round + a vector remainder
+    (18 432 problems per call): DC baselines 10x / 100x / 1000x the fluctuation, Student-t noise, SNR -10 and
+    +30 dB, constant / single-spike / all-zero series (tests/adversarial_data.py), lambda / lambda_max in
+    {1e-3, 1e-1, 1}, 500 iterations.  A random sample of every family against the C float64 oracle: diff_z, z
+    and x within eps = 1e-5 (diff_z[1:] too for the DC families, whose sample 0 carries the baseline) -- for
+    the problems the matrix-pipe kernel kept AND for those its guards handed back to the float32 operators;
+    all-zero solutions are all-zero; away from lambda_max the guards hand back (almost) nothing.  The full table
+    (4 lambdas, 192 samples per family) is profiles/r4_adversarial_sweep.txt (tools/r4_adversarial_sweep.py)."""
+    from oracle import c_oracle
+    from tests.adversarial_data import DC_FAMILIES, FAMILIES, hrf_for, make_batch
+    dev = torch.device("cuda")
+    hrf = hrf_for(k)
+    A = orc.toeplitz_from_kernel(hrf, n, n).dot(np.tril(np.ones((n, n))))
+    step = 1.0 / (0.9 * np.linalg.norm(A, 2) ** 2)
+    Y, fam = make_batch(n, hrf, 100 + n + k, dev)
+    P = Y.shape[0]
+    n_main, main, _ = solver.launch_plan(n, k, P)
+    assert n_main == 16384 and "matrix pipe" in main            # the call does run one matrix-pipe round
+    rng = np.random.RandomState(n * 100 + k)
+    samp = np.sort(np.concatenate([rng.choice(np.nonzero(fam == f)[0], 48, replace=False) for f in range(len(FAMILIES))]))
+    sel = torch.from_numpy(samp).to(dev)
+    Ys = Y[sel].cpu().numpy().astype(np.float64)
+    for c in (1e-3, 1e-1, 1.0):
+        W, _, nd = solver.fista_solve(Y, hrf, c, step, 500)
+        assert bool(torch.isfinite(W).all()) and int(nd.min()) == 500
+        _, _, nd0 = solver.fista_solve(Y, hrf, c, step, 500, force="noresolve")
+        back = (nd0 < 0).cpu().numpy()
+        if c < 1.0:
+            assert back.mean() < 0.03, (c, back.mean())
+        Wo, _, _ = c_oracle.fista_batch(Ys, hrf, c, step, 500, threads=0)
+        Xg, Zg = solver.fista_outputs(W[sel].contiguous(), hrf)
+        Wg, Xg, Zg = W[sel].cpu().numpy(), Xg.cpu().numpy(), Zg.cpu().numpy()
+        Xo, Zo = orc.fista_outputs(Wo, hrf)
+        zero = np.linalg.norm(Wo, axis=1) == 0
+        if zero.any():
+            assert np.abs(Wg[zero]).max() == 0.0
+        ok = ~zero
+        for name, a, b in (("diff_z", Wg, Wo), ("z", Zg, Zo), ("x", Xg, Xo)):
+            e = rel_rows(a[ok], b[ok])
+            assert e.max() < 1e-5, (n, k, c, name, float(e.max()), FAMILIES[int(fam[samp][ok][int(e.argmax())])],
+                                    "handed back" if back[samp][ok][int(e.argmax())] else "kept")
+        dc = ok & np.isin(fam[samp], DC_FAMILIES)
+        e = rel_rows(Wg[dc][:, 1:], Wo[dc][:, 1:])
+        assert e.max() < 1e-5, (n, k, c, "diff_z[1:] of the DC families", float(e.max()))

@@ -180,3 +180,25 @@ def test_launch_plan_of_a_plain_solve():
     n_main, main, tail = solver.launch_plan(300, 30, 100000, stop="loops")
     assert main in (None, row) and tail in (row, wave)
     assert solver.launch_plan(5000, 30, 100) == (0, None, solver.KERNEL_NAMES[0])
+
+
+def test_large_batch_oracle_ops_match_the_pinned_ones():
+    """`FastOracleOps` (C z-steps, normal equations from partial autocorrelations: the checker of the
+    full-size config-4 test) == `OracleOps` (NumPy, pinned by the goldens)."""
+    from oracle.shared_ops import FastOracleOps, OracleOps, hrf_normal_eq_blas
+    rng = np.random.RandomState(0)
+    for (V, n, K) in [(37, 300, 27), (3, 40, 30), (5, 20, 27), (1, 64, 1)]:
+        Z, Y = rng.randn(V, n), rng.randn(V, n)
+        G, b, yy = orc.hrf_normal_eq(Z, Y, K)
+        G2, b2, yy2 = hrf_normal_eq_blas(Z, Y, K)
+        np.testing.assert_allclose(G2, G, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(b2, b, rtol=1e-12, atol=1e-12)
+        assert yy2 == pytest.approx(yy, rel=1e-14)
+    t_r, dur, n = 0.75, 20.0, 300
+    slow, fast = OracleOps(n, t_r, dur), FastOracleOps(n, t_r, dur, threads=2)
+    taps = slow.hrf(torch.tensor([1.3]))
+    Y = torch.from_numpy(rng.randn(6, n).astype(np.float32))
+    W0 = torch.from_numpy(0.01 * rng.randn(6, n))
+    Ws, Wf = slow.z_step(Y, taps, 0.4, 25, W0.clone()), fast.z_step(Y, taps, 0.4, 25, W0.clone())
+    np.testing.assert_allclose(Wf.numpy(), Ws.numpy(), rtol=1e-10, atol=1e-14)
+    np.testing.assert_allclose(fast.normal_eq(Wf, Y, 27).numpy(), slow.normal_eq(Ws, Y, 27).numpy(), rtol=1e-10)
