@@ -62,6 +62,8 @@ extern "C" {
                                      back to the float32 operators.  For INTERMEDIATE solves of an outer loop (the z-steps
                                      of the blind loop but the last): their errors, relative 1e-5..1e-4 of a still tiny
                                      iterate, are forgotten by the warm-started solves that follow */
+#define PB_FLAG_FORCE_MFMA2 65536u /* the matrix-pipe form with every series split over two waves (fista_mfma2_kernel:
+                                     161..640 scans, HRFs of up to 33 taps, plain solves), one launch */
 #define PB_FLAG_NO_MFMA 8192u      /* plain solves: never the matrix-pipe form (fista_mfma_kernel), vector forms only */
 #define PB_FLAG_FORCE_CERT 1024u   /* PB_STOP_WINDOW, wind = 6: certificate path whatever tol * n_iter is */
 #define PB_FLAG_ONE_LAUNCH 32u    /* never split a plain solve into a full-rounds launch and a
@@ -151,6 +153,30 @@ int pb_fista_plan_ex(int N, int K, int P, int stop_mode, int wind, unsigned flag
  *            results are those of the full rule either way.  PB_FLAG_NO_CERT / _FORCE_CERT
  *            override the choice.  Other wind values, or series above 16*20 scans, evaluate the
  *            rule in full (single-row form; LDS kernel beyond its limits).
+ *
+ * ARITHMETIC.  The iterate, the gradient step, the threshold and the momentum are float64 in every
+ * kernel form; y is float32.  The two linear operators (H, H^T) run in one of two arithmetics:
+ *   (a) float32 on the vector pipe (fista_fast / fista_pair(_ffa) kernels), or
+ *   (b) on the matrix pipe (fista_mfma_kernel): operands split into two float16 parts (22 bits, low part
+ *       rounded to nearest), three v_mfma_f32_16x16x32_f16 products per tile, float32 accumulation; every
+ *       series scaled by a per-problem power of two into the float16 range (exact: the problem is
+ *       scale-covariant).
+ * (b) is chosen for plain solves (PB_STOP_NONE, or PB_STOP_WINDOW as a certificate with tol * n_iter < 0.02)
+ * of 129..320 scans with ONE lambda for the call (lbda_dev == NULL, or per-problem lambdas with the dense
+ * part of a regularisation path: see below) -- AND ONLY IF n_done_dev IS GIVEN: the matrix-pipe kernel
+ * reports through n_done the problems it must not keep, namely
+ *   - range: a residual fragment reached 2^15 or |sigma w| reached 60000 (checked after the first pass of a
+ *     warm start, every 8th iteration and at the end), and
+ *   - accuracy: the solution is too sparse for 22-bit operators, lbda * step > 0.02 * max|w| at the end (an
+ *     error eps in the gradient moves a solution entry by ~eps * threshold, so the relative error of ANY
+ *     arithmetic grows with threshold / max|w|; measured <= 3e-6 on diff_z below that bound, up to 1.5e-5
+ *     above 0.1; PB_FLAG_NO_RHO_GUARD switches this one off),
+ * leaves their iterate untouched (n_done = -1) and the same call re-solves them on (a) before it returns,
+ * so the caller only ever sees finished problems (n_done = n_iter).  With n_done_dev == NULL the call
+ * silently stays on (a): ~1.5x slower at 100k voxels, same results within 1e-6.  Either way the result
+ * is within 1e-5 (relative L2 per problem on diff_z, z, x) of the float64 reference recurrence
+ * (tests/test_gpu_round4.py: DC baselines up to 1000x the fluctuation, heavy tails, SNR -10..+30 dB,
+ * lambda / lambda_max in [1e-3, 1]; profiles/r4_adversarial_sweep.txt).
  */
 int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep,
                    double* w_dev, int64_t ldw, int P, int N,

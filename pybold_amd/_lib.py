@@ -26,6 +26,7 @@ PB_FLAG_CERT_NO_RESOLVE = 2048
 PB_FLAG_NO_MFMA = 8192
 PB_FLAG_FORCE_MFMA = 16384
 PB_FLAG_NO_RHO_GUARD = 32768
+PB_FLAG_FORCE_MFMA2 = 65536
 PB_STOP_NONE = 0
 PB_STOP_LOOPS = 1
 PB_STOP_WINDOW = 2

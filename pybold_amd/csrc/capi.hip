@@ -18,6 +18,7 @@
 #include "fista_exact.h"
 #include "blind.h"
 #include "fista_mfma.h"
+#include "fista_mfma2.h"
 
 namespace {
 
@@ -80,7 +81,26 @@ namespace pb {
 PB_MFMA(5) PB_MFMA(6) PB_MFMA(7) PB_MFMA(8) PB_MFMA(9) PB_MFMA(10)
 #undef PB_MFMA
 }
+namespace pb {
+#define PB_MFMA2(A, B) extern template int launch_mfma2<A, B>(const FistaArgs&, const double*, int, hipStream_t);
+PB_MFMA2(2, 3) PB_MFMA2(3, 3) PB_MFMA2(3, 4) PB_MFMA2(4, 4) PB_MFMA2(4, 5) PB_MFMA2(5, 5) PB_MFMA2(5, 6) PB_MFMA2(6, 6)
+PB_MFMA2(6, 7) PB_MFMA2(7, 7) PB_MFMA2(7, 8) PB_MFMA2(8, 8) PB_MFMA2(8, 9) PB_MFMA2(9, 9) PB_MFMA2(9, 10) PB_MFMA2(10, 10)
+#undef PB_MFMA2
+}
 namespace {
+// the matrix-pipe form with one series split over the two waves of a workgroup (fista_mfma2.h): nb = ceil(N / 32)
+// blocks, 5 <= nb <= 20 (129 .. 640 scans), floor(nb / 2) of them in the left wave; K <= 33; plain solves only
+typedef int (*mfma2_launch_fn)(const pb::FistaArgs&, const double*, int, hipStream_t);
+mfma2_launch_fn pick_mfma2(int N, int K) {
+  static const mfma2_launch_fn tab[] = {
+      &pb::launch_mfma2<2, 3>, &pb::launch_mfma2<3, 3>, &pb::launch_mfma2<3, 4>, &pb::launch_mfma2<4, 4>,
+      &pb::launch_mfma2<4, 5>, &pb::launch_mfma2<5, 5>, &pb::launch_mfma2<5, 6>, &pb::launch_mfma2<6, 6>,
+      &pb::launch_mfma2<6, 7>, &pb::launch_mfma2<7, 7>, &pb::launch_mfma2<7, 8>, &pb::launch_mfma2<8, 8>,
+      &pb::launch_mfma2<8, 9>, &pb::launch_mfma2<9, 9>, &pb::launch_mfma2<9, 10>, &pb::launch_mfma2<10, 10>};
+  const int nb = (N + 31) / 32;
+  if (K < 1 || K > 33 || nb < 5 || nb > 20) return nullptr;
+  return tab[nb - 5];
+}
 typedef int (*mfma_launch_fn)(const pb::FistaArgs&, const double*, int, bool, hipStream_t);
 // the matrix-pipe form (fista_mfma.h): NB = ceil(N / 32) blocks of 32 samples, 129 <= N <= 320; K <= 33
 // with two near tiles (every variant), 34 <= K <= 65 with three (`extras` = window-rule certificate:
@@ -246,7 +266,7 @@ int mfma_wide_base(int P, bool one_launch) {
 // exceeds half a round of pair waves, as a concurrent group (plan_pieces below).
 constexpr double COST_FAST1 = 0.63, COST_WIDE = 0.19, COST_PARTIAL = 0.56;
 constexpr double COST_LAUNCH = 0.03, COST_LAUNCH_WIDE = 0.05;
-enum Form { FORM_GENERIC = 0, FORM_FAST1 = 1, FORM_PAIR = 2, FORM_WIDE = 3, FORM_MFMA = 4 };
+enum Form { FORM_GENERIC = 0, FORM_FAST1 = 1, FORM_PAIR = 2, FORM_WIDE = 3, FORM_MFMA = 4, FORM_MFMA2 = 5 };
 
 double wave_slots() {
   static const double slots = [] {
@@ -427,11 +447,51 @@ int plan_pieces(int P, bool has_pair, bool has_wide, bool one_launch, bool one_s
 // ANY remainder launched on it costs a full round.  Whole rounds therefore go to the matrix pipe,
 // a remainder above half a round too; a smaller one keeps the plan of the vector forms
 // (plan_pieces: pair waves alone on their SIMDs, single-row and one-problem waves beside them).
-int plan_pieces_mfma(int P, bool has_pair, bool has_wide, bool one_launch, bool one_stream, Piece* out) {
+// A pass of the split form (fista_mfma2.h: 16 problems on TWO SIMDs, 8 192 problems per pass) lasts about 0.55 of a
+// one-wave pass (measured: profiles/r4_split_form_passes.txt).  With it (`has_mfma2`: plain solves without cost trace)
+// what the whole rounds leave is closed as
+//   R <= MFMA2_MIN_R                     the vector plan (latency-bound forms finish a few thousand problems sooner)
+//   MFMA2_MIN_R < R <= half a round      one pass of the split form
+//   half < R <= half + one-problem waves half a round on the split form, then the left-overs one problem per wave
+//   beyond                               one more pass of the one-wave form, as before
+constexpr int MFMA2_MIN_R = 4608;
+// Series of 321 .. 640 scans (11 .. 20 blocks) run on the split form from this many problems on (below, the
+// pair form over two slots or the latency-bound one-problem-per-wave form finish first: N = 600, 4 096 problems
+// 1.58 ms against 1.93, 8 192 2.87 against 1.97 -- profiles/r4_split_form_passes.txt); whole passes of 8 192
+// problems, a remainder above 5/16 of a pass too, a smaller one on the one-problem-per-wave form.
+constexpr int MFMA2_LONG_MIN_P = 5120;
+bool mfma2_serves_long(int N, int K) { return N > 320 && pick_mfma2(N, K) != nullptr && pick_wide(N, K) != nullptr; }
+int mfma2_long_base(int P, bool one_launch) {
+  const int pass = (int)wave_slots() * 4;            // 16 problems x (slots / 2 SIMDs / 2 waves)
+  const int base = (P / pass) * pass;
+  return (one_launch || P - base > pass * 5 / 16) ? P : base;
+}
+int plan_pieces_mfma(int P, bool has_pair, bool has_wide, bool one_launch, bool one_stream, bool has_mfma2, Piece* out) {
   const int round = (int)wave_slots() * 8;           // 16 problems x (slots / 2) waves
   const int whole = (P / round) * round;
   const int R = P - whole;
   int n = 0;
+  if (has_mfma2 && !one_launch && R > 0) {
+    const int half = round / 2, wide_max = (int)wave_slots();
+    if (R > MFMA2_MIN_R && R <= half) {
+      if (whole > 0) out[n++] = Piece{FORM_MFMA, 0, whole, false, false};
+      out[n++] = Piece{FORM_MFMA2, whole, P, false, false};
+      return n;
+    }
+    if (R > half && has_wide && R - half <= wide_max) {
+      // (the left-overs BESIDE the split-form pass, on the side stream: a wave of the N <= 320 split form holds 355
+      // registers, an 88-register one-problem wave fits next to it and issues in the gaps its barriers leave)
+      // ONE such wave per SIMD: with two, 355 + 2 x 88 registers no longer fit and the waves that wait block the
+      // placement of the two-wave workgroups (measured: 1 808 left-overs beside, 2.25 ms; 808, 1.15 ms; one after the
+      // other 1.62 / 1.41 ms, profiles/r4_split_form_passes.txt) -- left-overs beyond one per SIMD run behind the pass
+      if (whole > 0) out[n++] = Piece{FORM_MFMA, 0, whole, false, false};
+      const int beside = one_stream ? 0 : (R - half < wide_max / 2 ? R - half : wide_max / 2);
+      out[n++] = Piece{FORM_MFMA2, whole, whole + half, false, beside > 0};
+      if (beside > 0) out[n++] = Piece{FORM_WIDE, whole + half, whole + half + beside, true, true};
+      if (whole + half + beside < P) out[n++] = Piece{FORM_WIDE, whole + half + beside, P, false, false};
+      return n;
+    }
+  }
   // a remainder costs one matrix-pipe pass (1.74 ms per 500 iterations at N = 300) whatever its size; the
   // vector plan closes up to half a round of pair waves + one one-problem wave per SIMD beside them in
   // 1.55 ms, so it keeps remainders up to round/2 + round/16
@@ -623,6 +683,8 @@ int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mod
   (void)with_cost_trace;
   if (N < 1 || K < 1 || P < 1) return 0;
   const bool mfma_plain = stop_mode == PB_STOP_NONE && mfma_serves_plain(N, K);
+  const bool mfma2_ok = stop_mode == PB_STOP_NONE && !with_cost_trace && pick_mfma2(N, K) != nullptr;
+  if (mfma2_ok && mfma2_serves_long(N, K) && P >= MFMA2_LONG_MIN_P) return mfma2_long_base(P, false) > 0 ? FORM_MFMA2 : FORM_WIDE;
   if (const FastEntry* se = pick_split(N, K))
     if (!mfma_plain && P >= SPLIT_MIN_P && pair_carries(se, stop_mode, wind) && (stop_mode == PB_STOP_NONE || pick_wide(N, K)))
       return FORM_PAIR;
@@ -631,7 +693,7 @@ int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mod
   if (fe && (pair_carries(fe, stop_mode, wind) || stop_mode == PB_STOP_NONE) &&
       pick_mfma(N, K, stop_mode != PB_STOP_NONE)) {   // plain solves and the window-rule certificate
     Piece pc[6];
-    plan_pieces_mfma(P, fe->fn_pair != nullptr, pick_wide_small(N, K) != nullptr, false, false, pc);
+    plan_pieces_mfma(P, fe->fn_pair != nullptr, pick_wide_small(N, K) != nullptr, false, false, mfma2_ok, pc);
     return pc[0].form;
   }
   if (fe && stop_mode == PB_STOP_WINDOW && (!ring_wind(wind) || fe->S > 20)) fe = nullptr;
@@ -656,7 +718,14 @@ int pb_fista_plan_ex(int N, int K, int P, int stop_mode, int wind, unsigned flag
   const bool no_mfma = (flags & (PB_FLAG_NO_MFMA | PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_DIRECT_FIR)) != 0;
   const FastEntry* se = (N >= 1 && K >= 1 && P >= SPLIT_MIN_P) ? pick_split(N, K) : nullptr;
   const bool mfma_plain = N >= 1 && K >= 1 && stop_mode == PB_STOP_NONE && !no_mfma && mfma_serves_plain(N, K);
-  if (se && !mfma_plain && pair_carries(se, stop_mode, wind) && (stop_mode == PB_STOP_NONE || pick_wide(N, K))) {
+  const bool mfma2_ok = N >= 1 && K >= 1 && stop_mode == PB_STOP_NONE && !no_mfma && pick_mfma2(N, K) != nullptr;
+  if (mfma2_ok && mfma2_serves_long(N, K) && (P >= MFMA2_LONG_MIN_P || (flags & PB_FLAG_FORCE_MFMA2))) {
+    const int base = mfma2_long_base(P, (flags & (PB_FLAG_ONE_LAUNCH | PB_FLAG_FORCE_MFMA2)) != 0);
+    if (base > 0 && base < P) { nm = base; mf = FORM_MFMA2; tf = FORM_WIDE; }
+    else tf = base > 0 ? FORM_MFMA2 : FORM_WIDE;
+  } else if (mfma2_ok && (flags & PB_FLAG_FORCE_MFMA2) && P >= 1) {
+    tf = FORM_MFMA2;
+  } else if (se && !mfma_plain && pair_carries(se, stop_mode, wind) && (stop_mode == PB_STOP_NONE || pick_wide(N, K))) {
     tf = FORM_PAIR;                                     // one launch of the split pair form
   } else if (mfma_plain && P >= 1 && !pick_fast(N, K)) {
     const int base = mfma_wide_base(P, (flags & PB_FLAG_ONE_LAUNCH) != 0);
@@ -667,7 +736,7 @@ int pb_fista_plan_ex(int N, int K, int P, int stop_mode, int wind, unsigned flag
              pick_mfma(N, K, stop_mode != PB_STOP_NONE)) {
     Piece pc[6];
     const int npc = plan_pieces_mfma(P, pick_fast(N, K)->fn_pair != nullptr, pick_wide_small(N, K) != nullptr,
-                                     false, false, pc);
+                                     (flags & PB_FLAG_ONE_LAUNCH) != 0, (flags & PB_FLAG_ONE_STREAM) != 0, mfma2_ok, pc);
     int i = 1;
     while (i < npc && pc[i].form == pc[0].form) ++i;
     if (i < npc) {
@@ -752,6 +821,48 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
   const bool mfma_plain = stop_mode == PB_STOP_NONE && n_done_dev && (!lbda_dev || (flags & PB_FLAG_FORCE_MFMA)) &&
                           !(flags & (PB_FLAG_FORCE_GENERIC | PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_FORCE_WIDE |
                                      PB_FLAG_DIRECT_FIR | PB_FLAG_NO_MFMA)) && mfma_serves_plain(N, K);
+  // The matrix-pipe form with every series split over two waves (fista_mfma2.h): plain solves without cost trace.
+  // Series of 321..640 scans run on it from MFMA2_LONG_MIN_P problems on: whole passes (and a remainder above a
+  // quarter of a pass), the rest and whatever its guards hand back on the one-problem-per-wave form.  Shorter series
+  // meet it as a piece of the plan below (small batches, remainders) or through PB_FLAG_FORCE_MFMA2.
+  const mfma2_launch_fn mfma2 =
+      (stop_mode == PB_STOP_NONE && !J_dev && n_done_dev && (!lbda_dev || (flags & (PB_FLAG_FORCE_MFMA | PB_FLAG_FORCE_MFMA2))) &&
+       !(flags & (PB_FLAG_FORCE_GENERIC | PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_FORCE_WIDE | PB_FLAG_DIRECT_FIR |
+                  PB_FLAG_NO_MFMA))) ? pick_mfma2(N, K) : nullptr;
+  if (mfma2 && ((flags & PB_FLAG_FORCE_MFMA2) || (mfma2_serves_long(N, K) && P >= MFMA2_LONG_MIN_P))) {
+    const FastEntry* fe1 = pick_fast(N, K);
+    const WideEntry* we1 = pick_wide(N, K);
+    if (fe1 || we1) {
+      auto backup = [&](const pb::FistaArgs& b) -> int {     // the exact vector form behind it: single row, else one per wave
+        return (we1 && (!fe1 || N > 320)) ? we1->fn(b, taps_host, K, false, PB_STOP_NONE, (hipStream_t)stream)
+                                          : fe1->fn(b, taps_host, K, false, PB_STOP_NONE, (hipStream_t)stream);
+      };
+      const int base = (flags & PB_FLAG_FORCE_MFMA2) ? P : mfma2_long_base(P, (flags & PB_FLAG_ONE_LAUNCH) != 0);
+      pb::FistaArgs b = a;
+      if (base > 0) {
+        b.P = base;
+        if (mfma2(b, taps_host, K, (hipStream_t)stream) != 0)
+          return fail(PB_ERR_INVALID, "pb_fista_solve: split matrix-pipe kernel rejected the launch");
+        const int rc = check_launch("fista_mfma2_kernel");
+        if (rc != PB_OK) return rc;
+      }
+      if (base < P) {
+        b = a;
+        b.p0 = base;
+        if (backup(b) != 0) return fail(PB_ERR_INVALID, "pb_fista_solve: no vector form for the remainder");
+        const int rc = check_launch("fista_fast_kernel(remainder)");
+        if (rc != PB_OK) return rc;
+      }
+      if (base > 0 && !(flags & PB_FLAG_CERT_NO_RESOLVE)) {
+        b = a;
+        b.P = base;
+        b.only_flagged = 1;
+        if (backup(b) != 0) return fail(PB_ERR_INVALID, "pb_fista_solve: no vector form for the re-solve");
+        return check_launch("fista_fast_kernel(re-solve)");
+      }
+      return PB_OK;
+    }
+  }
   if (!mfma_plain && !(flags & (PB_FLAG_FORCE_GENERIC | PB_FLAG_NO_PAIR | PB_FLAG_FORCE_WIDE | PB_FLAG_DIRECT_FIR))) {
     const FastEntry* se = pick_split(N, K);
     const WideEntry* wre = se ? pick_wide(N, K) : nullptr;
@@ -807,6 +918,11 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
           return fail(PB_ERR_INVALID, "pb_fista_solve: matrix-pipe kernel rejected the launch");
         return check_launch("fista_mfma_kernel");
       }
+      if (form == FORM_MFMA2) {
+        if (!mfma2 || mfma2(b, taps_host, K, (hipStream_t)stream) != 0)
+          return fail(PB_ERR_INVALID, "pb_fista_solve: split matrix-pipe kernel rejected the launch");
+        return check_launch("fista_mfma2_kernel");
+      }
       if (form == FORM_PAIR && cert) {
         if (fe->fn_pair_cert(b, taps_host, K, (hipStream_t)stream) != 0)
           return fail(PB_ERR_INVALID, "pb_fista_solve: certificate kernel rejected the launch");
@@ -856,14 +972,14 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
     Piece pc[6];
     const bool one_stream = (flags & PB_FLAG_ONE_STREAM) != 0 || stream_is_capturing((hipStream_t)stream);
     const int npc = mfma ? plan_pieces_mfma(P, pair_ok, pick_wide_small(N, K) != nullptr,
-                                            (flags & PB_FLAG_ONE_LAUNCH) != 0, one_stream, pc)
+                                            (flags & PB_FLAG_ONE_LAUNCH) != 0, one_stream, mfma2 != nullptr, pc)
                          : plan_pieces(P, pair_ok, pick_wide_small(N, K) != nullptr,
                                        (flags & PB_FLAG_ONE_LAUNCH) != 0, one_stream, pc);
     bool any_side = false;
     int q0 = P, q1 = 0;                          // range of the pieces that may leave n_done = -1 (contiguous)
     for (int i = 0; i < npc; ++i) {
       any_side |= pc[i].side;
-      if ((pc[i].form == FORM_PAIR && cert) || pc[i].form == FORM_MFMA) {
+      if ((pc[i].form == FORM_PAIR && cert) || pc[i].form == FORM_MFMA || pc[i].form == FORM_MFMA2) {
         q0 = pc[i].p0 < q0 ? pc[i].p0 : q0;
         q1 = pc[i].p1 > q1 ? pc[i].p1 : q1;
       }
@@ -1314,13 +1430,21 @@ int pb_fista_solve_pp(const float* y_dev, int64_t ldy, double* w_dev, int64_t ld
         return check_launch(form == FORM_PAIR ? "fista_pair_ffa_kernel(shared taps)" : "fista_fast_kernel(pp)");
       };
       // whole rounds (and a remainder above half a round) on the matrix-pipe form, which reads the
-      // shared HRF and its step from device memory like the pair form (plan_pieces_mfma)
+      // shared HRF and its step from device memory like the pair form; what the whole rounds leave goes to the
+      // split form (fista_mfma2.h: half the latency for up to half a round) where plan_pieces_mfma would put it
       int base = 0;
       const mfma_launch_fn mfma = (n_done_dev && !(flags & (PB_FLAG_FORCE_PAIR | PB_FLAG_NO_MFMA))) ? pick_mfma(N, K) : nullptr;
+      const mfma2_launch_fn mfma2 = (mfma && K <= MFMA_K2) ? pick_mfma2(N, K) : nullptr;
+      int base2 = 0;                               // problems [base, base2) on the split form
       if (mfma) {
-        const int round = (int)wave_slots() * 8;
+        const int round = (int)wave_slots() * 8, half = round / 2;
         base = (P / round) * round;
-        if (P - base > round / 2 || (flags & PB_FLAG_ONE_LAUNCH)) base = P;
+        const int R = P - base;
+        base2 = base;
+        if (flags & PB_FLAG_ONE_LAUNCH) base = base2 = P;
+        else if (mfma2 && R > MFMA2_MIN_R && R <= half) base2 = P;
+        else if (mfma2 && ws && R > half && R - half <= (int)wave_slots()) base2 = base + half;
+        else if (R > half) base = base2 = P;
         if (base > 0) {
           pb::FistaArgs b = a;
           b.P = base;
@@ -1328,6 +1452,16 @@ int pb_fista_solve_pp(const float* y_dev, int64_t ldy, double* w_dev, int64_t ld
             return fail(PB_ERR_INVALID, "pb_fista_solve_pp: matrix-pipe kernel rejected the launch");
           const int rc = check_launch("fista_mfma_kernel(shared taps)");
           if (rc != PB_OK) return rc;
+        }
+        if (base2 > base) {
+          pb::FistaArgs b = a;
+          b.p0 = base;
+          b.P = base2;
+          if (mfma2(b, nullptr, K, (hipStream_t)stream) != 0)
+            return fail(PB_ERR_INVALID, "pb_fista_solve_pp: split matrix-pipe kernel rejected the launch");
+          const int rc = check_launch("fista_mfma2_kernel(shared taps)");
+          if (rc != PB_OK) return rc;
+          base = base2;
         }
       }
       if (base < P) {

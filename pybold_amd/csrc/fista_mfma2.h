@@ -1,0 +1,434 @@
+// The matrix-pipe form of the fused FISTA kernel (fista_mfma.h) with ONE series split over the TWO waves of a
+// workgroup: wave 0 ("left") owns blocks 0 .. NBA-1 of 32 samples, wave 1 ("right") blocks NBA .. NBA+NBB-1 of the
+// same 16 problems (NBB = NBA or NBA + 1: the left wave has the extra work of the exchange -- a float64 sum of its
+// updated iterate -- so an odd block goes to the right wave and that work hides in the left wave's slack).  Two uses:
+//   * series of 321 .. 640 scans (11 .. 20 blocks): they do not fit one wave (the float64 iterate alone would be
+//     304+ registers) -- the reference's own shipped demo is 600 scans (examples/synth_data/deconv.py:46);
+//   * small batches and remainders of 225 .. 320 scans: a pass of the one-wave form lasts what 16 problems x NB
+//     blocks last on ONE SIMD whatever the batch size; split over two SIMDs an iteration takes about half as long
+//     (8 192 problems per pass instead of 16 384).
+//
+// The operator is the one of fista_mfma.h (T_c = near band + constant far field, two near tiles, K <= 33), so the
+// two halves are coupled through very little, and both passes of an iteration run in BOTH waves at the same time:
+//   forward  (x = T_c w - y, ascending blocks): the right wave needs the float16 fragment of the left wave's LAST
+//            block (its near tile reaches one block back) and the far field of everything before it,
+//            S * sum(w over blocks 0 .. NBA-2) -- one scalar per problem;
+//   adjoint  (g = T_c^T r, descending blocks): the left wave needs the residual fragment of the right wave's FIRST
+//            block (already in LDS: every residual fragment waits there for the adjoint pass) and
+//            S * sum(r over blocks NBA+1 ..) -- one scalar per problem.
+// Those four items are produced at the END of the pass before: the left wave adds up its updated iterate in
+// float64 while it updates it (the order of a sum does not matter, so the descending adjoint pass can make the
+// ascending pass's prefix) and splits its last block -- the first one it updates -- at once; the right wave adds
+// up its residual samples as it finishes them.  Two workgroup barriers per iteration (phase boundaries), 2.3 KB of
+// LDS exchanged.  Everything else -- scaling, float16 split, guards, exact re-solve by capi.hip -- is fista_mfma.h's.
+//
+// Reference: pybold/bold_signal.py:62-72, pybold/linear.py:73-113, pybold/convolution.py:105-132.
+#pragma once
+#include "fista_mfma.h"
+
+namespace pb {
+
+// bytes of dynamic LDS of one workgroup (two waves; nbm = blocks of the larger half)
+constexpr size_t mfma2_lds_bytes(int nbm) {
+  return ((size_t)2 * nbm * 2 * 64 + 2 * 64) * sizeof(u4) + (size_t)(2 * 64 + 64 + 64 + 2 * 64 + 4 * 64) * sizeof(float);
+}
+
+// ROLE 0: the left wave (blocks 0 .. NBA-1), ROLE 1: the right wave (blocks NBA .. NBA+NBB-1; padding in its last block)
+template <int NBA, int NBB, bool TAPS_DEV, int ROLE>
+__device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& tp, char* smem) {
+  static_assert(NBB >= NBA && NBB <= NBA + 1 && NBA >= 2 && NBB <= 10, "right half = the larger one; two blocks at least per wave");
+  constexpr int NBM = NBB;                         // blocks of the larger half: the size of a wave's fragment area
+  constexpr int NT = 2, LCW = 64;
+  constexpr int NBW = ROLE == 0 ? NBA : NBB;       // blocks of this wave
+  constexpr int QOFF = ROLE == 0 ? 0 : NBA;        // its first block within the series
+  constexpr int NBT = NBA + NBB;
+  const int lane = threadIdx.x & 63;
+  const int v = lane & 15, g = lane >> 4;
+  const int prob = (int)blockIdx.x * 16 + v + a.p0;
+  const bool live = prob < a.P;
+  const int p = live ? prob : a.P - 1;
+  const int tb = 8 * g;
+
+  // ---- LDS: residual fragments of both waves, the exchange areas, the taps --------------------------------
+  u4* const lbase = reinterpret_cast<u4*>(smem);
+  u4* const lrf = lbase + ROLE * (NBM * 2 * 64) + lane;            // this wave's residual fragments
+  u4* const lrf_right = lbase + (NBM * 2 * 64) + lane;             // the right wave's (its block 0: what the left wave reads)
+  u4* const xw = lbase + 2 * (NBM * 2 * 64) + lane;                // [2][64]: fragment (hi, lo) of the left wave's last block
+  float* const fbase = reinterpret_cast<float*>(lbase + 2 * (NBM * 2 * 64) + 2 * 64);
+  float* const lc = fbase + ROLE * LCW;                            // [2][64] cumulative taps, one copy per wave
+  float* const xc = fbase + 2 * LCW + lane;                        // [64] left -> right: S sum(w, blocks 0 .. NBA-2)
+  float* const xr = fbase + 2 * LCW + 64 + lane;                   // [64] right -> left: S sum(r, blocks NBA+1 ..)
+  float* const xm = fbase + 2 * LCW + 128;                         // [2][64] max |y| of each half
+  float* const xg = fbase + 2 * LCW + 256;                         // [2][2][64] guard, largest |w| of each half
+  auto wave_sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  auto wg_sync = [] {                                // both waves: everything written to LDS before is visible after
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  };
+
+  // ---- cumulative taps (as fista_mfma.h) ---------------------------------------------------------------------
+  double step = a.step, g_scale = tp.g_scale;
+  float y_scale = tp.y_scale;
+  if constexpr (TAPS_DEV) {
+    double run = 0.0;
+    for (int k = 0; k <= lane && k < a.K; ++k) run += (double)(float)a.taps_pp[k];
+    float cm = fabsf((float)run);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) cm = fmaxf(cm, __shfl_xor(cm, o, 64));
+    int e = 0;
+    if (cm > 0.0f) (void)frexpf(cm, &e);
+    const int sa = 3 - e;
+    lc[lane] = (float)ldexp(run, sa);
+    g_scale = ldexp(1.0, -2 * sa);
+    y_scale = ldexpf(1.0f, sa);
+    step = a.step_vec[0];
+  } else {
+    lc[lane] = tp.c[lane];
+  }
+  wave_sync();
+
+  // ---- operator tiles (identical in both waves) ----------------------------------------------------------------
+  Frag An[2][NT], Bn[2][NT], Ff;
+  {
+    const int rho = lane & 15, kg = lane >> 4, gp = rho >> 2, i = rho & 3;
+    auto cval = [&](int lag) -> float { return lag < 0 ? 0.0f : lc[lag > LCW - 1 ? LCW - 1 : lag]; };
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int o = 0; o < NT; ++o) {
+        float fa[8], fb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          fa[j] = cval(32 * o + 8 * (gp - kg) + 4 * r + i - j);
+          fb[j] = cval(32 * o + 8 * (kg - gp) + j - 4 * r - i);
+        }
+        An[r][o] = split8(fa);
+        Bn[r][o] = split8(fb);
+      }
+    float ff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ff[j] = lc[LCW - 1];
+    Ff = split8(ff);
+  }
+  const float s_far = lc[LCW - 1];                 // 2^a S: the far-field gain (every lag >= K-1)
+
+  // ---- this wave's part of the problem; the scale comes from the WHOLE series ---------------------------------
+  const double lb = a.lbda_vec ? a.lbda_vec[p] : a.lbda;
+  float ysn[NBW][8];
+  double w[NBW][8];
+  float sigma = 1.0f, inv_sigma = 1.0f;
+  {
+    const float* yrow = a.y + (int64_t)(p / a.y_rep) * a.ldy;
+    float m = 0.0f;
+#pragma unroll
+    for (int q = 0; q < NBW; ++q)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int t = 32 * (QOFF + q) + tb + j;
+        const float yv = (t < a.N) ? yrow[t] : 0.0f;
+        ysn[q][j] = yv;
+        m = fmaxf(m, fabsf(yv));
+      }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    xm[ROLE * 64 + lane] = m;
+    wg_sync();
+    m = fmaxf(m, xm[(1 - ROLE) * 64 + lane]);
+    if (m > 0.0f && m < 3.0e38f) {
+      int e;
+      (void)frexpf(m, &e);
+      sigma = ldexpf(1.0f, a.ybits - e) / y_scale;
+      inv_sigma = ldexpf(1.0f, e - a.ybits) * y_scale;
+    }
+    const float ys = -sigma * y_scale;
+    const double* wrow = a.w + (int64_t)p * a.ldw;
+#pragma unroll
+    for (int q = 0; q < NBW; ++q)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int t = 32 * (QOFF + q) + tb + j;
+        ysn[q][j] *= ys;
+        w[q][j] = (t < a.N && !a.cold) ? wrow[t] * (double)sigma : 0.0;
+      }
+  }
+  const double th = lb * step * (double)sigma;
+  const double nstep = -step * g_scale;
+  float guard = 0.0f, wlast = 0.0f;
+
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int o = 0; o < NT; ++o)
+      asm volatile("" : "+a"(An[r][o].hi), "+a"(An[r][o].lo), "+a"(Bn[r][o].hi), "+a"(Bn[r][o].lo));
+  asm volatile("" : "+a"(Ff.hi), "+a"(Ff.lo));
+#pragma unroll
+  for (int q = 0; q < NBW; ++q)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) asm volatile("" : "+a"(ysn[q][j]));
+
+  auto mfma_part = [](const Frag& A, const Frag& B, f4 acc, int part) __attribute__((always_inline)) -> f4 {
+    return part == 0   ? __builtin_amdgcn_mfma_f32_16x16x32_f16(A.hi, B.hi, acc, 0, 0, 0)
+           : part == 1 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(A.hi, B.lo, acc, 0, 0, 0)
+                       : __builtin_amdgcn_mfma_f32_16x16x32_f16(A.lo, B.hi, acc, 0, 0, 0);
+  };
+  // left wave: what the right wave needs of the current iterate -- the fragment of the last block ...
+  auto publish_last_block = [&]() {
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = (float)w[NBW - 1][j];
+    const Frag f = split8(x);
+    xw[0] = __builtin_bit_cast(u4, f.hi);
+    xw[64] = __builtin_bit_cast(u4, f.lo);
+  };
+  // ... and the far field of the blocks before it (float64 sum over this lane's samples -> the problem's four lanes)
+  auto publish_far_field = [&](double s) {
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    *xc = (float)(s * (double)s_far);
+  };
+
+  // ---- forward: r = T_c w - y over this wave's blocks (ascending) ---------------------------------------------
+  auto forward = [&]() __attribute__((always_inline)) {
+    f4 carry = f4{0.f, 0.f, 0.f, 0.f};
+    Frag wfX;                                      // right wave: the left wave's last block
+    f2v rs2 = f2v{0.f, 0.f};                       // right wave: sum of the residual samples of its blocks 1 ..
+    if constexpr (ROLE == 1) {
+      const float c = *xc;
+      carry = f4{c, c, c, c};
+      wfX.hi = __builtin_bit_cast(h8, xw[0]);
+      wfX.lo = __builtin_bit_cast(h8, xw[64]);
+    }
+    Frag wf[NBW + 1];
+    f4 acc[NBW + 1][2];
+    unsigned ph[NBW + 1][4], pl[NBW + 1][4];
+    unsigned rh[NBW][4], rl[NBW][4];
+    auto prep_pair = [&](auto qc, auto pc) {
+      constexpr int q = decltype(qc)::value, pp = decltype(pc)::value;
+      float x0, x1;
+      asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(x0) : "v"(w[q][2 * pp]));
+      asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(x1) : "v"(w[q][2 * pp + 1]));
+      split_pair(x0, x1, ph[q][pp], pl[q][pp]);
+      if constexpr (pp == 3) {
+        wf[q].hi = __builtin_bit_cast(h8, u4{ph[q][0], ph[q][1], ph[q][2], ph[q][3]});
+        wf[q].lo = __builtin_bit_cast(h8, u4{pl[q][0], pl[q][1], pl[q][2], pl[q][3]});
+      }
+    };
+    auto cinit = [&](auto qc, auto rc, const f4& cy) {
+      constexpr int q = decltype(qc)::value, r = decltype(rc)::value;
+      acc[q][r] = f4{cy[0] + ysn[q][4 * r + 0], cy[1] + ysn[q][4 * r + 1], cy[2] + ysn[q][4 * r + 2],
+                     cy[3] + ysn[q][4 * r + 3]};
+    };
+    auto finish_pair = [&](auto qc, auto pc) {
+      constexpr int q = decltype(qc)::value, pp = decltype(pc)::value;
+      float x0 = acc[q][pp >> 1][(2 * pp) & 3], x1 = acc[q][pp >> 1][(2 * pp + 1) & 3];
+      if constexpr (QOFF + q == NBT - 1) {         // padding behind sample N-1 (last block of the series only)
+        x0 = (32 * (QOFF + q) + tb + 2 * pp < a.N) ? x0 : 0.0f;
+        x1 = (32 * (QOFF + q) + tb + 2 * pp + 1 < a.N) ? x1 : 0.0f;
+      }
+      if constexpr (ROLE == 1 && q >= 1) rs2 += f2v{x0, x1};
+      split_pair(x0, x1, rh[q][pp], rl[q][pp]);
+      if constexpr (pp == 3) {
+        lrf[(2 * q) * 64] = u4{rh[q][0], rh[q][1], rh[q][2], rh[q][3]};
+        lrf[(2 * q + 1) * 64] = u4{rl[q][0], rl[q][1], rl[q][2], rl[q][3]};
+      }
+    };
+    static_for<0, 4>([&](auto pc) { prep_pair(std::integral_constant<int, 0>{}, pc); });
+    cinit(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, carry);
+    cinit(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, carry);
+    static_for<0, NBW>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      f4 cn = carry;                               // carry of block q+1
+      static_for<0, 3 + 6 * NT>([&](auto sc) {
+        constexpr int sl = decltype(sc)::value;
+        if constexpr (sl < 3) {                      // carry of block q+1: + S (sum of block q+1-NT)
+          if constexpr (q + 1 < NBW) {
+            if constexpr (q >= NT - 1) cn = mfma_part(Ff, wf[q >= NT - 1 ? q - (NT - 1) : 0], cn, sl);
+            else if constexpr (ROLE == 1) cn = mfma_part(Ff, wfX, cn, sl);      // (q = 0: the left wave's last block)
+          }
+        } else {
+          constexpr int c = sl - 3, r = c & 1, k = c >> 1, o = k / 3;          // near tile o: block q-o
+          if constexpr (q >= o) acc[q][r] = mfma_part(An[r][o], wf[q >= o ? q - o : 0], acc[q][r], k - 3 * o);
+          else if constexpr (ROLE == 1) acc[q][r] = mfma_part(An[r][o], wfX, acc[q][r], k - 3 * o);
+        }
+        if constexpr (sl < 4) {
+          if constexpr (ROLE == 0 && q + 1 == NBW - 1) {     // the left wave's last block: split when it was updated (xw)
+            if constexpr (sl == 0) {
+              wf[q + 1].hi = __builtin_bit_cast(h8, xw[0]);
+              wf[q + 1].lo = __builtin_bit_cast(h8, xw[64]);
+            }
+          } else if constexpr (q + 1 < NBW) prep_pair(std::integral_constant<int, q + 1>{}, sc);
+        } else if constexpr (sl < 8) {
+          if constexpr (q >= 1) finish_pair(std::integral_constant<int, q - 1>{}, std::integral_constant<int, sl - 4>{});
+        } else if constexpr (sl == 10 || sl == 11) {
+          if constexpr (q + 1 < NBW) cinit(std::integral_constant<int, q + 1>{}, std::integral_constant<int, sl - 10>{}, cn);
+        }
+      });
+      carry = cn;
+    });
+    static_for<0, 4>([&](auto pc) { finish_pair(std::integral_constant<int, NBW - 1>{}, pc); });
+    if constexpr (ROLE == 1) {                     // what the left wave's adjoint pass needs of the far blocks
+      float rs = rs2[0] + rs2[1];
+      rs += __shfl_xor(rs, 16, 64);
+      rs += __shfl_xor(rs, 32, 64);
+      *xr = rs * s_far;
+    }
+  };
+
+  // ---- adjoint and update: g = T_c^T r over this wave's blocks (descending) -----------------------------------
+  auto backward = [&](const double beta) __attribute__((always_inline)) {
+    const double nb1 = -(1.0 + beta);
+    f4 carry = f4{0.f, 0.f, 0.f, 0.f};
+    Frag rfX;                                      // left wave: the right wave's first block
+    double sum0 = 0.0, sum1 = 0.0;                 // left wave: sum of the updated iterate over blocks 0 .. NBW-2
+    if constexpr (ROLE == 0) {
+      const float c = *xr;
+      carry = f4{c, c, c, c};
+      rfX.hi = __builtin_bit_cast(h8, lrf_right[0]);
+      rfX.lo = __builtin_bit_cast(h8, lrf_right[64]);
+    }
+    f4 acc[NBW + 1][2];
+    Frag rf[NBW + 2];
+    auto fetch = [&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      rf[q].hi = __builtin_bit_cast(h8, lrf[(2 * q) * 64]);
+      rf[q].lo = __builtin_bit_cast(h8, lrf[(2 * q + 1) * 64]);
+    };
+    auto update = [&](auto qc, auto jc) {
+      constexpr int q = decltype(qc)::value, j = decltype(jc)::value;
+      const double gj = (double)acc[q][j >> 2][j & 3];
+      const double u = fma(nstep, gj, w[q][j]);
+      const double d = fmin(fmax(u, -th), th);
+      w[q][j] = fma(nb1, d, u);
+      if constexpr (ROLE == 0 && q <= NBW - 2) {
+        if constexpr ((j & 1) == 0) sum0 += w[q][j]; else sum1 += w[q][j];
+      }
+    };
+    fetch(std::integral_constant<int, NBW - 1>{});
+    static_for<0, NBW>([&](auto qq) {
+      constexpr int q = NBW - 1 - decltype(qq)::value;
+      f4 cn = carry;                               // carry of block q-1
+      if constexpr (q >= 1) fetch(std::integral_constant<int, q - 1>{});
+      static_for<0, 3 + 6 * NT>([&](auto sc) {
+        constexpr int sl = decltype(sc)::value;
+        if constexpr (sl < 3) {                      // carry of block q-1: + S (sum of block q-1+NT)
+          if constexpr (q >= 1) {
+            if constexpr (q - 1 + NT < NBW) cn = mfma_part(Ff, rf[q - 1 + NT < NBW ? q - 1 + NT : 0], cn, sl);
+            else if constexpr (ROLE == 0 && q - 1 + NT == NBW) cn = mfma_part(Ff, rfX, cn, sl);
+          }
+        } else {
+          constexpr int c = sl - 3, r = c & 1, k = c >> 1, o = k / 3;          // near tile o: block q+o
+          if constexpr (k == 0) acc[q][r] = mfma_part(Bn[r][0], rf[q], carry, 0);
+          else if constexpr (q + o < NBW) acc[q][r] = mfma_part(Bn[r][o], rf[q + o < NBW ? q + o : 0], acc[q][r], k - 3 * o);
+          else if constexpr (ROLE == 0 && q + o == NBW) acc[q][r] = mfma_part(Bn[r][o], rfX, acc[q][r], k - 3 * o);
+        }
+        if constexpr ((sl & 1) == 0 && sl < 16 && q + 1 < NBW)
+          update(std::integral_constant<int, q + 1>{}, std::integral_constant<int, sl / 2>{});
+      });
+      carry = cn;
+      // the left wave's last block is complete once the block before it has run: its fragment goes out at once
+      if constexpr (ROLE == 0 && q == NBW - 2) publish_last_block();
+    });
+    static_for<0, 8>([&](auto jc) { update(std::integral_constant<int, 0>{}, jc); });
+    if constexpr (ROLE == 0) publish_far_field(sum0 + sum1);
+  };
+  auto range_check = [&]() {
+    unsigned mb = 0;
+#pragma unroll
+    for (int q = 0; q < NBW; ++q)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) mb = max(mb, __builtin_bit_cast(unsigned, (float)w[q][j]) & 0x7fffffffu);
+    const float m = mb >= 0x7f800000u ? 65504.0f : __builtin_bit_cast(float, mb);
+    wlast = m;
+    unsigned e = 0;
+#pragma unroll
+    for (int q = 0; q < NBW; ++q) {
+      const u4 h = lrf[(2 * q) * 64];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        e = max(e, h[c] & 0x7fffu);
+        e = max(e, (h[c] >> 16) & 0x7fffu);
+      }
+    }
+    guard = __builtin_fmaxf(guard, __builtin_fmaxf(m, e >= 0x7800u ? 65504.0f : 0.0f));
+  };
+
+  // ---- iterations: both passes in both waves at once, one barrier per phase boundary ----------------------------
+  if constexpr (ROLE == 0) {                       // the start iterate's contribution to the right wave's first pass
+    publish_last_block();
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q <= NBW - 2; ++q)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += w[q][j];
+    publish_far_field(s);
+  }
+  wg_sync();
+  for (int it = 0; it < a.n_iter; ++it) {
+    const double beta = a.betas[it];
+    forward();
+    wg_sync();                                     // residual fragments and their far field are out
+    backward(beta);
+    if (PB_MFMA_CHECKS && (((it & 7) == 7) || (it == a.n_iter - 1) || (it == 0 && !a.cold))) range_check();
+    wg_sync();                                     // the updated iterate's fragment and far field are out
+  }
+
+  // ---- guards over the whole series, store ---------------------------------------------------------------------
+  guard = fmaxf(guard, __shfl_xor(guard, 16, 64));
+  guard = fmaxf(guard, __shfl_xor(guard, 32, 64));
+  wlast = fmaxf(wlast, __shfl_xor(wlast, 16, 64));
+  wlast = fmaxf(wlast, __shfl_xor(wlast, 32, 64));
+  xg[(ROLE * 2 + 0) * 64 + lane] = guard;
+  xg[(ROLE * 2 + 1) * 64 + lane] = wlast;
+  wg_sync();
+  {
+    const float go = xg[((1 - ROLE) * 2 + 0) * 64 + lane], wo = xg[((1 - ROLE) * 2 + 1) * 64 + lane];
+    guard = (guard < 60000.0f && go < 60000.0f) ? fmaxf(guard, go) : 65504.0f;      // NaN on either side: out of range
+    wlast = fmaxf(wlast, wo);
+  }
+  const bool bad = !(guard < 60000.0f) || (a.rho_guard && wlast > 0.0f && (float)th > MFMA_RHO_MAX * wlast);
+  if (live && !bad) {
+    double* wrow = a.w + (int64_t)p * a.ldw;
+#pragma unroll
+    for (int q = 0; q < NBW; ++q)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int t = 32 * (QOFF + q) + tb + j;
+        if (t < a.N) wrow[t] = w[q][j] * (double)inv_sigma;
+      }
+  }
+  if (ROLE == 0 && live && a.n_done && g == 0) a.n_done[p] = bad ? -1 : a.n_iter;
+}
+
+// one workgroup = two waves = 16 problems; the wave index picks the half (a scalar branch: each wave runs one role)
+template <int NBA, int NBB, bool TAPS_DEV = false>
+__global__ __launch_bounds__(128) void fista_mfma2_kernel(FistaArgs a, MfmaTaps tp) {
+  extern __shared__ __attribute__((aligned(16))) char mf2_smem[];
+  if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) mfma2_role<NBA, NBB, TAPS_DEV, 0>(a, tp, mf2_smem);
+  else mfma2_role<NBA, NBB, TAPS_DEV, 1>(a, tp, mf2_smem);
+}
+
+// Plain solves (no stop rule, no cost trace), HRFs of up to 33 taps, 32 (NBA+NBB-1) < N <= 32 (NBA+NBB).
+template <int NBA, int NBB>
+int launch_mfma2(const FistaArgs& a, const double* taps, int K, hipStream_t st) {
+  constexpr int NB = NBA + NBB;
+  if (a.N > 32 * NB || a.N <= 32 * (NB - 1) || K < 1 || K > 33) return 1;
+  if (a.stop_mode != PB_STOP_NONE || a.J || !a.n_done) return 1;
+  const int64_t groups = ((int64_t)(a.P - a.p0) + 15) / 16;
+  const dim3 grid((unsigned)groups), block(128);
+  const size_t lds = mfma2_lds_bytes(NBB);
+  if (a.taps_pp) {                                 // shared HRF and step in device memory (the blind step's z-step)
+    const MfmaTaps none{};
+    hipLaunchKernelGGL((fista_mfma2_kernel<NBA, NBB, true>), grid, block, lds, st, a, none);
+    return 0;
+  }
+  const MfmaTaps tp = make_mfma_taps(taps, K);
+  hipLaunchKernelGGL((fista_mfma2_kernel<NBA, NBB, false>), grid, block, lds, st, a, tp);
+  return 0;
+}
+
+}  // namespace pb

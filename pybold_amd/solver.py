@@ -34,6 +34,8 @@ _FORCE = {None: 0, "generic": PB_FLAG_FORCE_GENERIC, "fast": PB_FLAG_FORCE_FAST,
           # "valu": library dispatch without the matrix-pipe form; "mfma": everything on it, one launch
           "valu": _lib.PB_FLAG_NO_MFMA, "valuseq": _lib.PB_FLAG_NO_MFMA | PB_FLAG_ONE_STREAM,
           "mfma": PB_FLAG_ONE_LAUNCH | _lib.PB_FLAG_FORCE_MFMA,
+          # "mfma2": everything on the matrix-pipe form with each series split over two waves, one launch
+          "mfma2": _lib.PB_FLAG_FORCE_MFMA2, "mfma2only": _lib.PB_FLAG_FORCE_MFMA2 | _lib.PB_FLAG_CERT_NO_RESOLVE,
           # intermediate solve of an outer loop: the matrix-pipe form keeps sparse iterates (no accuracy guard)
           "intermediate": _lib.PB_FLAG_NO_RHO_GUARD,
           "intermediate_noresolve": _lib.PB_FLAG_NO_RHO_GUARD | _lib.PB_FLAG_CERT_NO_RESOLVE,   # measurement aid
@@ -165,7 +167,9 @@ def has_fast_path(n_scans, n_taps):
 KERNEL_NAMES = {0: "fista_generic_kernel (LDS)", 1: "fista_fast_kernel (register-resident)",
                 2: "fista_pair_ffa_kernel (register-resident, two problems per row, fast FIRs)",
                 3: "fista_fast_kernel (register-resident, one problem per wave)",
-                4: "fista_mfma_kernel (register-resident, 16 problems per wave, both operators on the matrix pipe)"}
+                4: "fista_mfma_kernel (register-resident, 16 problems per wave, both operators on the matrix pipe)",
+                5: "fista_mfma2_kernel (register-resident, 16 problems per two waves -- every series split over two "
+                   "SIMDs --, both operators on the matrix pipe)"}
 
 
 def which_kernel(n_scans, n_taps, n_problems, want_J=False, stop=None, wind=6):
@@ -318,7 +322,8 @@ def round_size(n_scans, n_taps, dev=None):
     (two waves on every SIMD of the device), or None when only the LDS kernel applies."""
     n_main, main, tail = launch_plan(n_scans, n_taps, 1 << 22)
     # problems per wave x waves per SIMD of each form
-    per_simd = {KERNEL_NAMES[4]: 16, KERNEL_NAMES[2]: 16, KERNEL_NAMES[1]: 8, KERNEL_NAMES[3]: 2}.get(main if n_main else tail)
+    per_simd = {KERNEL_NAMES[4]: 16, KERNEL_NAMES[5]: 8, KERNEL_NAMES[2]: 16, KERNEL_NAMES[1]: 8,
+                KERNEL_NAMES[3]: 2}.get(main if n_main else tail)
     if per_simd is None:
         return None
     return torch.cuda.get_device_properties(device(dev)).multi_processor_count * 4 * per_simd

@@ -156,3 +156,90 @@ def test_adversarial_series_through_the_default_dispatch(solver, n, k):
         dc = ok & np.isin(fam[samp], DC_FAMILIES)
         e = rel_rows(Wg[dc][:, 1:], Wo[dc][:, 1:])
         assert e.max() < 1e-5, (n, k, c, "diff_z[1:] of the DC families", float(e.max()))
+
+
+# ---- the matrix-pipe form with every series split over two waves (fista_mfma2.h) ---------------------------------
+@pytest.mark.parametrize("n,k", [(300, 30), (320, 33), (160, 27), (129, 16), (225, 27), (289, 2), (321, 30), (330, 16),
+                                 (400, 27), (480, 30), (577, 30), (600, 30), (608, 30), (640, 33)])
+def test_split_matrix_pipe_form_matches_oracle(solver, n, k):
+    """`fista_mfma2_kernel`: 16 problems per workgroup of two waves, the left wave owning the first
+    ceil(nb / 2) blocks of 32 samples and the right wave the rest (5 <= nb <= 20: 129 .. 640 scans -- the
+    reference's shipped demo is 600, examples/synth_data/deconv.py:46); warm and cold start, against the C float64
+    oracle; nothing handed back on ordinary data; any batch position gives the same bits; for N <= 320 equal to
+    the one-wave form within the split-operand rounding."""
+    from oracle import c_oracle
+    rng = np.random.RandomState(n + k)
+    hrf = orc.spm_hrf(1.0, 1.0, float(k), False)[0][:k] if k >= 20 else (np.hanning(k + 2)[1:-1] * 0.3 if k > 2 else np.array([0.0, 0.7])[:k])
+    assert len(hrf) == k
+    lip = orc.gram_lipschitz(hrf, n)
+    Yv = rng.randn(40, n)
+    W0 = 0.01 * rng.randn(40, n)
+    Yh = Yv.astype(np.float32).astype(np.float64)
+    Yd, W0d = torch.from_numpy(Yv.astype(np.float32)).cuda(), torch.from_numpy(W0).cuda()
+    Wo, _, _ = c_oracle.fista_batch(Yh, hrf, 0.3, 1.0 / lip, 200, W0=W0, threads=4)
+    W, _, nd = solver.fista_solve(Yd, hrf, 0.3, 1.0 / lip, 200, W0=W0d, force="mfma2only")
+    assert int(nd.min()) == 200 and int(nd.max()) == 200            # nothing handed back
+    assert rel_rows(W.cpu().numpy(), Wo).max() < 3e-6
+    Wc, _, ndc = solver.fista_solve(Yd, hrf, 0.3, 1.0 / lip, 200, force="mfma2only")       # cold start
+    Woc, _, _ = c_oracle.fista_batch(Yh, hrf, 0.3, 1.0 / lip, 200, threads=4)
+    assert int(ndc.min()) == 200 and rel_rows(Wc.cpu().numpy(), Woc).max() < 3e-6
+    # another batch position, another workgroup: the same bits
+    perm = np.r_[np.arange(23, 40), np.arange(23)]
+    W2, _, _ = solver.fista_solve(Yd[torch.from_numpy(perm).cuda()].contiguous(), hrf, 0.3, 1.0 / lip, 200,
+                                  W0=W0d[torch.from_numpy(perm).cuda()].contiguous(), force="mfma2only")
+    assert torch.equal(W2, W[torch.from_numpy(perm).cuda()])
+    if n <= 320:
+        W1, _, _ = solver.fista_solve(Yd, hrf, 0.3, 1.0 / lip, 200, W0=W0d, force="mfmaonly")
+        assert rel_rows(W.cpu().numpy(), W1.cpu().numpy()).max() < 3e-6
+    # the library's own dispatch for this shape: long series take the split form from 5 120 problems on
+    if n > 320:
+        assert "split over two" in solver.which_kernel(n, k, 6000)
+        Yb = torch.from_numpy(np.tile(Yv, (150, 1)).astype(np.float32)).cuda()             # 6 000 series
+        Wl, _, ndl = solver.fista_solve(Yb, hrf, 0.3, 1.0 / lip, 200)
+        assert int(ndl.min()) == 200 and torch.equal(Wl[:40], Wc) and torch.equal(Wl[-40:], Wc)
+
+
+def test_split_matrix_pipe_form_guards_and_shared_hrf(solver, golden):
+    """The guards of the split form see the WHOLE series (both waves agree): a warm start outside the float16
+    range in the left half only / the right half only, NaN, sparse solutions, an all-zero series -- handed back
+    and re-solved to the oracle's answer; the shared-HRF z-step (taps and step read from device memory) through
+    `pb_fista_solve_pp` on a batch between a quarter and half a round."""
+    from oracle import c_oracle
+    from pybold_amd import data
+    g = golden("case1")
+    hrf, lip = g["hrf"], float(g["lipschitz"])
+    Y, _, _ = data.gen_rnd_bloc_bold_batch(48, dur=5.0, tr=1.0, hrf=hrf, nb_events=5, avg_dur=12.0, std_dur=1.0,
+                                           snr=1.0, seed=6)
+    Y[7] = 0.0
+    Yh = Y.cpu().numpy().astype(np.float64)
+    rng = np.random.RandomState(2)
+    W0 = 1e-3 * rng.randn(48, 300)
+    W0[3, :100] *= 1e9                                      # out of range in the left wave's half only
+    W0[5, 200:] *= 1e9                                      # ... in the right wave's half only
+    W0[21, 250] = np.nan
+    lmax = solver.lambda_max(Y, hrf).cpu().numpy()
+    lam = np.where(np.arange(48) % 2 == 0, 1.0, 0.7 * lmax)
+    lam[[3, 5, 7, 21]] = 1.0
+    Wo, _, _ = c_oracle.fista_batch(Yh, hrf, lam, 1.0 / lip, 120, W0=W0, threads=8)
+    W0d = torch.from_numpy(W0).cuda()
+    W, _, nd = solver.fista_solve(Y, hrf, lam, 1.0 / lip, 120, W0=W0d, force="mfma2")
+    Wn = W.cpu().numpy()
+    ok = (np.arange(48) != 21) & (np.linalg.norm(Wo, axis=1) > 0)
+    assert (nd.cpu().numpy() == 120).all() and rel_rows(Wn[ok], Wo[ok]).max() < 1e-5 and np.isnan(Wn[21]).any()
+    _, _, ndc = solver.fista_solve(Y, hrf, lam, 1.0 / lip, 120, W0=W0d, force="mfma2only")
+    caught = np.flatnonzero(ndc.cpu().numpy() == -1)
+    assert {3, 5, 21} <= set(caught) and (ndc.cpu().numpy()[[0, 2, 6, 8]] == 120).all()
+    assert np.isin(caught, np.r_[3, 5, 21, np.arange(1, 48, 2)]).all() and len(caught) >= 10
+    # shared HRF from device memory: 6 000 voxels = one pass of the split form (the config-4 shard of one of 8 GPUs)
+    t_r, dur, n = 0.75, 20.0, 300
+    h = orc.spm_hrf(0.9, t_r, dur, False)[0]
+    lip4 = orc.gram_lipschitz(h, n)
+    Yb = torch.from_numpy(rng.randn(6000, n).astype(np.float32)).cuda()
+    taps, stepc = torch.from_numpy(h.copy()).cuda(), torch.from_numpy(np.array([1.0 / lip4])).cuda()
+    Wp, ndp = solver.fista_solve_pp(Yb, taps, stepc, 1.7, 60)
+    assert int(ndp.min()) == 60 and "split over two" in solver.launch_plan(n, len(h), 6000)[2]
+    idx = np.r_[0, 15, 16, 5999, rng.choice(6000, 12, replace=False)]
+    Wop = orc.fista_batch(Yb.cpu().numpy()[idx].astype(np.float64), h, 1.7, 1.0 / lip4, 60)
+    assert rel_rows(Wp.cpu().numpy()[idx], Wop).max() < 1e-5
+    Wv, _ = solver.fista_solve_pp(Yb, taps, stepc, 1.7, 60, force="valu")
+    assert float(((Wp - Wv).norm(dim=1) / Wv.norm(dim=1)).max()) < 4e-6

@@ -161,17 +161,23 @@ def test_launch_plan_of_a_plain_solve():
               29000: (24576, pair, row), 50000: (49152, pair, wave), 100000: (98304, pair, wave)}
     for P, want in expect.items():
         assert solver.launch_plan(300, 30, P, force="valu") == want, P
-    # with the matrix-pipe form (round 3; 129..320 scans, up to 33 taps): whole rounds of 16 384 problems
-    # and any remainder above half a round + 1 024 on it (what half a round of pair waves with one
-    # one-problem wave per SIMD beside them closes faster than a matrix-pipe pass), a smaller remainder
-    # on the vector forms' plan
-    mm = solver.KERNEL_NAMES[4]
-    expect = {1: (0, None, wave), 4096: (0, None, row), 8192: (0, None, pair), 8193: (8192, pair, wave),
-              9216: (8192, pair, wave), 9217: (0, None, mm), 10000: (0, None, mm),
-              12500: (0, None, mm), 16384: (0, None, mm), 21000: (16384, mm, row), 25000: (16384, mm, pair),
-              25601: (0, None, mm), 50000: (49152, mm, wave), 100000: (98304, mm, wave)}
+    # with the matrix-pipe forms (129..320 scans, up to 33 taps): whole rounds of 16 384 problems on the one-wave form
+    # (round 3); what they leave (round 4): up to 4 608 problems on the vector forms' plan, up to half a round as ONE
+    # pass of the split form (every series over two waves: half the latency), up to half a round + 2 048 as that pass
+    # with one-problem waves beside and behind it, anything larger as one more pass of the one-wave form
+    mm, m2 = solver.KERNEL_NAMES[4], solver.KERNEL_NAMES[5]
+    expect = {1: (0, None, wave), 4096: (0, None, row), 4608: (4096, row, wave), 4609: (0, None, m2), 8192: (0, None, m2),
+              8193: (8192, m2, wave), 10000: (8192, m2, wave), 10240: (8192, m2, wave), 10241: (0, None, mm),
+              12500: (0, None, mm), 16384: (0, None, mm), 20000: (16384, mm, row), 21000: (16384, mm, m2),
+              25000: (16384, mm, m2), 26624: (16384, mm, m2), 26625: (0, None, mm), 50000: (49152, mm, wave),
+              100000: (98304, mm, wave)}
     for P, want in expect.items():
         assert solver.launch_plan(300, 30, P) == want, P
+    # the cost trace and the window rule do not ride the split form: the round-3 plan
+    assert solver.launch_plan(300, 30, 10000, stop="window") == (0, None, mm)
+    # series of 321..640 scans: the split form from 5 120 problems on (whole passes of 8 192, remainders above 2 560)
+    assert solver.launch_plan(600, 30, 50000) == (49152, m2, wave) and solver.launch_plan(600, 30, 8192) == (0, None, m2)
+    assert solver.launch_plan(600, 30, 4096)[2] == pair and solver.launch_plan(600, 30, 11000) == (0, None, m2)
     assert solver.launch_plan(128, 16, 100000)[1] == pair and row in solver.launch_plan(300, 40, 100000)[1:]
     # the window rule at the reference's wind = 6 rides the pair form (no-fire certificate +
     # re-solve); the _loops_deconv rule does not; shapes outside the tables go to the LDS kernel
