@@ -56,13 +56,17 @@ def executed_flops_per_voxel_iter(n, k):
     return 3.0 * n * k + 12.0 * n
 
 
-def mfma_per_wave_iteration(n, k):
-    """v_mfma_f32_16x16x32_f16 instructions one wave (16 problems) of fista_mfma_kernel issues per
-    iteration: NB = ceil(N/32) blocks, NT near tiles (2 for K <= 33, 3 for K <= 65), three split
-    products per tile and row half, three for the running far-field carry; both passes
-    (pybold_amd/csrc/fista_mfma.h).  276 at N = 300, K = 30 -- the count SQ_INSTS_MFMA reports
-    (profiles/r3_pmc_mfma.json)."""
+def mfma_per_wave_iteration(n, k, split=False):
+    """v_mfma_f32_16x16x32_f16 instructions per iteration and 16 problems: one wave of fista_mfma_kernel
+    (NB = ceil(N/32) blocks, NT near tiles (2 for K <= 33, 3 for K <= 65), three split products per tile
+    and row half, three for the running far-field carry; both passes; pybold_amd/csrc/fista_mfma.h --
+    276 at N = 300, K = 30, the count SQ_INSTS_MFMA reports, profiles/r3_pmc_mfma.json) or, `split`,
+    the two waves of fista_mfma2_kernel together (fista_mfma2.h: floor(NB/2) + ceil(NB/2) blocks; the
+    waves' carry chains restart at the cut: 270 at N = 300)."""
     nb, nt = (n + 31) // 32, (2 if k <= 33 else 3)
+    if split:
+        a, b = nb // 2, nb - nb // 2
+        return (3 * (a - 2) + 6 * a + 6 * (a - 1)) + (3 * (b - 1) + 12 * b) + (3 * (b - 2) + 6 * b + 6 * (b - 1)) + (3 * (a - 1) + 12 * a)
     return 2 * (3 * (nb - nt) + 6 * sum(nb - o for o in range(nt)))
 
 
@@ -319,10 +323,11 @@ def run(args):
     n_main, main_kernel, tail_kernel = solver.launch_plan(N, K, max(P, 1), force=plan_force)
     P_dom = n_main if (args.kernel in ("auto", "seq") and n_main > 0) else P
     matrix_pipe = args.kernel in ("auto", "seq") and "matrix pipe" in (main_kernel if n_main else tail_kernel)
+    split_form = matrix_pipe and "split over two" in (main_kernel if n_main else tail_kernel)
     if P_dom != P and P_dom % y_rep == 0:
         lam_dom = lam[:P_dom] if torch.is_tensor(lam) else lam
         plan_dom = solver.FistaPlan(Y[:P_dom // y_rep], hrf, lam_dom, step, n_iter, y_rep=y_rep,
-                                    force="mfma" if matrix_pipe else "fast2")
+                                    force=("mfma2" if split_form else "mfma") if matrix_pipe else "fast2")
         _, dom_ms = timed_local(lambda: plan_dom.launch(cold=True), max(3, min(args.steps, 5)), 1, 0.05)
         del plan_dom
     else:
@@ -333,10 +338,11 @@ def run(args):
     mfma_block = None
     if matrix_pipe:
         # what the matrix-pipe kernel EXECUTES: mfma_per_wave_iteration() matrix instructions per wave of 16 problems
-        n_mfma = mfma_per_wave_iteration(N, K)
+        n_mfma = mfma_per_wave_iteration(N, K, split_form)
         mfma_flop = n_mfma * MFMA_FLOP / 16.0
         exec_launch = mfma_flop * float(P_dom) * n_iter
-        mfma_block = {"mfma_instructions_per_wave_iteration": n_mfma, "problems_per_wave": 16,
+        mfma_block = {"mfma_instructions_per_16_problems_and_iteration": n_mfma,
+                      "waves_per_16_problems": 2 if split_form else 1,
                       "f16_flops_per_voxel_iteration": mfma_flop,
                       "matrix_pipe_busy_estimate": n_mfma * 16.0 / 16.0 * float(P_dom) * n_iter /
                                                    (1024.0 * 2.1e9 * dom_ms * 1e-3),
@@ -481,7 +487,8 @@ def roofline_block(matrix_pipe, kernel, dom_ms, P_dom, n_iter, N, K, flops_launc
                 "executed_flops_per_launch": exec_launch}
         binding = ("issue of ONE wave per SIMD: 993 vector + 276 matrix instructions per 16 voxel-iterations at N = 300 "
                    "(profiles/r3_pmc_sq.json: 0.63 of the cycles issuing, 0.20 waiting on matrix results; matrix "
-                   "pipe busy 0.55) -- neither HBM nor the MFMA peak")
+                   "pipe busy 0.55) -- neither HBM nor the MFMA peak; the split form (fista_mfma2_kernel: two waves per "
+                   "16 problems) adds two workgroup barriers per iteration")
     else:
         ach, peak = flops_launch / sec / 1e12, VALU_FP32_PEAK_TFLOPS
         head = {"bound": "valu_fp32", "pipe": "vector fp32 (v_pk_fma_f32)", "achieved": ach, "peak": peak,
@@ -551,6 +558,7 @@ def run_config4(args, world, rank, dev, dist, V, V_total, lo, timed, timed_local
     Wd = torch.zeros((V_dom, N), dtype=torch.float64, device=dev)
     Yd = Y[:V_dom]
     matrix_pipe = "matrix pipe" in (main_kernel if n_main else tail_kernel)
+    split_form = matrix_pipe and "split over two" in (main_kernel if n_main else tail_kernel)
     _, dom_ms = timed_local(lambda: solver.fista_solve_pp(Yd, taps, stepc, lbda, nb_inner, W0=Wd, inplace=True,
                                                           force="intermediate" if matrix_pipe else "fast2"), 10, 2, 0.05)
     dom_kernel = main_kernel if n_main else tail_kernel
@@ -558,9 +566,10 @@ def run_config4(args, world, rank, dev, dist, V, V_total, lo, timed, timed_local
     exec_launch = executed_flops_per_voxel_iter(N, K) * float(V_dom) * nb_inner
     mfma_block = None
     if matrix_pipe:
-        n_mfma = mfma_per_wave_iteration(N, K)
+        n_mfma = mfma_per_wave_iteration(N, K, split_form)
         exec_launch = n_mfma * MFMA_FLOP / 16.0 * float(V_dom) * nb_inner
-        mfma_block = {"mfma_instructions_per_wave_iteration": n_mfma, "problems_per_wave": 16,
+        mfma_block = {"mfma_instructions_per_16_problems_and_iteration": n_mfma,
+                      "waves_per_16_problems": 2 if split_form else 1,
                       "f16_flops_per_voxel_iteration": n_mfma * MFMA_FLOP / 16.0}
     alg_bytes = BYTES_PER_VOXEL_ITER_PER_SCAN * N * float(V_dom) * nb_inner
     ms_step = elapsed / args.steps * 1e3

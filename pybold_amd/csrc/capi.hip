@@ -455,6 +455,7 @@ int plan_pieces(int P, bool has_pair, bool has_wide, bool one_launch, bool one_s
 //   half < R <= half + one-problem waves half a round on the split form, then the left-overs one problem per wave
 //   beyond                               one more pass of the one-wave form, as before
 constexpr int MFMA2_MIN_R = 4608;
+constexpr int MFMA2_BESIDE_CHUNKS = 2;         // chunks of one one-problem wave per SIMD beside a split-form pass
 // Series of 321 .. 640 scans (11 .. 20 blocks) run on the split form from this many problems on (below, the
 // pair form over two slots or the latency-bound one-problem-per-wave form finish first: N = 600, 4 096 problems
 // 1.58 ms against 1.93, 8 192 2.87 against 1.97 -- profiles/r4_split_form_passes.txt); whole passes of 8 192
@@ -478,17 +479,23 @@ int plan_pieces_mfma(int P, bool has_pair, bool has_wide, bool one_launch, bool 
       out[n++] = Piece{FORM_MFMA2, whole, P, false, false};
       return n;
     }
-    if (R > half && has_wide && R - half <= wide_max) {
-      // (the left-overs BESIDE the split-form pass, on the side stream: a wave of the N <= 320 split form holds 355
-      // registers, an 88-register one-problem wave fits next to it and issues in the gaps its barriers leave)
-      // ONE such wave per SIMD: with two, 355 + 2 x 88 registers no longer fit and the waves that wait block the
-      // placement of the two-wave workgroups (measured: 1 808 left-overs beside, 2.25 ms; 808, 1.15 ms; one after the
-      // other 1.62 / 1.41 ms, profiles/r4_split_form_passes.txt) -- left-overs beyond one per SIMD run behind the pass
+    if (R > half && has_wide && R - half <= (one_stream ? wide_max : MFMA2_BESIDE_CHUNKS * (wide_max / 2))) {
+      // The left-overs as one-problem waves BESIDE the split-form pass, on the side stream: a wave of the N <= 320
+      // split form holds 355 registers, ONE 88-register one-problem wave fits next to it on a SIMD and issues in the
+      // gaps the pass's barriers leave.  One per SIMD and no more: with two, 355 + 2 x 88 registers no longer fit and
+      // the waves that wait block the placement of the two-wave workgroups (measured: 1 808 left-overs in one launch
+      // beside the pass 2.25 ms, one after the other 1.62 ms; 808 beside it 1.15 ms) -- so they go in chunks of one
+      // per SIMD, one chunk after the other on the side stream (a chunk beside the pass lasts about twice what it lasts
+      // alone: 10 000 problems 1.52 ms, 9 000 1.14 ms; three chunks, 11 000 problems, 1.87 ms: slower than one pass of
+      // the one-wave form, so two at most).
       if (whole > 0) out[n++] = Piece{FORM_MFMA, 0, whole, false, false};
-      const int beside = one_stream ? 0 : (R - half < wide_max / 2 ? R - half : wide_max / 2);
-      out[n++] = Piece{FORM_MFMA2, whole, whole + half, false, beside > 0};
-      if (beside > 0) out[n++] = Piece{FORM_WIDE, whole + half, whole + half + beside, true, true};
-      if (whole + half + beside < P) out[n++] = Piece{FORM_WIDE, whole + half + beside, P, false, false};
+      out[n++] = Piece{FORM_MFMA2, whole, whole + half, false, !one_stream};
+      if (one_stream) {
+        out[n++] = Piece{FORM_WIDE, whole + half, P, false, false};
+      } else {
+        for (int c0 = whole + half; c0 < P; c0 += wide_max / 2)
+          out[n++] = Piece{FORM_WIDE, c0, c0 + wide_max / 2 < P ? c0 + wide_max / 2 : P, true, true};
+      }
       return n;
     }
   }
