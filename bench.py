@@ -301,7 +301,10 @@ def run(args):
     else:
         lam = args.lbda
     P = V * y_rep                                               # problems of this rank
-    plan = solver.FistaPlan(Y, hrf, lam, step, n_iter, y_rep=y_rep, force=force)
+    lmax5 = None
+    if cfg == 5 and args.kernel == "auto":
+        lmax5 = solver.lambda_max(Y, hrf)      # (the path's own top: what the caller built its lambdas from)
+    plan = solver.FistaPlan(Y, hrf, lam, step, n_iter, y_rep=y_rep, force=force, lmax=lmax5)
     plan0 = solver.launch_plan(N, K, max(P, 1), force="valu" if torch.is_tensor(lam) else None)
     kernel_name = ((plan0[1] if plan0[0] > 0 else plan0[2]) if args.kernel in ("auto", "seq") else
                    {"fast1": solver.KERNEL_NAMES[1], "generic": solver.KERNEL_NAMES[0]}[args.kernel])
@@ -333,6 +336,30 @@ def run(args):
     else:
         P_dom, dom_ms = P, kern_ms
     pair_form = args.kernel in ("auto", "seq") and "two problems per row" in (main_kernel if n_main else tail_kernel)
+    path_info = None
+    if lmax5 is not None:
+        # regularisation path partitioned on the device (pb_fista_solve_path): two big launches per step -- the dense
+        # class on the matrix-pipe form, the sparse class on the pair form; each is timed on its own (same lists), the
+        # longer one is the step's dominant kernel
+        n_dense = int(plan.work[P].item())
+        _, _, nd0 = solver.fista_solve(Y, hrf, lam, step, n_iter, y_rep=y_rep, lmax=lmax5, force="noresolve")
+        n_back = int((nd0 < 0).sum())
+        t_cls = {}
+        for tag, frc in (("dense", "path_dense"), ("sparse", "path_sparse")):
+            pl = solver.FistaPlan(Y, hrf, lam, step, n_iter, y_rep=y_rep, force=frc, lmax=lmax5, W=plan.W)
+            _, t_cls[tag] = timed_local(lambda: pl.launch(cold=True), 3, 1, 0.0)
+        plan.launch(cold=True)                                  # the complete result again (the aids leave a class unsolved)
+        torch.cuda.synchronize(dev)
+        matrix_pipe = t_cls["dense"] >= t_cls["sparse"]
+        pair_form, split_form = not matrix_pipe, False
+        P_dom, dom_ms = (n_dense, t_cls["dense"]) if matrix_pipe else (P - n_dense, t_cls["sparse"])
+        main_kernel, tail_kernel, n_main = solver.KERNEL_NAMES[4], solver.KERNEL_NAMES[2], n_dense
+        kernel_name = main_kernel if matrix_pipe else tail_kernel
+        path_info = {"dense_ratio": 0.13, "dense_problems": n_dense, "sparse_problems": P - n_dense,
+                     "handed_back_by_the_guards": n_back, "handed_back_fraction_of_dense": n_back / max(n_dense, 1),
+                     "dense_launch_ms": t_cls["dense"], "sparse_launch_ms": t_cls["sparse"],
+                     "note": "each launch includes the three partition launches (lists built on the device, no host "
+                             "synchronisation) and covers P slots: waves beyond a list's length leave at once"}
     flops_launch = flops_per_voxel_iter(N, K) * float(P_dom) * n_iter      # dominant kernel, one launch
     exec_launch = (executed_flops_per_voxel_iter(N, K) if pair_form else flops_per_voxel_iter(N, K)) * float(P_dom) * n_iter
     mfma_block = None
@@ -391,13 +418,15 @@ def run(args):
                    "launches_per_step": ([{"kernel": main_kernel, "problems": n_main}] if n_main else []) +
                                         [{"kernel": tail_kernel, "problems": P - n_main}]
                    if args.kernel in ("auto", "seq") else [{"kernel": kernel_name, "problems": P}],
+                   **({"regularisation_path": path_info} if path_info else {}),
                    "parallelism": "contiguous voxel shards x%d, no data-path collective" % world},
-        "roofline": roofline_block(matrix_pipe, main_kernel if n_main else tail_kernel, dom_ms, P_dom, n_iter, N, K,
+        "roofline": roofline_block(matrix_pipe, kernel_name if path_info else (main_kernel if n_main else tail_kernel), dom_ms, P_dom, n_iter, N, K,
                                    flops_launch, exec_launch, alg_bytes, traffic, mfma_block,
                                    {"step_kernels_ms": kern_ms,
-                                    "step_frac": (exec_launch if matrix_pipe else flops_launch) * (float(P) / P_dom) /
-                                                 (kern_ms * 1e-3) / 1e12 /
-                                                 (MFMA_F16_PEAK_TFLOPS if matrix_pipe else VALU_FP32_PEAK_TFLOPS)}),
+                                    **({} if path_info else {
+                                        "step_frac": (exec_launch if matrix_pipe else flops_launch) * (float(P) / P_dom) /
+                                                     (kern_ms * 1e-3) / 1e12 /
+                                                     (MFMA_F16_PEAK_TFLOPS if matrix_pipe else VALU_FP32_PEAK_TFLOPS)})}),
     }
 
     if world > 1 and args.scaling == "strong":

@@ -188,6 +188,30 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep,
                    unsigned flags, void* stream);
 
 /*
+ * Regularisation path: P = V * y_rep problems (voxel v, lambda_{v,i}), lbda_dev[p] the lambda of problem p, all
+ * lambdas of a voxel sharing its series (row p / y_rep of y_dev).  The reference has no such routine: its lambda
+ * lists are hard-coded "already grid-search" values (examples/icassp_2019/simulation.py:113-114,
+ * validation.py:60-62); each problem equals one reference call deconv(y_v, t_r, hrf, lbda=lambda_{v,i}).
+ * Same recurrence, arguments and results as pb_fista_solve with lbda_dev (plain solve: no stop rule, no cost
+ * trace), but the problems are PARTITIONED on the device, without a host synchronisation, by
+ *     lbda_dev[p] < dense_ratio * lmax_dev[p / y_rep]         (lmax_dev: pb_lambda_max of every series)
+ * -- the dense class runs on the matrix-pipe form, the sparse class (solutions of a few small entries, where the
+ * 22-bit operators of that form would be handed back by its accuracy guard and solved twice) straight on the
+ * two-problems-per-row float32 form; whatever a guard still hands back is re-solved exactly as in pb_fista_solve.
+ * dense_ratio <= 0 selects PB_PATH_DENSE_RATIO (calibrated on block-signal paths, profiles/r4_path_partition.txt: the
+ * guard hands back 0.3 % of the problems at lambda / lambda_max = 0.11, 5 % at 0.14, 24 % at 0.18, 62 % at 0.23).  work_dev: int32 scratch of at least pb_fista_path_work_len(P)
+ * entries (index lists and counts; contents meaningless afterwards).  lmax_dev == NULL, work_dev == NULL or a
+ * shape outside the matrix-pipe form (129..320 scans, <= 33 taps): the call is pb_fista_solve with lbda_dev.
+ */
+#define PB_PATH_DENSE_RATIO 0.13
+int64_t pb_fista_path_work_len(int P);
+int pb_fista_solve_path(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, int64_t ldw, int P, int N,
+                        const double* taps_host, const double* taps_dev, int K, double step,
+                        const double* lbda_dev, const double* lmax_dev, double dense_ratio,
+                        const double* betas_dev, int n_iter, int32_t* n_done_dev, int32_t* work_dev,
+                        int64_t work_len, unsigned flags, void* stream);
+
+/*
  * z = cumsum(w), x = taps * z (causal, truncated): the outputs deconv returns
  * next to diff_z (pybold/bold_signal.py:74-75,97).  float64 in, float64 out.
  * Either output pointer may be NULL.

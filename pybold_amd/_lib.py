@@ -54,6 +54,15 @@ SIGNATURES = {
         _ptr, _c_i64,                    # J_dev, ldj
         _c_int, _c_dbl, _c_int, _ptr,    # stop_mode, tol, wind, n_done_dev
         ctypes.c_uint, _ptr]),           # flags, stream
+    "pb_fista_path_work_len": (_c_i64, [_c_int]),
+    "pb_fista_solve_path": (_c_int, [
+        _ptr, _c_i64, _c_int,            # y_dev, ldy, y_rep
+        _ptr, _c_i64, _c_int, _c_int,    # w_dev, ldw, P, N
+        _ptr, _ptr, _c_int,              # taps_host, taps_dev, K
+        _c_dbl, _ptr, _ptr, _c_dbl,      # step, lbda_dev, lmax_dev, dense_ratio
+        _ptr, _c_int,                    # betas_dev, n_iter
+        _ptr, _ptr, _c_i64,              # n_done_dev, work_dev, work_len
+        ctypes.c_uint, _ptr]),           # flags, stream
     "pb_fista_outputs": (_c_int, [_ptr, _c_i64, _c_int, _c_int, _ptr, _c_int,
                                   _ptr, _c_i64, _ptr, _c_i64, _ptr]),
     "pb_fista_stats": (_c_int, [_ptr, _c_i64, _ptr, _c_i64, _c_int, _c_int, _c_int, _ptr,

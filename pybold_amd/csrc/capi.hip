@@ -19,6 +19,7 @@
 #include "blind.h"
 #include "fista_mfma.h"
 #include "fista_mfma2.h"
+#include "path.h"
 
 namespace {
 
@@ -1520,6 +1521,78 @@ int pb_fista_solve_pp(const float* y_dev, int64_t ldy, double* w_dev, int64_t ld
   hipLaunchKernelGGL((pb::fista_generic_kernel<false>), dim3(P), dim3(pb::GEN_THREADS),
                      (size_t)nd * sizeof(double), (hipStream_t)stream, a, taps_dev, K, 0);
   return check_launch("fista_generic_kernel(pp)");
+}
+
+int64_t pb_fista_path_work_len(int P) {
+  return P >= 0 ? (int64_t)P + 1 + (P + pb::PATH_PER_BLOCK - 1) / pb::PATH_PER_BLOCK + 8 : 0;
+}
+
+int pb_fista_solve_path(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, int64_t ldw, int P, int N,
+                        const double* taps_host, const double* taps_dev, int K, double step,
+                        const double* lbda_dev, const double* lmax_dev, double dense_ratio,
+                        const double* betas_dev, int n_iter, int32_t* n_done_dev, int32_t* work_dev,
+                        int64_t work_len, unsigned flags, void* stream) {
+  if (P < 0 || N < 1 || K < 1 || n_iter < 0 || y_rep < 1)
+    return fail(PB_ERR_INVALID, "pb_fista_solve_path: bad size (P=%d N=%d K=%d n_iter=%d y_rep=%d)", P, N, K, n_iter, y_rep);
+  if (P > (1 << 25)) return fail(PB_ERR_INVALID, "pb_fista_solve_path: more than 2^25 problems per launch");
+  if (ldy < N || ldw < N) return fail(PB_ERR_INVALID, "pb_fista_solve_path: leading dimension < N");
+  if (!(step > 0.0)) return fail(PB_ERR_INVALID, "pb_fista_solve_path: step must be positive");
+  if (P == 0) return PB_OK;
+  if (!y_dev || !w_dev || !taps_host || !lbda_dev || !n_done_dev || (n_iter > 0 && !betas_dev))
+    return fail(PB_ERR_INVALID, "pb_fista_solve_path: NULL pointer (per-problem lambdas and n_done are required)");
+  const FastEntry* fe = pick_fast(N, K);
+  const mfma_launch_fn mfma = (fe && fe->fn_pair_ffa && !(flags & PB_FLAG_NO_MFMA)) ? pick_mfma(N, K) : nullptr;
+  // no partition possible (no lambda_max, no workspace, a shape outside the matrix-pipe form or the pair form): the
+  // plain dispatch of per-problem lambdas (vector forms)
+  if (!mfma || !lmax_dev || !work_dev || work_len < pb_fista_path_work_len(P))
+    return pb_fista_solve(y_dev, ldy, y_rep, w_dev, ldw, P, N, taps_host, taps_dev, K, step, 0.0, lbda_dev, betas_dev,
+                          n_iter, nullptr, 0, PB_STOP_NONE, 0.0, 0, n_done_dev, flags, stream);
+  const double ratio = dense_ratio > 0.0 ? dense_ratio : PB_PATH_DENSE_RATIO;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = (P + pb::PATH_PER_BLOCK - 1) / pb::PATH_PER_BLOCK;
+  hipLaunchKernelGGL(pb::path_count_kernel, dim3(nblk), dim3(pb::PATH_THREADS), 0, st, lbda_dev, lmax_dev, y_rep, ratio, P, work_dev);
+  hipLaunchKernelGGL(pb::path_scan_kernel, dim3(1), dim3(pb::PATH_THREADS), 0, st, P, nblk, work_dev);
+  hipLaunchKernelGGL(pb::path_scatter_kernel, dim3(nblk), dim3(pb::PATH_THREADS), 0, st, lbda_dev, lmax_dev, y_rep, ratio, P, work_dev);
+  int rc = check_launch("path_partition");
+  if (rc != PB_OK) return rc;
+
+  pb::FistaArgs a;
+  a.y = y_dev; a.y64 = nullptr; a.ldy = ldy; a.w = w_dev; a.ldw = ldw; a.lbda_vec = lbda_dev;
+  a.betas = betas_dev; a.J = nullptr; a.J64 = nullptr; a.ldj = 0; a.n_done = n_done_dev;
+  a.step = step; a.lbda = 0.0; a.tol = 0.0;
+  a.y_rep = y_rep; a.P = P; a.N = N; a.n_iter = n_iter; a.stop_mode = PB_STOP_NONE;
+  a.taps_pp = nullptr; a.ldt = 0; a.step_vec = nullptr; a.step_shared = 0; a.K = K; a.p0 = 0;
+  a.cold = (flags & PB_FLAG_COLD_START) ? 1 : 0;
+  a.rho_guard = (flags & PB_FLAG_NO_RHO_GUARD) ? 0 : 1;
+  a.perm = work_dev;
+  a.n_dense = work_dev + P;
+  // dense list on the matrix pipe, sparse list on the pair form: both launches cover P slots, the waves beyond a
+  // list's length (read on the device) leave at once
+  // (measurement aids: PB_FLAG_FORCE_MFMA = the dense list's launch only, PB_FLAG_FORCE_PAIR = the sparse list's only;
+  // the other class is then left unsolved)
+  const bool only_dense = (flags & PB_FLAG_FORCE_MFMA) != 0, only_sparse = (flags & PB_FLAG_FORCE_PAIR) != 0;
+  if (!only_sparse) {
+    a.perm_side = 1;
+    if (mfma(a, taps_host, K, false, st) != 0) return fail(PB_ERR_INVALID, "pb_fista_solve_path: matrix-pipe kernel rejected the launch");
+    rc = check_launch("fista_mfma_kernel(path, dense list)");
+    if (rc != PB_OK) return rc;
+  }
+  if (!only_dense) {
+    a.perm_side = 2;
+    if (fe->fn_pair_ffa(a, taps_host, K, false, st) != 0) return fail(PB_ERR_INVALID, "pb_fista_solve_path: pair kernel rejected the launch");
+    rc = check_launch("fista_pair_ffa_kernel(path, sparse list)");
+    if (rc != PB_OK) return rc;
+  }
+  if (!(flags & PB_FLAG_CERT_NO_RESOLVE) && !only_dense && !only_sparse) {       // what the guards of the matrix-pipe form handed back: exact re-solve
+    a.perm_side = 0;
+    a.perm = nullptr;
+    a.n_dense = nullptr;
+    a.only_flagged = 1;
+    if (fe->fn(a, taps_host, K, false, PB_STOP_NONE, st) != 0)
+      return fail(PB_ERR_INVALID, "pb_fista_solve_path: no single-row form for the re-solve");
+    rc = check_launch("fista_fast_kernel(path, re-solve)");
+  }
+  return rc;
 }
 
 }  // extern "C"

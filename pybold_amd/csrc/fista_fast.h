@@ -66,7 +66,27 @@ struct FistaArgs {
   int rho_guard = 1;      // matrix-pipe form: hand sparse solutions (th / max|w| > MFMA_RHO_MAX) back to the vector forms
   int only_flagged = 0;   // 1: solve only the problems with n_done[p] < 0 (left by the certificate
                           //    form of the pair kernel, fista_pair_ffa.h), skip the others
+  // Partition of a regularisation path (pb_fista_solve_path, path.h): perm[0 .. *n_dense) lists the problems of the
+  // dense class in ascending order, perm[P-1], perm[P-2], ... those of the sparse class.  perm_side = 1: this launch
+  // solves the dense list (slot s -> problem perm[s]), 2: the sparse list (slot s -> perm[P-1-s]); the count is read on
+  // the device, so the grid covers P slots and the waves beyond the list leave at once.  0: slot = problem.
+  const int32_t* perm = nullptr;
+  const int32_t* n_dense = nullptr;
+  int perm_side = 0;
 };
+
+// slots of this launch's list (the whole batch without a partition)
+__device__ __forceinline__ int list_length(const FistaArgs& a) {
+  if (a.perm_side == 0) return a.P;
+  const int nd = *a.n_dense;
+  return a.perm_side == 1 ? nd : a.P - nd;
+}
+// slot -> problem; `live` = the slot is inside the list (a dead slot maps to a valid problem whose data may be read)
+__device__ __forceinline__ int slot_to_problem(const FistaArgs& a, int slot, int n_list, bool& live) {
+  live = slot < n_list;
+  if (a.perm_side == 0) return live ? slot : a.P - 1;
+  return live ? a.perm[a.perm_side == 1 ? slot : a.P - 1 - slot] : 0;
+}
 
 // Tap pairs as kernel arguments (read with scalar loads, kept in SGPRs).
 //   even[a] = (h[2a],   h[2a+1])

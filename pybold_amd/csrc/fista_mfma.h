@@ -170,9 +170,10 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
   const int lane = threadIdx.x & 63;
   const int v = lane & 15, g = lane >> 4;
   const int wave = (int)((blockIdx.x * 256 + threadIdx.x) >> 6);
-  const int prob = wave * 16 + v + a.p0;
-  const bool live = prob < a.P;
-  const int p = live ? prob : a.P - 1;
+  const int n_list = list_length(a);              // (a.P without a partition; else the length of this launch's list)
+  if (wave * 16 + a.p0 >= n_list) return;         // the whole wave lies beyond the list (no workgroup barrier anywhere below)
+  bool live;
+  const int p = slot_to_problem(a, wave * 16 + v + a.p0, n_list, live);
   const int tb = 8 * g;                          // this lane's offset inside a block of 32
 
   extern __shared__ __attribute__((aligned(16))) char mf_smem[];

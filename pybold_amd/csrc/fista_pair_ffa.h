@@ -106,11 +106,14 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
   const int row = gid >> 4;
   const int base = sub * S;
   const int pA0 = SPLIT ? row + a.p0 : 2 * row + a.p0, pB0 = SPLIT ? pA0 : pA0 + 1;
-  const bool liveA = pA0 < a.P, liveB = pB0 < a.P;
+  const int n_list = list_length(a);              // (a.P without a partition; else the length of this launch's list)
+  // the four rows of this wave all lie beyond the list: leave (wave-level synchronisation only below)
+  if ((SPLIT ? 4 : 8) * (gid >> 6) + a.p0 >= n_list) return;
+  bool liveA, liveB;
   // samples of the series held by slot A / slot B, and where slot B starts in the row
   const int nA = SPLIT ? 16 * S : a.N, nB = SPLIT ? a.N - 16 * S : a.N, oB = SPLIT ? 16 * S : 0;
-  const int pA = liveA ? pA0 : a.P - 1;
-  const int pB = liveB ? pB0 : a.P - 1;
+  const int pA = slot_to_problem(a, pA0, n_list, liveA);
+  const int pB = slot_to_problem(a, pB0, n_list, liveB);
 
   extern __shared__ __attribute__((aligned(16))) char pair_smem[];
   const int rslot = (threadIdx.x >> 4) * S * 16;

@@ -35,6 +35,8 @@ _FORCE = {None: 0, "generic": PB_FLAG_FORCE_GENERIC, "fast": PB_FLAG_FORCE_FAST,
           "valu": _lib.PB_FLAG_NO_MFMA, "valuseq": _lib.PB_FLAG_NO_MFMA | PB_FLAG_ONE_STREAM,
           "mfma": PB_FLAG_ONE_LAUNCH | _lib.PB_FLAG_FORCE_MFMA,
           # "mfma2": everything on the matrix-pipe form with each series split over two waves, one launch
+          # pb_fista_solve_path, measurement aids: only the dense list's launch / only the sparse list's
+          "path_dense": _lib.PB_FLAG_FORCE_MFMA, "path_sparse": PB_FLAG_FORCE_PAIR,
           "mfma2": _lib.PB_FLAG_FORCE_MFMA2, "mfma2only": _lib.PB_FLAG_FORCE_MFMA2 | _lib.PB_FLAG_CERT_NO_RESOLVE,
           # intermediate solve of an outer loop: the matrix-pipe form keeps sparse iterates (no accuracy guard)
           "intermediate": _lib.PB_FLAG_NO_RHO_GUARD,
@@ -190,7 +192,7 @@ def launch_plan(n_scans, n_taps, n_problems, stop=None, wind=6, force=None):
 
 
 def fista_solve(Y, hrf, lbda, step, n_iter, W0=None, want_J=False, stop=None,
-                tol=0.0, wind=6, y_rep=1, force=None):
+                tol=0.0, wind=6, y_rep=1, force=None, lmax=None, dense_ratio=0.0):
     """Run ``n_iter`` iterations of the reference recurrence
     (pybold/bold_signal.py:62-72, :259-276) for every row of ``Y`` in one launch.
 
@@ -203,6 +205,9 @@ def fista_solve(Y, hrf, lbda, step, n_iter, W0=None, want_J=False, stop=None,
     step  ``1 / L``
     W0    optional float64 CUDA ``(P, N)`` warm start (not modified)
     stop  None | "loops" (_loops_deconv rule) | "window" (deconv rule)
+    lmax  optional float64 CUDA ``(V,)``: :func:`lambda_max` of every series.  With per-problem ``lbda`` it turns a
+          plain solve into ``pb_fista_solve_path``: the problems with ``lbda < dense_ratio * lmax`` (default 0.13) run on
+          the matrix-pipe form, the sparse rest on the float32 vector form -- a regularisation path, BASELINE config 5
     Returns ``(W float64 (P, N), J float32 (P, n_iter) or None, n_done int32 (P,))``.
     """
     lib = _lib.load()
@@ -250,6 +255,18 @@ def fista_solve(Y, hrf, lbda, step, n_iter, W0=None, want_J=False, stop=None,
                 _stream_ptr(dev))
         _lib.check(rc, "pb_fista_solve_d")
         return W, J, n_done
+    if lmax is not None and lbda_dev is not None and not want_J and _STOP[stop] == PB_STOP_NONE:
+        lmax = lmax.to(device=dev, dtype=torch.float64).contiguous().ravel()
+        if lmax.numel() != V:
+            raise ValueError("lmax must have one entry per series (%d)" % V)
+        work = torch.empty((int(lib.pb_fista_path_work_len(P)),), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.pb_fista_solve_path(
+                Y.data_ptr(), _ld(Y), int(y_rep), W.data_ptr(), _ld(W), P, N, taps.ctypes.data, taps_dev.data_ptr(),
+                taps.size, float(step), lbda_dev.data_ptr(), lmax.data_ptr(), float(dense_ratio), betas.data_ptr(),
+                int(n_iter), n_done.data_ptr(), work.data_ptr(), work.numel(), _FORCE[force] | cold, _stream_ptr(dev))
+        _lib.check(rc, "pb_fista_solve_path")
+        return W, J, n_done
     _warn_if_slow_kernel(lib, N, taps.size, P, want_J, stop, wind, _FORCE[force])
     with torch.cuda.device(dev):
         rc = lib.pb_fista_solve(
@@ -272,7 +289,7 @@ class FistaPlan:
     remainder on others, part of it on the library's side stream (forked from and joined back
     into the current stream; see ``include/pybold_hip.h``)."""
 
-    def __init__(self, Y, hrf, lbda, step, n_iter, y_rep=1, force="fast", W=None):
+    def __init__(self, Y, hrf, lbda, step, n_iter, y_rep=1, force="fast", W=None, lmax=None, dense_ratio=0.0):
         self.lib = _lib.load()
         self.Y = _rows(Y, torch.float32, "Y")
         self.dev = self.Y.device
@@ -297,10 +314,27 @@ class FistaPlan:
         self.n_iter = int(n_iter)
         self.betas = _betas_on(self.dev, self.n_iter)
         self.flags = _FORCE[force]
+        # regularisation path (per-problem lambdas + lambda_max of every series): pb_fista_solve_path
+        self.lmax, self.work, self.dense_ratio = None, None, float(dense_ratio)
+        if lmax is not None and self.lbda_dev is not None:
+            self.lmax = lmax.to(device=self.dev, dtype=torch.float64).contiguous().ravel()
+            if self.lmax.numel() != V:
+                raise ValueError("lmax must have one entry per series (%d)" % V)
+            self.work = torch.empty((int(self.lib.pb_fista_path_work_len(self.P)),), dtype=torch.int32, device=self.dev)
 
     def launch(self, cold=False):
         """Only the solver launch: the iterate continues from its current value, or
         (``cold``) starts from 0 without being read."""
+        if self.lmax is not None:
+            with torch.cuda.device(self.dev):
+                rc = self.lib.pb_fista_solve_path(
+                    self.Y.data_ptr(), _ld(self.Y), self.y_rep, self.W.data_ptr(), _ld(self.W), self.P, self.N,
+                    self.taps.ctypes.data, self.taps_dev.data_ptr(), self.taps.size, self.step, self.lbda_dev.data_ptr(),
+                    self.lmax.data_ptr(), self.dense_ratio, self.betas.data_ptr(), self.n_iter, self.n_done.data_ptr(),
+                    self.work.data_ptr(), self.work.numel(), self.flags | (PB_FLAG_COLD_START if cold else 0),
+                    _stream_ptr(self.dev))
+            _lib.check(rc, "pb_fista_solve_path")
+            return
         # the library finds its per-device side stream and wave count through the CURRENT device
         with torch.cuda.device(self.dev):
             rc = self.lib.pb_fista_solve(

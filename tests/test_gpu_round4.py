@@ -243,3 +243,55 @@ def test_split_matrix_pipe_form_guards_and_shared_hrf(solver, golden):
     assert rel_rows(Wp.cpu().numpy()[idx], Wop).max() < 1e-5
     Wv, _ = solver.fista_solve_pp(Yb, taps, stepc, 1.7, 60, force="valu")
     assert float(((Wp - Wv).norm(dim=1) / Wv.norm(dim=1)).max()) < 4e-6
+
+
+# ---- regularisation path partitioned on the device (pb_fista_solve_path) -------------------------------------------
+def test_regularisation_path_partition(solver, golden):
+    """BASELINE config 5's workload (voxel x 20 lambdas = logspace(-2, 0, 20) x lambda_max,v, y shared) through
+    `pb_fista_solve_path`: the dense class on the matrix-pipe form, the sparse class on the pair form, the lists built
+    on the device.  Every problem equals the plain per-problem-lambda dispatch (vector forms) within the split-operand
+    rounding and the C float64 oracle within eps, across all 20 lambda indices; the top of the path is exactly 0;
+    partition ratios from "everything sparse" to "everything dense" (the guards then hand the sparse third back),
+    ragged sizes, one lambda per series, an all-zero series."""
+    from oracle import c_oracle
+    from pybold_amd import data
+    g = golden("case1")
+    hrf, lip = g["hrf"], float(g["lipschitz"])
+    V, L, N = 2100, 20, 300
+    Y, _, _ = data.gen_rnd_bloc_bold_batch(V, dur=5.0, tr=1.0, hrf=hrf, nb_events=5, avg_dur=12.0, std_dur=1.0, snr=1.0, seed=9)
+    Y[17] = 0.0
+    lmax = solver.lambda_max(Y, hrf)
+    grid = torch.logspace(-2.0, 0.0, L, dtype=torch.float64, device="cuda")
+    lam = (lmax[:, None] * grid[None, :]).reshape(-1)
+    lam[17 * L:18 * L] = 1.0
+    P = V * L
+    Wv, _, ndv = solver.fista_solve(Y, hrf, lam, 1.0 / lip, 300, y_rep=L)
+    W, _, nd = solver.fista_solve(Y, hrf, lam, 1.0 / lip, 300, y_rep=L, lmax=lmax)
+    assert int(nd.min()) == 300 and int(nd.max()) == 300 and bool(torch.isfinite(W).all())
+    nrm = Wv.norm(dim=1)
+    assert bool((W[nrm == 0] == 0).all())                      # lambda_max and the all-zero series: exactly 0
+    assert float(((W - Wv).norm(dim=1)[nrm > 0] / nrm[nrm > 0]).max()) < 4e-6
+    # the dense class did run on the matrix pipe: different bits from the vector forms there, equal bits in the sparse class
+    dense = (lam < 0.13 * lmax.repeat_interleave(L))
+    assert 0.45 < float(dense.double().mean()) < 0.65
+    assert not bool((W[dense] == Wv[dense]).all())
+    _, _, nd0 = solver.fista_solve(Y, hrf, lam, 1.0 / lip, 300, y_rep=L, lmax=lmax, force="noresolve")
+    assert float((nd0[dense] < 0).double().mean()) < 0.03 and int((nd0[~dense] < 0).sum()) == 0
+    rng = np.random.RandomState(3)
+    idx = np.sort(np.concatenate([rng.choice(V, 6, replace=False) * L + i for i in range(L)]))     # every lambda index
+    Ys = Y[torch.from_numpy(idx // L).cuda()].cpu().numpy().astype(np.float64)
+    Wo, _, _ = c_oracle.fista_batch(Ys, hrf, lam.cpu().numpy()[idx], 1.0 / lip, 300, threads=0)
+    ok = np.linalg.norm(Wo, axis=1) > 0
+    assert rel_rows(W.cpu().numpy()[idx][ok], Wo[ok]).max() < 1e-5
+    # other ratios: all sparse (bitwise the vector dispatch), all dense (the guards + re-solve take care of the sparse third)
+    Ws, _, _ = solver.fista_solve(Y, hrf, lam, 1.0 / lip, 300, y_rep=L, lmax=lmax, dense_ratio=1e-9)
+    assert float(((Ws - Wv).norm(dim=1)[nrm > 0] / nrm[nrm > 0]).max()) < 2e-6     # (pair form vs the plan of the default dispatch)
+    Wd, _, ndd = solver.fista_solve(Y, hrf, lam, 1.0 / lip, 300, y_rep=L, lmax=lmax, dense_ratio=1e9)
+    assert int(ndd.min()) == 300 and float(((Wd - Wv).norm(dim=1)[nrm > 0] / nrm[nrm > 0]).max()) < 4e-6
+    # ragged: one lambda per series (y_rep = 1), a count that fills no block, warm start
+    lam1 = lmax * torch.from_numpy(rng.choice([0.01, 0.05, 0.3, 0.9], V)).cuda()
+    W0 = torch.from_numpy(1e-3 * rng.randn(V - 3, N)).cuda()
+    Wa, _, nda = solver.fista_solve(Y[:V - 3], hrf, lam1[:V - 3], 1.0 / lip, 120, W0=W0, lmax=lmax[:V - 3])
+    Wb, _, _ = solver.fista_solve(Y[:V - 3], hrf, lam1[:V - 3], 1.0 / lip, 120, W0=W0)
+    nb = Wb.norm(dim=1)
+    assert int(nda.min()) == 120 and float(((Wa - Wb).norm(dim=1)[nb > 0] / nb[nb > 0]).max()) < 4e-6
