@@ -563,12 +563,21 @@ def run_config4(args, world, rank, dev, dist, V, V_total, lo, timed, timed_local
                                            std_dur=1.0, snr=10.0, seed=4000 + rank, device=dev)
     comm = distributed.Comm()                    # RCCL under torchrun, gloo in the rehearsal, nothing for one process
     res = {}
+    # one bench step = one whole bd_shared call, submitted as ONE HIP graph (captured once: 21 z-steps, normal
+    # equations, all-reduces, theta fits -- ~130 launches); the eager loop where capture is not possible (gloo rehearsal)
+    runner = distributed.BdSharedGraph(Y, t_r, lbda=lbda, theta_0=2.0, hrf_dur=hrf_dur, nb_iter=nb_outer,
+                                       nb_inner=nb_inner, comm=comm)
 
     def one_step():
-        res["W"], res["h"], res["d"] = distributed.bd_shared(Y, t_r, lbda=lbda, theta_0=2.0, hrf_dur=hrf_dur,
-                                                             nb_iter=nb_outer, nb_inner=nb_inner, comm=comm)
+        runner.launch()
 
     elapsed, step_ms = timed(one_step, args.steps, args.warmup, args.spin_seconds)
+    res["W"], res["h"], res["d"] = runner.result()
+
+    def eager_step():
+        distributed.bd_shared(Y, t_r, lbda=lbda, theta_0=2.0, hrf_dur=hrf_dur, nb_iter=nb_outer, nb_inner=nb_inner, comm=comm)
+    el_eager, _ = timed(eager_step, max(2, min(args.steps, 5)), 1, 0.0)       # (every rank: the loop holds collectives)
+    eager_ms = el_eager / max(2, min(args.steps, 5)) * 1e3
     n_z = nb_outer + 1
     value = float(V_total) * n_z * nb_inner * args.steps / elapsed
     d = res["d"]
@@ -629,7 +638,10 @@ def run_config4(args, world, rank, dev, dist, V, V_total, lo, timed, timed_local
                                                    "its step constant and the cost folded in)",
                    "parallelism": "contiguous voxel shards x%d; ONE all-reduce (SUM) of %d float64 per outer "
                                   "iteration" % (world, K * K + K + 2)},
-        "config4": {"end_to_end_ms": ms_step, "z_steps_ms": z_ms, "theta_steps_and_glue_ms": ms_step - z_ms,
+        "config4": {"end_to_end_ms": ms_step, "submission": ("one HIP graph per bd_shared call" if runner.graph is not None
+                                                             else "eager loop (%s)" % runner.fallback),
+                    "eager_loop_end_to_end_ms": eager_ms,
+                    "z_steps_ms": z_ms, "theta_steps_and_glue_ms": ms_step - z_ms,
                     "z_step_fraction": z_ms / ms_step,
                     "theta_final": float(theta[-1]), "theta_true": theta_true,
                     "theta_trajectory": [round(float(t), 9) for t in theta],

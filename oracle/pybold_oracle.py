@@ -303,6 +303,36 @@ def loops_deconv(y, diff_z, H, lbda, nb_iter, early_stopping, wind, tol):
     return w
 
 
+def loops_batch(Y, hrf, lbda, step, nb_iter, tol, W0=None):
+    """The recurrence and stop rule of :func:`loops_deconv` (pybold/bold_signal.py:259-276) for every row of ``Y``
+    with the matrix-free operator and a given ``step`` (any constant step: the rule does not depend on how it was
+    chosen).  Returns ``(W, n_done)``: a row that meets ``||w_{k+1} - u_k|| / (||w_{k+1}|| + 1e-10) < tol`` at
+    iteration ``j > 2`` keeps its ``w_{k+1}`` and ``n_done = j + 1``; the others run ``nb_iter`` iterations.
+    Equal to :func:`loops_deconv` row by row when ``step = 1 / ||A^T A||_F`` (tests/test_oracle_golden.py)."""
+    Y = np.atleast_2d(np.asarray(Y, dtype=np.float64))
+    V, n = Y.shape
+    hrf = np.asarray(hrf, dtype=np.float64)
+    W = np.zeros((V, n)) if W0 is None else np.array(W0, dtype=np.float64)
+    H = _MatrixFreeH(hrf)
+    betas = momentum_sequence(nb_iter)
+    th = lbda * step
+    active = np.ones(V, dtype=bool)
+    n_done = np.full(V, nb_iter, dtype=np.int64)
+    out = W.copy()
+    for j in range(nb_iter):
+        U = W - step * H.adj(H.op(W) - Y)
+        P = soft_threshold(U, th)
+        W = P + betas[j] * (P - (U if j > 0 else 0.0))
+        if j > 2:
+            crit = np.linalg.norm(W - U, axis=1) / (np.linalg.norm(W, axis=1) + 1.0e-10)
+            fire = active & (crit < tol)
+            out[fire] = W[fire]
+            n_done[fire] = j + 1
+            active &= ~fire
+    out[active] = W[active]
+    return out, n_done
+
+
 # --------------------------------------------------------------------------
 # HRF model and the blind loop
 # --------------------------------------------------------------------------

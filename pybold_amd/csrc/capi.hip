@@ -698,10 +698,10 @@ int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mod
       return FORM_PAIR;
   const FastEntry* fe = pick_fast(N, K);
   if (!fe && mfma_plain) return mfma_wide_base(P, false) > 0 ? FORM_MFMA : FORM_WIDE;
-  if (fe && (pair_carries(fe, stop_mode, wind) || stop_mode == PB_STOP_NONE) &&
-      pick_mfma(N, K, stop_mode != PB_STOP_NONE)) {   // plain solves and the window-rule certificate
+  if (fe && (pair_carries(fe, stop_mode, wind) || stop_mode == PB_STOP_NONE || (stop_mode == PB_STOP_LOOPS && !with_cost_trace)) &&
+      pick_mfma(N, K, stop_mode != PB_STOP_NONE)) {   // plain solves, the window-rule certificate, the _loops_deconv rule
     Piece pc[6];
-    plan_pieces_mfma(P, fe->fn_pair != nullptr, pick_wide_small(N, K) != nullptr, false, false, mfma2_ok, pc);
+    plan_pieces_mfma(P, fe->fn_pair != nullptr && stop_mode != PB_STOP_LOOPS, pick_wide_small(N, K) != nullptr, false, false, mfma2_ok, pc);
     return pc[0].form;
   }
   if (fe && stop_mode == PB_STOP_WINDOW && (!ring_wind(wind) || fe->S > 20)) fe = nullptr;
@@ -740,10 +740,10 @@ int pb_fista_plan_ex(int N, int K, int P, int stop_mode, int wind, unsigned flag
     if (base > 0 && base < P) { nm = base; mf = FORM_MFMA; tf = FORM_WIDE; }
     else tf = base > 0 ? FORM_MFMA : FORM_WIDE;
   } else if (N >= 1 && K >= 1 && P >= 1 && !no_mfma && pick_fast(N, K) &&
-             (pair_carries(pick_fast(N, K), stop_mode, wind) || stop_mode == PB_STOP_NONE) &&
+             (pair_carries(pick_fast(N, K), stop_mode, wind) || stop_mode == PB_STOP_NONE || stop_mode == PB_STOP_LOOPS) &&
              pick_mfma(N, K, stop_mode != PB_STOP_NONE)) {
     Piece pc[6];
-    const int npc = plan_pieces_mfma(P, pick_fast(N, K)->fn_pair != nullptr, pick_wide_small(N, K) != nullptr,
+    const int npc = plan_pieces_mfma(P, pick_fast(N, K)->fn_pair != nullptr && stop_mode != PB_STOP_LOOPS, pick_wide_small(N, K) != nullptr,
                                      (flags & PB_FLAG_ONE_LAUNCH) != 0, (flags & PB_FLAG_ONE_STREAM) != 0, mfma2_ok, pc);
     int i = 1;
     while (i < npc && pc[i].form == pc[0].form) ++i;
@@ -912,7 +912,9 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
   // (its bound rests on four tracked samples per problem instead of sixteen: only where the rule is
   // far from firing, tol * n_iter < 0.02; closer calls stay on the pair form)
   const bool mfma_cert = cert && ((flags & PB_FLAG_FORCE_MFMA) || tol * (double)n_iter < 0.02);
-  const mfma_launch_fn mfma = (fe && (stop_mode == PB_STOP_NONE || mfma_cert) && n_done_dev &&
+  // (the _loops_deconv rule rides it too, evaluated exactly inside the kernel: no cost trace, K <= 33)
+  const bool mfma_loops = stop_mode == PB_STOP_LOOPS && !J_dev && K <= MFMA_K2;
+  const mfma_launch_fn mfma = (fe && (stop_mode == PB_STOP_NONE || mfma_cert || mfma_loops) && n_done_dev &&
                                (!lbda_dev || (flags & PB_FLAG_FORCE_MFMA)) &&
                                !(flags & (PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_DIRECT_FIR | PB_FLAG_NO_MFMA)))
                                   ? pick_mfma(N, K, stop_mode != PB_STOP_NONE) : nullptr;

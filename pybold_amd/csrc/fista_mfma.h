@@ -162,9 +162,15 @@ __device__ __forceinline__ f4 mma3(const Frag& A, const Frag& B, f4 acc) {
 #ifndef PB_MFMA_KATTR
 #define PB_MFMA_KATTR
 #endif
-template <int NB, bool WITH_J = false, bool TAPS_DEV = false, bool CERT = false, int NT = 2>
+// LOOPS: the _loops_deconv stop rule (pybold/bold_signal.py:267-273), EXACT: ||w_{k+1} - u_k|| / (||w_{k+1}|| + 1e-10)
+//   < tol from the fourth iteration on.  With w_{k+1} = u_k - (1 + beta) d, d = clamp(u_k, +-th), the numerator is
+//   (1 + beta) ||d||: two float64 multiply-adds per sample next to the update.  A problem that meets the rule is
+//   written out at that moment (after a range / accuracy check of its own) and its lanes keep iterating, results
+//   discarded -- as in fista_fast.h.  Plain variant only (no cost trace, taps as kernel arguments, two near tiles).
+template <int NB, bool WITH_J = false, bool TAPS_DEV = false, bool CERT = false, int NT = 2, bool LOOPS = false>
 __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs a, MfmaTaps tp) {
   static_assert(NT == 2 || NT == 3, "two near tiles (K <= 33) or three (K <= 65)");
+  static_assert(!LOOPS || (!WITH_J && !TAPS_DEV && !CERT && NT == 2), "the stop rule rides the plain variant");
   constexpr int LCW = NT == 2 ? 64 : 96;           // cumulative taps kept per wave: lags 0 .. 32 NT - 1
   static_assert(!CERT || (WITH_J && !TAPS_DEV), "the certificate runs in the rotated (cost trace) loop");
   const int lane = threadIdx.x & 63;
@@ -307,6 +313,8 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
   // CERT: tracked sample = sample 3 of block CQ[g] (one block per lane group, spread over the series)
   constexpr int CQ0 = NB / 8, CQ1 = (3 * NB) / 8, CQ2 = (5 * NB) / 8, CQ3 = (7 * NB) / 8;
   static_assert(!CERT || (CQ0 < CQ1 && CQ1 < CQ2 && CQ2 < CQ3), "four distinct blocks");
+  double ldsq0 = 0.0, ldsq1 = 0.0, lwsq0 = 0.0, lwsq1 = 0.0;     // LOOPS: this lane's parts of ||d||^2 and ||w_{k+1}||^2
+  bool lactive = true;                           // LOOPS: this problem has not met its rule yet
   double cu = 0.0, cw = 0.0;                     // u_k and w_{k+1} of the tracked sample
   float jw2 = 0.0f, cvsq = 0.0f;                 // this lane's ||w||^2 part, its v^2
   bool cflag = false;
@@ -449,6 +457,10 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
       const double u = fma(nstep, gj, w[q][j]);
       const double d = fmin(fmax(u, -th), th);
       w[q][j] = fma(nb1, d, u);
+      if constexpr (LOOPS) {
+        if constexpr ((j & 1) == 0) { ldsq0 = fma(d, d, ldsq0); lwsq0 = fma(w[q][j], w[q][j], lwsq0); }
+        else { ldsq1 = fma(d, d, ldsq1); lwsq1 = fma(w[q][j], w[q][j], lwsq1); }
+      }
       if constexpr (CERT && j == 3 && (q == CQ0 || q == CQ1 || q == CQ2 || q == CQ3)) {
         constexpr int gq = q == CQ0 ? 0 : (q == CQ1 ? 1 : (q == CQ2 ? 2 : 3));
         cu = (g == gq) ? u : cu;
@@ -522,7 +534,42 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
     for (int it = 0; it < a.n_iter; ++it) {
       const double beta = a.betas[it];
       forward();
+      if constexpr (LOOPS) { ldsq0 = ldsq1 = lwsq0 = lwsq1 = 0.0; }
       backward(beta);
+      if constexpr (LOOPS) {
+        double num = ldsq0 + ldsq1, den = lwsq0 + lwsq1;     // this lane's 8 NB samples -> the problem's 32 NB
+        num += __shfl_xor(num, 16, 64);
+        den += __shfl_xor(den, 16, 64);
+        num += __shfl_xor(num, 32, 64);
+        den += __shfl_xor(den, 32, 64);
+        // ||w' - u|| = (1 + beta) ||d||; everything lives at the scale sigma, and so does the reference's 1e-10 floor
+        const bool fire = lactive && it >= 3 &&
+                          (1.0 + beta) * sqrt(num) / (sqrt(den) + 1.0e-10 * (double)sigma) < a.tol;
+        if (__builtin_amdgcn_ballot_w64(fire) != 0) {         // (rare: at most once per problem)
+          range_check();                                      // this moment's operands, for the problems that finish now
+          float gq = guard, wq = wlast;
+          gq = fmaxf(gq, __shfl_xor(gq, 16, 64));
+          gq = fmaxf(gq, __shfl_xor(gq, 32, 64));
+          wq = fmaxf(wq, __shfl_xor(wq, 16, 64));
+          wq = fmaxf(wq, __shfl_xor(wq, 32, 64));
+          const bool badq = !(gq < 60000.0f) || (a.rho_guard && wq > 0.0f && (float)th > MFMA_RHO_MAX * wq);
+          if (fire) {
+            lactive = false;
+            if (live && !badq) {
+              double* wrow = a.w + (int64_t)p * a.ldw;
+#pragma unroll
+              for (int q = 0; q < NB; ++q)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                  const int t = 32 * q + tb + j;
+                  if (t < a.N) wrow[t] = w[q][j] * (double)inv_sigma;
+                }
+            }
+            if (live && a.n_done && g == 0) a.n_done[p] = badq ? -1 : it + 1;
+          }
+          if (__builtin_amdgcn_ballot_w64(lactive && live) == 0) return;       // every problem of the wave has finished
+        }
+      }
       // (a warm start may overshoot in its first iterations -- the blind loop changes the HRF gain 2-4x between
       // z-steps -- and come back into range before iteration 7: it is checked right after its first pass too)
       if (PB_MFMA_CHECKS && (((it & 7) == 7) || (it == a.n_iter - 1) || (it == 0 && !a.cold))) range_check();
@@ -567,7 +614,7 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
   // operators like those that left the float16 range.
   const bool bad = !(guard < 60000.0f) ||        // NaN-safe (float16: 65504)
                    (a.rho_guard && wlast > 0.0f && (float)th > MFMA_RHO_MAX * wlast) || (CERT && cflag);
-  if (live && !bad) {
+  if (live && !bad && (!LOOPS || lactive)) {
     double* wrow = a.w + (int64_t)p * a.ldw;
 #pragma unroll
     for (int q = 0; q < NB; ++q)
@@ -577,7 +624,7 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
         if (t < a.N) wrow[t] = w[q][j] * (double)inv_sigma;
       }
   }
-  if (live && a.n_done && g == 0) a.n_done[p] = bad ? -1 : a.n_iter;
+  if (live && a.n_done && g == 0 && (!LOOPS || lactive)) a.n_done[p] = bad ? -1 : a.n_iter;
 }
 
 // 16 problems per wave, 4 waves per workgroup, one wave per SIMD.  NT near tiles: 2 for K <= 33, 3 for
@@ -591,6 +638,17 @@ int launch_mfma_nt(const FistaArgs& a, const double* taps, int K, bool with_j, h
   const int64_t waves = ((int64_t)(a.P - a.p0) + 15) / 16;
   const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
   const bool cert = a.stop_mode == PB_STOP_WINDOW;
+  if (a.stop_mode == PB_STOP_LOOPS) {            // the exact _loops_deconv rule: plain variant with two near tiles only
+    if constexpr (NT == 2) {
+      if (!a.n_done || a.taps_pp || with_j) return 1;
+      const size_t lds0 = (size_t)4 * NB * 2 * 64 * sizeof(u4) + 4 * 64 * sizeof(float);
+      const MfmaTaps tp0 = make_mfma_taps(taps, K);
+      hipLaunchKernelGGL((fista_mfma_kernel<NB, false, false, false, 2, true>), grid, block, lds0, st, a, tp0);
+      return 0;
+    } else {
+      return 1;
+    }
+  }
   if (cert && (!a.n_done || a.taps_pp)) return 1;
   if (NT == 3 && cert) return 1;               // (the certificate's state spills beside three near tiles: 260 B per lane)
   const size_t lds = (size_t)4 * NB * 2 * 64 * sizeof(u4) + 4 * (NT == 2 ? 64 : 96) * sizeof(float) +    // residual fragments (8 KB per block of 32 samples), taps

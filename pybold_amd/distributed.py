@@ -155,35 +155,12 @@ class HipOps:
         return self.s.theta_fit_step(msg, self.t_r, self.hrf_dur, bounds, self.n, lbda)
 
 
-def bd_shared(Y, t_r, lbda=1.0, theta_0=None, hrf_dur=20.0, bounds=None, nb_iter=20,
-              nb_inner=100, comm=None, verbose=0, theta_solver="device", ops=None):
-    """Semi-blind deconvolution with ONE HRF dilation shared by all voxels of
-    all ranks (BASELINE config 4).  ``Y`` is this rank's shard, float32 CUDA
-    ``(V_local, N)`` (may be empty).  Structure of ``bd``
-    (pybold/bold_signal.py:281-382): outer loop of z-step (``nb_inner`` iterations
-    of the ``_loops_deconv`` recurrence, step ``1/||A^T A||_F``, warm-started) and
-    theta-step (see the module docstring), then a last z-step (:365-369).
-
-    Returns ``(W float64 CUDA (V_local, N), h, d)`` with ``d['theta']``,
-    ``d['J']`` (global normalised cost per outer iteration) and ``d['evals']``
-    (cost evaluations per theta-step: passes over the data for "lbfgsb", 1 for
-    "device").  With ``theta_solver="device"`` nothing is copied to the host before
-    the loop ends.
-    """
-    if theta_solver == "lbfgsb":
-        return _bd_shared_lbfgsb(Y, t_r, lbda, theta_0, hrf_dur, bounds, nb_iter, nb_inner, comm,
-                                 verbose)
-    if theta_solver != "device":
-        raise ValueError("theta_solver must be 'device' or 'lbfgsb'")
-    comm = comm or Comm()
+def _bd_shared_device_loop(Y, t_r, lbda, theta0, hrf_dur, bounds, nb_iter, nb_inner, comm, ops):
+    """The outer loop of :func:`bd_shared` with the theta-step on the device: enqueues everything on the current
+    stream and returns device tensors only -- ``(W, taps, thetas [nb_iter + 1 tensors (1,)], costs [nb_iter + 1])``.
+    No host synchronisation, so the whole loop can be captured into one HIP graph (:class:`BdSharedGraph`)."""
     dev = Y.device
     V, n = Y.shape
-    ops = ops or HipOps(t_r, hrf_dur, n)
-    theta0 = MAX_DELTA if theta_0 is None else float(theta_0)
-    if theta0 < MIN_DELTA or theta0 > MAX_DELTA:
-        raise ValueError("theta_0 must lie in [%g, %g]" % (MIN_DELTA, MAX_DELTA))
-    if bounds is None:
-        bounds = [(MIN_DELTA + 1.0e-1, MAX_DELTA - 1.0e-1)]
     theta = torch.full((1,), theta0, dtype=torch.float64, device=dev)
     taps = ops.hrf(theta)                                        # (K,), stays on the device
     K = taps.numel()
@@ -214,12 +191,103 @@ def bd_shared(Y, t_r, lbda=1.0, theta_0=None, hrf_dur=20.0, bounds=None, nb_iter
             G, b = ne[:K * K].reshape(K, K), ne[K * K:K * K + K]
             f = (0.5 * ne[ne_len - 1] - taps.dot(b) + 0.5 * taps.dot(G.mv(taps))).reshape(1)
             costs.append((2.0 * f + lbda * msg[ne_len]) / ne[ne_len - 1])
-        if verbose > 0 and comm.rank == 0:
-            print("bd_shared outer %d: theta=%.6f J=%.6f" % (it, float(theta), float(costs[-1])))
+    return W, taps, thetas, costs
+
+
+def _check_bd_shared_args(theta_0, bounds):
+    theta0 = MAX_DELTA if theta_0 is None else float(theta_0)
+    if theta0 < MIN_DELTA or theta0 > MAX_DELTA:
+        raise ValueError("theta_0 must lie in [%g, %g]" % (MIN_DELTA, MAX_DELTA))
+    if bounds is None:
+        bounds = [(MIN_DELTA + 1.0e-1, MAX_DELTA - 1.0e-1)]
+    return theta0, bounds
+
+
+def bd_shared(Y, t_r, lbda=1.0, theta_0=None, hrf_dur=20.0, bounds=None, nb_iter=20,
+              nb_inner=100, comm=None, verbose=0, theta_solver="device", ops=None):
+    """Semi-blind deconvolution with ONE HRF dilation shared by all voxels of
+    all ranks (BASELINE config 4).  ``Y`` is this rank's shard, float32 CUDA
+    ``(V_local, N)`` (may be empty).  Structure of ``bd``
+    (pybold/bold_signal.py:281-382): outer loop of z-step (``nb_inner`` iterations
+    of the ``_loops_deconv`` recurrence, step ``1/||A^T A||_F``, warm-started) and
+    theta-step (see the module docstring), then a last z-step (:365-369).
+
+    Returns ``(W float64 CUDA (V_local, N), h, d)`` with ``d['theta']``,
+    ``d['J']`` (global normalised cost per outer iteration) and ``d['evals']``
+    (cost evaluations per theta-step: passes over the data for "lbfgsb", 1 for
+    "device").  With ``theta_solver="device"`` nothing is copied to the host before
+    the loop ends (:class:`BdSharedGraph` submits that loop as ONE HIP graph).
+    """
+    if theta_solver == "lbfgsb":
+        return _bd_shared_lbfgsb(Y, t_r, lbda, theta_0, hrf_dur, bounds, nb_iter, nb_inner, comm,
+                                 verbose)
+    if theta_solver != "device":
+        raise ValueError("theta_solver must be 'device' or 'lbfgsb'")
+    comm = comm or Comm()
+    ops = ops or HipOps(t_r, hrf_dur, Y.shape[1])
+    theta0, bounds = _check_bd_shared_args(theta_0, bounds)
+    W, taps, thetas, costs = _bd_shared_device_loop(Y, t_r, lbda, theta0, hrf_dur, bounds, nb_iter, nb_inner, comm, ops)
     d = {"theta": torch.cat(thetas).cpu().numpy(),
          "J": np.concatenate([[1.0], torch.cat(costs).cpu().numpy()]),
          "evals": [1] * nb_iter}
+    if verbose > 0 and comm.rank == 0:
+        for it in range(nb_iter + 1):
+            print("bd_shared outer %d: theta=%.6f J=%.6f" % (it, d["theta"][min(it + 1, nb_iter)], d["J"][it + 1]))
     return W, taps.cpu().numpy(), d
+
+
+class BdSharedGraph:
+    """:func:`bd_shared` (``theta_solver="device"``) as ONE submission: the whole outer loop -- ``nb_iter + 1`` z-steps,
+    normal equations, the all-reduce of each outer iteration (RCCL collectives can be captured) and the theta fits,
+    ~6 launches per outer iteration -- is captured once into a HIP graph on the data it was built for and replayed by
+    :meth:`launch`.  At small shards the loop is bound by its ~130 dependent launches (21 x 3 ... 6), not by the kernels:
+    6 250 voxels 6.6 ms eager.  ``Y`` may be refilled in place between launches (same shape).
+
+    Falls back to the eager loop (``self.graph is None``, reason in ``self.fallback``) when capture is not possible:
+    a communicator that cannot be captured (gloo), or a capture error."""
+
+    def __init__(self, Y, t_r, lbda=1.0, theta_0=None, hrf_dur=20.0, bounds=None, nb_iter=20, nb_inner=100, comm=None):
+        self.comm = comm or Comm()
+        self.Y, self.t_r, self.lbda, self.hrf_dur = Y, t_r, lbda, hrf_dur
+        self.nb_iter, self.nb_inner = nb_iter, nb_inner
+        self.theta0, self.bounds = _check_bd_shared_args(theta_0, bounds)
+        self.ops = HipOps(t_r, hrf_dur, Y.shape[1])
+        self.graph, self.fallback, self.out = None, None, None
+        self._eager()                            # warm-up: every cache (momentum factors, sample times, work buffers) filled
+        torch.cuda.synchronize(Y.device)
+        capturable = self.comm.dist is None or self.comm.device.type == "cuda"
+        if not capturable:
+            self.fallback = "communicator is not on the GPU (gloo): eager loop"
+            return
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self._loop()
+            self.graph, self.out = g, out
+        except Exception as e:                   # capture refused: keep the eager loop
+            self.graph, self.fallback = None, "capture failed: %s" % (str(e).splitlines()[0] if str(e) else type(e).__name__)
+            torch.cuda.synchronize(Y.device)
+
+    def _loop(self):
+        return _bd_shared_device_loop(self.Y, self.t_r, self.lbda, self.theta0, self.hrf_dur, self.bounds, self.nb_iter,
+                                      self.nb_inner, self.comm, self.ops)
+
+    def _eager(self):
+        self.out = self._loop()
+
+    def launch(self):
+        """Enqueue one whole ``bd_shared`` call (one graph launch, or the eager loop) on the current stream."""
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._eager()
+
+    def result(self):
+        """``(W, h, d)`` of the last :meth:`launch`, as :func:`bd_shared` returns them (synchronises)."""
+        W, taps, thetas, costs = self.out
+        d = {"theta": torch.cat(thetas).cpu().numpy(), "J": np.concatenate([[1.0], torch.cat(costs).cpu().numpy()]),
+             "evals": [1] * self.nb_iter}
+        return W, taps.cpu().numpy(), d
 
 
 def _bd_shared_lbfgsb(Y, t_r, lbda, theta_0, hrf_dur, bounds, nb_iter, nb_inner, comm, verbose):

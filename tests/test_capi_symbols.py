@@ -60,7 +60,8 @@ def test_version_and_dispatch_table(lib):
     assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 0, 6) == 4      # plain solves: both operators on the matrix pipe (round 3)
     assert lib.pb_fista_which_kernel(300, 30, 100000, 1, 0, 6) == 4      # cost trace: matrix-pipe form too
     assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 2, 6) == 4      # window rule at wind = 6: no-fire certificate on the matrix-pipe form
-    assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 1, 6) == 1      # _loops_deconv rule: single-row form
+    assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 1, 6) == 4      # _loops_deconv rule: evaluated exactly inside the matrix-pipe form (round 4)
+    assert lib.pb_fista_which_kernel(300, 30, 100000, 1, 1, 6) == 1      # ... with the cost trace: single-row form
     assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 2, 4) == 1      # wind 4 / 8: full rule, single-row form
     assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 2, 8) == 1
     assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 2, 5) == 0      # other windows: LDS kernel (the Python layer warns)

@@ -39,7 +39,7 @@ def _worker(rank, world, port, backend, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
-    if backend == "nccl":
+    if backend.startswith("nccl"):
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -51,8 +51,16 @@ def _worker(rank, world, port, backend, ret):
             lo, hi = [(0, 400), (400, 700), (700, 700)][rank]
         else:
             lo, hi = distributed.shard_bounds(V, world, rank)
-        W, h, d = distributed.bd_shared(Y[lo:hi].contiguous(), T_R, lbda=1.7, hrf_dur=DUR, nb_iter=NB_ITER,
-                                        nb_inner=NB_INNER)
+        if backend == "nccl-graph":              # the whole loop, all-reduces included, as ONE captured HIP graph
+            runner = distributed.BdSharedGraph(Y[lo:hi].contiguous(), T_R, lbda=1.7, hrf_dur=DUR, nb_iter=NB_ITER,
+                                               nb_inner=NB_INNER)
+            assert runner.graph is not None, runner.fallback
+            runner.launch()
+            runner.launch()                      # a replay gives the same answer
+            W, h, d = runner.result()
+        else:
+            W, h, d = distributed.bd_shared(Y[lo:hi].contiguous(), T_R, lbda=1.7, hrf_dur=DUR, nb_iter=NB_ITER,
+                                            nb_inner=NB_INNER)
         ret[rank] = (lo, hi, W.cpu().numpy(), h, d["theta"], d["J"])
     finally:
         dist.destroy_process_group()
@@ -64,7 +72,7 @@ def _single():
     return W.cpu().numpy(), h, d["theta"], d["J"]
 
 
-@pytest.mark.parametrize("world,backend", [(2, "gloo"), (3, "gloo"), (1, "nccl")])
+@pytest.mark.parametrize("world,backend", [(2, "gloo"), (3, "gloo"), (1, "nccl"), (1, "nccl-graph")])
 def test_bd_shared_ranks_on_one_gpu_equal_one_process(world, backend):
     W1, h1, th1, J1 = _single()
     ret = mp.Manager().dict()
@@ -81,3 +89,26 @@ def test_bd_shared_ranks_on_one_gpu_equal_one_process(world, backend):
     scale = np.abs(W1).max()
     assert np.abs(Wn - W1).max() / scale < 1e-5
     assert th1[-1] < th1[0]                                          # moved from 2.0 towards the true 0.8
+
+
+def test_bd_shared_as_one_hip_graph():
+    """`BdSharedGraph`: the whole outer loop captured once and replayed -- the same bits as the eager loop, replay
+    after replay, also after the series were refilled in place; gloo communicators fall back to the eager loop."""
+    from pybold_amd import distributed
+    Y = _batch()
+    W1, h1, th1, J1 = _single()
+    runner = distributed.BdSharedGraph(Y, T_R, lbda=1.7, hrf_dur=DUR, nb_iter=NB_ITER, nb_inner=NB_INNER)
+    assert runner.graph is not None, runner.fallback
+    for _ in range(3):
+        runner.launch()
+    W, h, d = runner.result()
+    assert np.array_equal(W.cpu().numpy(), W1) and np.array_equal(d["theta"], th1) and np.array_equal(d["J"], J1)
+    np.testing.assert_array_equal(h, h1)
+    Y2 = Y.clone()
+    Y.mul_(0.5)                                  # new data in the captured buffer
+    runner.launch()
+    Wh, hh, dh = runner.result()
+    We, he, de = distributed.bd_shared(Y, T_R, lbda=1.7, hrf_dur=DUR, nb_iter=NB_ITER, nb_inner=NB_INNER)
+    assert torch.equal(Wh, We) and np.array_equal(dh["theta"], de["theta"])
+    assert not np.array_equal(dh["theta"], th1)
+    Y.copy_(Y2)

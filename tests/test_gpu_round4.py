@@ -295,3 +295,56 @@ def test_regularisation_path_partition(solver, golden):
     Wb, _, _ = solver.fista_solve(Y[:V - 3], hrf, lam1[:V - 3], 1.0 / lip, 120, W0=W0)
     nb = Wb.norm(dim=1)
     assert int(nda.min()) == 120 and float(((Wa - Wb).norm(dim=1)[nb > 0] / nb[nb > 0]).max()) < 4e-6
+
+
+# ---- the _loops_deconv stop rule inside the matrix-pipe kernel ------------------------------------------------------
+def test_loops_rule_inside_the_matrix_pipe_kernel(solver, golden):
+    """`_loops_deconv`'s criterion ||w_{k+1} - u_k|| / (||w_{k+1}|| + 1e-10) < tol (pybold/bold_signal.py:267-273)
+    evaluated EXACTLY in `fista_mfma_kernel<..., LOOPS>` (two float64 sums per sample beside the update): the
+    iteration every problem stops at and its iterate equal the float64 oracle's -- on the golden series, and on a
+    1 000-case sweep (series x lambda x tolerance: about half of the problems stop early, spread over the run);
+    the library's dispatch puts whole rounds of such solves on that kernel."""
+    from pybold_amd import data
+    g = golden("loops_deconv")
+    y, h = g["y"], g["h"]
+    n = len(y)
+    lip = orc.gram_lipschitz(h, n)
+    Yb = np.stack([y, 0.3 * y, 3.0 * y, -y, 0.05 * y])
+    Yd = torch.from_numpy(Yb.astype(np.float32)).cuda()
+    Y32 = Yb.astype(np.float32).astype(np.float64)
+    for tol in (1e-2, 1e-3, 2e-2):
+        Wo, ndo = orc.loops_batch(Y32, h, 1.7, 1.0 / lip, 100, tol)
+        W, _, nd = solver.fista_solve(Yd, h, 1.7, 1.0 / lip, 100, stop="loops", tol=tol, force="mfma")
+        assert (nd.cpu().numpy() == ndo).all(), (tol, nd.cpu().numpy(), ndo)
+        assert rel_rows(W.cpu().numpy(), Wo).max() < 1e-5
+    assert solver.launch_plan(n, len(h), 100000, stop="loops")[1].startswith("fista_mfma_kernel")
+    # sweep: 250 series x 4 (lambda, tolerance) pairs, N = 300, K = 30: stops spread over iterations 40 .. 400,
+    # a quarter of the problems never stop
+    g1 = golden("case1")
+    hrf, lip1 = g1["hrf"], float(g1["lipschitz"])
+    rng = np.random.RandomState(12)
+    Z = np.zeros((250, 300))
+    for v in range(250):
+        for _ in range(5):
+            o = rng.randint(0, 280)
+            Z[v, o:o + rng.randint(8, 16)] = 1.0
+    X = orc.causal_conv(hrf, Z)
+    noise = rng.randn(250, 300)
+    noise *= (np.linalg.norm(X, axis=1) / np.linalg.norm(noise, axis=1) / np.sqrt(10 ** (np.linspace(-5, 20, 250) / 10)))[:, None]
+    Y = torch.from_numpy((X + noise).astype(np.float32)).cuda()
+    Yh = Y.cpu().numpy().astype(np.float64)
+    cases = early = 0
+    for lbda, tol in ((0.5, 1e-4), (0.5, 2e-4), (2.0, 2.5e-4), (2.0, 2.7e-4)):
+        Wo, ndo = orc.loops_batch(Yh, hrf, lbda, 1.0 / lip1, 400, tol)
+        W, _, nd = solver.fista_solve(Y, hrf, lbda, 1.0 / lip1, 400, stop="loops", tol=tol, force="mfma")
+        assert (nd.cpu().numpy() == ndo).all(), (lbda, tol, int((nd.cpu().numpy() != ndo).sum()))
+        assert rel_rows(W.cpu().numpy(), Wo).max() < 1e-5
+        cases += len(ndo)
+        early += int((ndo < 400).sum())
+    assert cases == 1000 and 0.5 < early / cases < 0.95 and len(set(ndo.tolist())) > 20, early
+    # through the default dispatch: whole round on the matrix pipe + remainder on the vector forms, same rule
+    Yl = Y.repeat(70, 1)[:16384 + 500].contiguous()
+    Wl, _, ndl = solver.fista_solve(Yl, hrf, 2.0, 1.0 / lip1, 400, stop="loops", tol=2.7e-4)
+    _, ndo = orc.loops_batch(Yh, hrf, 2.0, 1.0 / lip1, 400, 2.7e-4)
+    assert (ndl.cpu().numpy() == ndo[np.arange(16384 + 500) % 250]).all()      # (the remainder: single-row / one-per-wave forms)
+    assert torch.equal(Wl[:250], Wl[250:500])

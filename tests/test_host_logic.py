@@ -183,8 +183,8 @@ def test_launch_plan_of_a_plain_solve():
     # re-solve); the _loops_deconv rule does not; shapes outside the tables go to the LDS kernel
     assert solver.launch_plan(300, 30, 100000, stop="window", force="valu") == (98304, pair, wave)
     assert solver.launch_plan(300, 30, 100000, stop="window") == (98304, solver.KERNEL_NAMES[4], wave)
-    n_main, main, tail = solver.launch_plan(300, 30, 100000, stop="loops")
-    assert main in (None, row) and tail in (row, wave)
+    n_main, main, tail = solver.launch_plan(300, 30, 100000, stop="loops")      # the exact rule inside the matrix-pipe form
+    assert (n_main, main) == (98304, solver.KERNEL_NAMES[4]) and tail in (row, wave)
     assert solver.launch_plan(5000, 30, 100) == (0, None, solver.KERNEL_NAMES[0])
 
 

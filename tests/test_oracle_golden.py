@@ -94,6 +94,19 @@ def test_loops_deconv(golden):
     lip = orc.gram_lipschitz(h, len(y))
     W = orc.fista_batch(y[None], h, 1.7, 1.0 / lip, 100)
     assert rel(W[0], g["w_n100_es0_tol1e-12"]) < 1e-9
+    # ... and its stop rule for batches (the checker of the in-kernel rule): the golden early-stopped iterates, and
+    # row by row what loops_deconv returns for scaled copies of the series (different stop iterations)
+    for tol in (1e-2, 1e-3):
+        Wb, nd = orc.loops_batch(y[None], h, 1.7, 1.0 / lip, 100, tol)
+        assert rel(Wb[0], g["w_n100_es1_tol%g" % tol]) < 1e-9 and 3 < nd[0] <= 100
+    Yb = np.stack([y, 0.3 * y, 3.0 * y, -y, 0.05 * y])
+    Wb, nd = orc.loops_batch(Yb, h, 1.7, 1.0 / lip, 60, 2e-2)
+    assert len(set(nd.tolist())) >= 2
+    for v in range(len(Yb)):
+        wv = orc.loops_deconv(Yb[v], np.zeros_like(y), H, 1.7, 60, True, 4, 2e-2)
+        assert rel(Wb[v], wv) < 1e-9
+        wn = orc.loops_deconv(Yb[v], np.zeros_like(y), H, 1.7, int(nd[v]), False, 4, 2e-2)   # stopped exactly there
+        assert rel(Wb[v], wn) < 1e-9
 
 
 def test_bd_five_outer_iterations(golden):
