@@ -68,8 +68,8 @@ def _warn_if_slow_kernel(lib, N, K, P, want_J, stop, wind, flags):
     if lib.pb_fista_which_kernel(int(N), int(K), int(P), int(bool(want_J)), _STOP[stop], int(wind)) != 0:
         return
     why = []
-    if _STOP[stop] == PB_STOP_WINDOW and wind not in (4, 5, 6, 7, 8):
-        why.append("wind=%d (register-resident window rule: 4 <= wind <= 8)" % wind)
+    if _STOP[stop] == PB_STOP_WINDOW and wind not in (4, 6, 8):
+        why.append("wind=%d (register-resident window rule: wind in {4, 6, 8})" % wind)
     if _STOP[stop] == PB_STOP_WINDOW and N > 1216:
         why.append("window rule beyond 1216 scans")
     if K > 48:
