@@ -21,6 +21,9 @@ rows = []
 def case(name, V, N, hrf, nit, **kw):
     Y = torch.randn(V, N, device="cuda", dtype=torch.float32)
     y_rep = kw.get("y_rep", 1)
+    # a step that is valid for THIS shape (1 / ||A^T A||_F <= 1 / rho): with the N = 300 constant a 600-scan solve
+    # diverges, and since round 4 the matrix-pipe forms notice (range guard -> every problem re-solved on the vector forms)
+    step = 1.0 / gram_frobenius(hrf, N)
     dt = timeit(lambda: solver.fista_solve(Y, hrf, kw.pop("lbda", 1.0) if False else kw.get("lbda", 1.0), step, nit,
                                            **{k: v for k, v in kw.items() if k != "lbda"}))
     vi = V * y_rep * nit / dt
