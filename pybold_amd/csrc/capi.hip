@@ -83,15 +83,16 @@ PB_MFMA(5) PB_MFMA(6) PB_MFMA(7) PB_MFMA(8) PB_MFMA(9) PB_MFMA(10)
 #undef PB_MFMA
 }
 namespace pb {
-#define PB_MFMA2(A, B) extern template int launch_mfma2<A, B>(const FistaArgs&, const double*, int, hipStream_t);
+#define PB_MFMA2(A, B) extern template int launch_mfma2<A, B>(const FistaArgs&, const double*, int, bool, hipStream_t);
 PB_MFMA2(2, 3) PB_MFMA2(3, 3) PB_MFMA2(3, 4) PB_MFMA2(4, 4) PB_MFMA2(4, 5) PB_MFMA2(5, 5) PB_MFMA2(5, 6) PB_MFMA2(6, 6)
 PB_MFMA2(6, 7) PB_MFMA2(7, 7) PB_MFMA2(7, 8) PB_MFMA2(8, 8) PB_MFMA2(8, 9) PB_MFMA2(9, 9) PB_MFMA2(9, 10) PB_MFMA2(10, 10)
 #undef PB_MFMA2
 }
 namespace {
 // the matrix-pipe form with one series split over the two waves of a workgroup (fista_mfma2.h): nb = ceil(N / 32)
-// blocks, 5 <= nb <= 20 (129 .. 640 scans), floor(nb / 2) of them in the left wave; K <= 33; plain solves only
-typedef int (*mfma2_launch_fn)(const pb::FistaArgs&, const double*, int, hipStream_t);
+// blocks, 5 <= nb <= 20 (129 .. 640 scans), floor(nb / 2) of them in the left wave; K <= 33; plain solves, the cost
+// trace and the window rule (wind = 6) as a no-fire certificate; the shared-HRF z-step plain only
+typedef int (*mfma2_launch_fn)(const pb::FistaArgs&, const double*, int, bool, hipStream_t);
 mfma2_launch_fn pick_mfma2(int N, int K) {
   static const mfma2_launch_fn tab[] = {
       &pb::launch_mfma2<2, 3>, &pb::launch_mfma2<3, 3>, &pb::launch_mfma2<3, 4>, &pb::launch_mfma2<4, 4>,
@@ -691,8 +692,9 @@ int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mod
   (void)with_cost_trace;
   if (N < 1 || K < 1 || P < 1) return 0;
   const bool mfma_plain = stop_mode == PB_STOP_NONE && mfma_serves_plain(N, K);
-  const bool mfma2_ok = stop_mode == PB_STOP_NONE && !with_cost_trace && pick_mfma2(N, K) != nullptr;
-  if (mfma2_ok && mfma2_serves_long(N, K) && P >= MFMA2_LONG_MIN_P) return mfma2_long_base(P, false) > 0 ? FORM_MFMA2 : FORM_WIDE;
+  const bool mfma2_ok = (stop_mode == PB_STOP_NONE || (stop_mode == PB_STOP_WINDOW && wind == 6)) && pick_mfma2(N, K) != nullptr;
+  if (mfma2_ok && mfma2_serves_long(N, K) && P >= MFMA2_LONG_MIN_P && (stop_mode == PB_STOP_NONE || pick_wide(N, K)->S <= 20))
+    return mfma2_long_base(P, false) > 0 ? FORM_MFMA2 : FORM_WIDE;
   if (const FastEntry* se = pick_split(N, K))
     if (!mfma_plain && P >= SPLIT_MIN_P && pair_carries(se, stop_mode, wind) && (stop_mode == PB_STOP_NONE || pick_wide(N, K)))
       return FORM_PAIR;
@@ -726,8 +728,10 @@ int pb_fista_plan_ex(int N, int K, int P, int stop_mode, int wind, unsigned flag
   const bool no_mfma = (flags & (PB_FLAG_NO_MFMA | PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_DIRECT_FIR)) != 0;
   const FastEntry* se = (N >= 1 && K >= 1 && P >= SPLIT_MIN_P) ? pick_split(N, K) : nullptr;
   const bool mfma_plain = N >= 1 && K >= 1 && stop_mode == PB_STOP_NONE && !no_mfma && mfma_serves_plain(N, K);
-  const bool mfma2_ok = N >= 1 && K >= 1 && stop_mode == PB_STOP_NONE && !no_mfma && pick_mfma2(N, K) != nullptr;
-  if (mfma2_ok && mfma2_serves_long(N, K) && (P >= MFMA2_LONG_MIN_P || (flags & PB_FLAG_FORCE_MFMA2))) {
+  const bool mfma2_ok = N >= 1 && K >= 1 && (stop_mode == PB_STOP_NONE || (stop_mode == PB_STOP_WINDOW && wind == 6)) && !no_mfma &&
+                        pick_mfma2(N, K) != nullptr;
+  if (mfma2_ok && mfma2_serves_long(N, K) && (P >= MFMA2_LONG_MIN_P || (flags & PB_FLAG_FORCE_MFMA2)) &&
+      (stop_mode == PB_STOP_NONE || pick_wide(N, K)->S <= 20)) {
     const int base = mfma2_long_base(P, (flags & (PB_FLAG_ONE_LAUNCH | PB_FLAG_FORCE_MFMA2)) != 0);
     if (base > 0 && base < P) { nm = base; mf = FORM_MFMA2; tf = FORM_WIDE; }
     else tf = base > 0 ? FORM_MFMA2 : FORM_WIDE;
@@ -833,23 +837,30 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
   // Series of 321..640 scans run on it from MFMA2_LONG_MIN_P problems on: whole passes (and a remainder above a
   // quarter of a pass), the rest and whatever its guards hand back on the one-problem-per-wave form.  Shorter series
   // meet it as a piece of the plan below (small batches, remainders) or through PB_FLAG_FORCE_MFMA2.
+  // (the window rule rides it as the no-fire certificate of the one-wave form: wind = 6, far from firing)
+  const bool mfma2_cert = stop_mode == PB_STOP_WINDOW && wind == 6 && n_done_dev && !(flags & PB_FLAG_NO_CERT) &&
+                          ((flags & PB_FLAG_FORCE_CERT) || tol * (double)n_iter < 0.02);
   const mfma2_launch_fn mfma2 =
-      (stop_mode == PB_STOP_NONE && !J_dev && n_done_dev && (!lbda_dev || (flags & (PB_FLAG_FORCE_MFMA | PB_FLAG_FORCE_MFMA2))) &&
+      ((stop_mode == PB_STOP_NONE || mfma2_cert) && n_done_dev && (!lbda_dev || (flags & (PB_FLAG_FORCE_MFMA | PB_FLAG_FORCE_MFMA2))) &&
        !(flags & (PB_FLAG_FORCE_GENERIC | PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_FORCE_WIDE | PB_FLAG_DIRECT_FIR |
                   PB_FLAG_NO_MFMA))) ? pick_mfma2(N, K) : nullptr;
   if (mfma2 && ((flags & PB_FLAG_FORCE_MFMA2) || (mfma2_serves_long(N, K) && P >= MFMA2_LONG_MIN_P))) {
     const FastEntry* fe1 = pick_fast(N, K);
     const WideEntry* we1 = pick_wide(N, K);
-    if (fe1 || we1) {
-      auto backup = [&](const pb::FistaArgs& b) -> int {     // the exact vector form behind it: single row, else one per wave
-        return (we1 && (!fe1 || N > 320)) ? we1->fn(b, taps_host, K, false, PB_STOP_NONE, (hipStream_t)stream)
-                                          : fe1->fn(b, taps_host, K, false, PB_STOP_NONE, (hipStream_t)stream);
+    const bool use_wide = we1 && (!fe1 || N > 320);
+    // the exact vector form behind it (remainder, re-solve): single row, else one per wave -- with the window rule it
+    // must hold the rule's increment ring (strips of at most 20 samples)
+    const bool backup_ok = (fe1 || we1) && (stop_mode == PB_STOP_NONE || (use_wide ? we1->S <= 20 : fe1->S <= 20));
+    if (backup_ok) {
+      auto backup = [&](const pb::FistaArgs& b) -> int {
+        return use_wide ? we1->fn(b, taps_host, K, J_dev != nullptr, stop_mode, (hipStream_t)stream)
+                        : fe1->fn(b, taps_host, K, J_dev != nullptr, stop_mode, (hipStream_t)stream);
       };
       const int base = (flags & PB_FLAG_FORCE_MFMA2) ? P : mfma2_long_base(P, (flags & PB_FLAG_ONE_LAUNCH) != 0);
       pb::FistaArgs b = a;
       if (base > 0) {
         b.P = base;
-        if (mfma2(b, taps_host, K, (hipStream_t)stream) != 0)
+        if (mfma2(b, taps_host, K, J_dev != nullptr, (hipStream_t)stream) != 0)
           return fail(PB_ERR_INVALID, "pb_fista_solve: split matrix-pipe kernel rejected the launch");
         const int rc = check_launch("fista_mfma2_kernel");
         if (rc != PB_OK) return rc;
@@ -929,7 +940,7 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
         return check_launch("fista_mfma_kernel");
       }
       if (form == FORM_MFMA2) {
-        if (!mfma2 || mfma2(b, taps_host, K, (hipStream_t)stream) != 0)
+        if (!mfma2 || mfma2(b, taps_host, K, J_dev != nullptr, (hipStream_t)stream) != 0)
           return fail(PB_ERR_INVALID, "pb_fista_solve: split matrix-pipe kernel rejected the launch");
         return check_launch("fista_mfma2_kernel");
       }
@@ -982,7 +993,8 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
     Piece pc[6];
     const bool one_stream = (flags & PB_FLAG_ONE_STREAM) != 0 || stream_is_capturing((hipStream_t)stream);
     const int npc = mfma ? plan_pieces_mfma(P, pair_ok, pick_wide_small(N, K) != nullptr,
-                                            (flags & PB_FLAG_ONE_LAUNCH) != 0, one_stream, mfma2 != nullptr, pc)
+                                            (flags & PB_FLAG_ONE_LAUNCH) != 0, one_stream,
+                                            mfma2 != nullptr && (stop_mode == PB_STOP_NONE || mfma_cert), pc)
                          : plan_pieces(P, pair_ok, pick_wide_small(N, K) != nullptr,
                                        (flags & PB_FLAG_ONE_LAUNCH) != 0, one_stream, pc);
     bool any_side = false;
@@ -1467,7 +1479,7 @@ int pb_fista_solve_pp(const float* y_dev, int64_t ldy, double* w_dev, int64_t ld
           pb::FistaArgs b = a;
           b.p0 = base;
           b.P = base2;
-          if (mfma2(b, nullptr, K, (hipStream_t)stream) != 0)
+          if (mfma2(b, nullptr, K, false, (hipStream_t)stream) != 0)
             return fail(PB_ERR_INVALID, "pb_fista_solve_pp: split matrix-pipe kernel rejected the launch");
           const int rc = check_launch("fista_mfma2_kernel(shared taps)");
           if (rc != PB_OK) return rc;

@@ -177,7 +177,9 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
   const int v = lane & 15, g = lane >> 4;
   const int wave = (int)((blockIdx.x * 256 + threadIdx.x) >> 6);
   const int n_list = list_length(a);              // (a.P without a partition; else the length of this launch's list)
-  if (wave * 16 + a.p0 >= n_list) return;         // the whole wave lies beyond the list (no workgroup barrier anywhere below)
+  // the whole wave lies beyond the list: leave (no workgroup barrier anywhere below; a SCALAR branch -- the wave index is
+  // the same in every lane -- so that the body does not run under a saved exec mask)
+  if (__builtin_amdgcn_readfirstlane(wave) * 16 + a.p0 >= n_list) return;
   bool live;
   const int p = slot_to_problem(a, wave * 16 + v + a.p0, n_list, live);
   const int tb = 8 * g;                          // this lane's offset inside a block of 32
@@ -272,20 +274,33 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
     for (int q = 0; q < NB; ++q)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
+        // Only the LAST block can hold padding (32 (NB-1) < N): every other load is unconditional, the last block's
+        // are branch-free (clamped address + select).  A per-lane `if` around each load put 80 exec-masked regions
+        // into this prologue, and the compiler was seen to place a VGPR -> AGPR spill INSIDE such a region
+        // (fista_mfma2.h, round 4: with the mask empty -- a cold start -- the spill never happened and its reload,
+        // an LDS address, was garbage); tools/isa_spill_lint.py looks for that pattern in the listings.
         const int t = 32 * q + tb + j;
-        const float yv = (t < a.N) ? yrow[t] : 0.0f;
+        float yv;
+        if (q == NB - 1) {
+          const float yl = yrow[t < a.N ? t : a.N - 1];
+          yv = (t < a.N) ? yl : 0.0f;
+        } else {
+          yv = yrow[t];
+        }
         ysn[q][j] = yv;
         m = fmaxf(m, fabsf(yv));
       }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
-    if (m > 0.0f && m < 3.0e38f) {
-      int e;
-      (void)frexpf(m, &e);                       // m = f 2^e, f in [0.5, 1)
+    {                                            // (branch-free too)
+      const bool okm = m > 0.0f && m < 3.0e38f;
+      int e = 0;
+      (void)frexpf(okm ? m : 1.0f, &e);          // m = f 2^e, f in [0.5, 1)
       // max |2^a sigma y| in [2^(ybits-1), 2^ybits): the residual fragments 2^a sigma (x - y) are
       // what float16 has to hold (hi part below 2^15), so the tap scale 2^a belongs in sigma
-      sigma = ldexpf(1.0f, a.ybits - e) / y_scale;
-      inv_sigma = ldexpf(1.0f, e - a.ybits) * y_scale;
+      const float sg = ldexpf(1.0f, a.ybits - e) / y_scale, isg = ldexpf(1.0f, e - a.ybits) * y_scale;
+      sigma = okm ? sg : 1.0f;
+      inv_sigma = okm ? isg : 1.0f;
     }
     const float ys = -sigma * y_scale;
     const double* wrow = a.w + (int64_t)p * a.ldw;
@@ -293,10 +308,23 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
     for (int q = 0; q < NB; ++q)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int t = 32 * q + tb + j;
         ysn[q][j] *= ys;
-        w[q][j] = (t < a.N && !a.cold) ? wrow[t] * (double)sigma : 0.0;
+        w[q][j] = 0.0;
       }
+    if (!a.cold) {                                // (the same for every lane: a scalar branch)
+#pragma unroll
+      for (int q = 0; q < NB; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int t = 32 * q + tb + j;
+          if (q == NB - 1) {
+            const double wl = wrow[t < a.N ? t : a.N - 1] * (double)sigma;
+            w[q][j] = (t < a.N) ? wl : 0.0;
+          } else {
+            w[q][j] = wrow[t] * (double)sigma;
+          }
+        }
+    }
   }
 #if PB_MFMA_YMAT
   Frag yf[NB];                                   // -2^a sigma y as float16 hi / lo fragments (B operands)

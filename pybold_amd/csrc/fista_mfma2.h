@@ -28,14 +28,20 @@
 
 namespace pb {
 
-// bytes of dynamic LDS of one workgroup (two waves; nbm = blocks of the larger half)
+// bytes of dynamic LDS of one workgroup (two waves; nbm = blocks of the larger half): residual fragments, the exchange
+// areas (fragment, far fields, scale, guards, cost-trace parts), the taps, the certificate's per-lane state
 constexpr size_t mfma2_lds_bytes(int nbm) {
-  return ((size_t)2 * nbm * 2 * 64 + 2 * 64) * sizeof(u4) + (size_t)(2 * 64 + 64 + 64 + 2 * 64 + 4 * 64) * sizeof(float);
+  return ((size_t)2 * nbm * 2 * 64 + 2 * 64) * sizeof(u4) +
+         (size_t)(2 * 64 + 64 + 64 + 2 * 64 + 4 * 64 + 6 * 64 + 7 * 128) * sizeof(float);
 }
 
 // ROLE 0: the left wave (blocks 0 .. NBA-1), ROLE 1: the right wave (blocks NBA .. NBA+NBB-1; padding in its last block)
-template <int NBA, int NBB, bool TAPS_DEV, int ROLE>
+// WITH_J: cost trace (the loop rotated as in fista_mfma.h; each wave adds up its half, the halves meet in LDS at the
+//   barrier that is there anyway).  CERT: the window rule (wind = 6) as the no-fire certificate of fista_mfma.h, four
+//   tracked samples per WAVE (eight per problem); implies WITH_J; a problem that cannot be cleared is handed back.
+template <int NBA, int NBB, bool TAPS_DEV, int ROLE, bool WITH_J = false, bool CERT = false>
 __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& tp, char* smem) {
+  static_assert(!CERT || (WITH_J && !TAPS_DEV), "the certificate runs in the rotated (cost trace) loop");
   static_assert(NBB >= NBA && NBB <= NBA + 1 && NBA >= 2 && NBB <= 10, "right half = the larger one; two blocks at least per wave");
   constexpr int NBM = NBB;                         // blocks of the larger half: the size of a wave's fragment area
   constexpr int NT = 2, LCW = 64;
@@ -60,6 +66,12 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
   float* const xr = fbase + 2 * LCW + 64 + lane;                   // [64] right -> left: S sum(r, blocks NBA+1 ..)
   float* const xm = fbase + 2 * LCW + 128;                         // [2][64] max |y| of each half
   float* const xg = fbase + 2 * LCW + 256;                         // [2][2][64] guard, largest |w| of each half
+  float* const xj = fbase + 2 * LCW + 512;                         // [2][3][64] cost-trace parts of each half: ||r||^2, ||w||_1, certificate
+  float* const lt = fbase + 2 * LCW + 896 + threadIdx.x;           // [7][128] certificate state of every lane (as fista_mfma.h)
+  if constexpr (CERT) {
+#pragma unroll
+    for (int q = 0; q < 7; ++q) lt[q * 128] = 0.0f;
+  }
   auto wave_sync = [] {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -129,8 +141,18 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
     for (int q = 0; q < NBW; ++q)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
+        // (branch-free loads: a clamped address and a select.  With a per-lane `if` around each load this compiler
+        // placed a VGPR -> AGPR spill INSIDE one of the exec-masked regions; on a cold start that mask is empty, the
+        // spill never happened and its reload -- an LDS address -- was garbage: the certificate variant at 17+ blocks)
+        // only the LAST block of the series can hold padding (32 (NBT-1) < N): every other load is unconditional
         const int t = 32 * (QOFF + q) + tb + j;
-        const float yv = (t < a.N) ? yrow[t] : 0.0f;
+        float yv;
+        if (QOFF + q == NBT - 1) {
+          const float yl = yrow[t < a.N ? t : a.N - 1];
+          yv = (t < a.N) ? yl : 0.0f;
+        } else {
+          yv = yrow[t];
+        }
         ysn[q][j] = yv;
         m = fmaxf(m, fabsf(yv));
       }
@@ -139,11 +161,13 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
     xm[ROLE * 64 + lane] = m;
     wg_sync();
     m = fmaxf(m, xm[(1 - ROLE) * 64 + lane]);
-    if (m > 0.0f && m < 3.0e38f) {
-      int e;
-      (void)frexpf(m, &e);
-      sigma = ldexpf(1.0f, a.ybits - e) / y_scale;
-      inv_sigma = ldexpf(1.0f, e - a.ybits) * y_scale;
+    {                                            // (branch-free: see the note on the loads above)
+      const bool okm = m > 0.0f && m < 3.0e38f;
+      int e = 0;
+      (void)frexpf(okm ? m : 1.0f, &e);
+      const float sg = ldexpf(1.0f, a.ybits - e) / y_scale, isg = ldexpf(1.0f, e - a.ybits) * y_scale;
+      sigma = okm ? sg : 1.0f;
+      inv_sigma = okm ? isg : 1.0f;
     }
     const float ys = -sigma * y_scale;
     const double* wrow = a.w + (int64_t)p * a.ldw;
@@ -151,14 +175,41 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
     for (int q = 0; q < NBW; ++q)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int t = 32 * (QOFF + q) + tb + j;
         ysn[q][j] *= ys;
-        w[q][j] = (t < a.N && !a.cold) ? wrow[t] * (double)sigma : 0.0;
+        w[q][j] = 0.0;
       }
+    if (!a.cold) {                                // (wave-uniform: a scalar branch; the loads inside are branch-free)
+#pragma unroll
+      for (int q = 0; q < NBW; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int t = 32 * (QOFF + q) + tb + j;
+          if (QOFF + q == NBT - 1) {
+            const double wl = wrow[t < a.N ? t : a.N - 1] * (double)sigma;
+            w[q][j] = (t < a.N) ? wl : 0.0;
+          } else {
+            w[q][j] = wrow[t] * (double)sigma;
+          }
+        }
+    }
   }
   const double th = lb * step * (double)sigma;
   const double nstep = -step * g_scale;
   float guard = 0.0f, wlast = 0.0f;
+  // cost trace: 0.5 ||r''||^2 / (2^a sigma)^2 + lbda ||w'||_1 / sigma
+  const float jq = 0.5f * (inv_sigma / y_scale) * (inv_sigma / y_scale), jl = (float)lb * inv_sigma;
+  float jsq = 0.0f, jl1 = 0.0f;
+  // CERT: lane group g tracks sample 3 of block CQ[g] of this wave's half
+  constexpr int CQ0 = NBW / 8, CQ1 = (3 * NBW) / 8, CQ2 = (5 * NBW) / 8, CQ3 = (7 * NBW) / 8;
+  const int cq_mine = g == 0 ? CQ0 : (g == 1 ? CQ1 : (g == 2 ? CQ2 : CQ3));
+  double cu = 0.0, cw = 0.0;
+  float jw2 = 0.0f, cvsq = 0.0f;
+  bool cflag = false;
+  int cert_it = -1;
+  constexpr float CP1 = 0.3133f, CP2 = 0.6467f, CP3 = 0.04f;
+  const float cert_t2 = ((float)a.tol * 1.001f) * ((float)a.tol * 1.001f);
+  const float cert_c0 = (float)th * (4.0f * 1.0001f) * __builtin_sqrtf(32.0f * NBT) + 3.1e-10f * sigma;
+  const float cert_lim = cert_t2 * cert_c0 * cert_c0 * (1.0001f / CP3);
 
 #pragma unroll
   for (int r = 0; r < 2; ++r)
@@ -207,11 +258,15 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
     f4 acc[NBW + 1][2];
     unsigned ph[NBW + 1][4], pl[NBW + 1][4];
     unsigned rh[NBW][4], rl[NBW][4];
+    if constexpr (WITH_J) { jsq = 0.0f; jl1 = 0.0f; }
+    if constexpr (CERT) jw2 = 0.0f;
     auto prep_pair = [&](auto qc, auto pc) {
       constexpr int q = decltype(qc)::value, pp = decltype(pc)::value;
       float x0, x1;
       asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(x0) : "v"(w[q][2 * pp]));
       asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(x1) : "v"(w[q][2 * pp + 1]));
+      if constexpr (WITH_J) jl1 += fabsf(x0) + fabsf(x1);
+      if constexpr (CERT) jw2 = fmaf(x1, x1, fmaf(x0, x0, jw2));
       split_pair(x0, x1, ph[q][pp], pl[q][pp]);
       if constexpr (pp == 3) {
         wf[q].hi = __builtin_bit_cast(h8, u4{ph[q][0], ph[q][1], ph[q][2], ph[q][3]});
@@ -231,6 +286,7 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
         x1 = (32 * (QOFF + q) + tb + 2 * pp + 1 < a.N) ? x1 : 0.0f;
       }
       if constexpr (ROLE == 1 && q >= 1) rs2 += f2v{x0, x1};
+      if constexpr (WITH_J) jsq = fmaf(x1, x1, fmaf(x0, x0, jsq));
       split_pair(x0, x1, rh[q][pp], rl[q][pp]);
       if constexpr (pp == 3) {
         lrf[(2 * q) * 64] = u4{rh[q][0], rh[q][1], rh[q][2], rh[q][3]};
@@ -256,7 +312,8 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
           else if constexpr (ROLE == 1) acc[q][r] = mfma_part(An[r][o], wfX, acc[q][r], k - 3 * o);
         }
         if constexpr (sl < 4) {
-          if constexpr (ROLE == 0 && q + 1 == NBW - 1) {     // the left wave's last block: split when it was updated (xw)
+          if constexpr (ROLE == 0 && q + 1 == NBW - 1 && !WITH_J) {   // the left wave's last block: split when it was updated (xw)
+            // (with the cost trace its samples are converted again: ||w||_1 needs them)
             if constexpr (sl == 0) {
               wf[q + 1].hi = __builtin_bit_cast(h8, xw[0]);
               wf[q + 1].lo = __builtin_bit_cast(h8, xw[64]);
@@ -307,6 +364,10 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
       if constexpr (ROLE == 0 && q <= NBW - 2) {
         if constexpr ((j & 1) == 0) sum0 += w[q][j]; else sum1 += w[q][j];
       }
+      if constexpr (CERT && j == 3 && (q == CQ0 || q == CQ1 || q == CQ2 || q == CQ3)) {
+        cu = (cq_mine == q) ? u : cu;
+        cw = (cq_mine == q) ? w[q][j] : cw;
+      }
     };
     fetch(std::integral_constant<int, NBW - 1>{});
     static_for<0, NBW>([&](auto qq) {
@@ -335,6 +396,20 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
     });
     static_for<0, 8>([&](auto jc) { update(std::integral_constant<int, 0>{}, jc); });
     if constexpr (ROLE == 0) publish_far_field(sum0 + sum1);
+    if constexpr (CERT) {                          // the window combination on this lane's tracked sample (fista_mfma.h)
+      const float d1 = lt[((cert_it + 3) & 3) * 128], d2 = lt[((cert_it + 2) & 3) * 128], d3 = lt[((cert_it + 1) & 3) * 128];
+      const unsigned ulo = __builtin_bit_cast(unsigned, lt[4 * 128]), uhi = __builtin_bit_cast(unsigned, lt[5 * 128]);
+      const double up = __builtin_bit_cast(double, ((unsigned long long)uhi << 32) | ulo);
+      const float dk = (float)(cu - up), e = (float)(cw - cu);
+      const float v = fmaf(2.0f, d2, fmaf(3.0f, d1, fmaf(2.0f, dk, e))) + d3;
+      const float m = fmaf(2.0f, fabsf(d2), fmaf(3.0f, fabsf(d1), fmaf(2.0f, fabsf(dk), fabsf(e)))) + fabsf(d3);
+      const float vs = fmaxf(fmaf(-0x1p-21f, m, fabsf(v)), 0.0f);
+      cvsq = vs * vs;
+      lt[(cert_it & 3) * 128] = dk;
+      const unsigned long long ub = __builtin_bit_cast(unsigned long long, cu);
+      lt[4 * 128] = __builtin_bit_cast(float, (unsigned)ub);
+      lt[5 * 128] = __builtin_bit_cast(float, (unsigned)(ub >> 32));
+    }
   };
   auto range_check = [&]() {
     unsigned mb = 0;
@@ -368,13 +443,52 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
     publish_far_field(s);
   }
   wg_sync();
-  for (int it = 0; it < a.n_iter; ++it) {
-    const double beta = a.betas[it];
+  if constexpr (!WITH_J) {
+    for (int it = 0; it < a.n_iter; ++it) {
+      const double beta = a.betas[it];
+      forward();
+      wg_sync();                                   // residual fragments and their far field are out
+      backward(beta);
+      if (PB_MFMA_CHECKS && (((it & 7) == 7) || (it == a.n_iter - 1) || (it == 0 && !a.cold))) range_check();
+      wg_sync();                                   // the updated iterate's fragment and far field are out
+    }
+  } else {
+    // rotated: the cost of iterate k+1 comes from the residual of the NEXT forward pass (one pass in front)
     forward();
-    wg_sync();                                     // residual fragments and their far field are out
-    backward(beta);
-    if (PB_MFMA_CHECKS && (((it & 7) == 7) || (it == a.n_iter - 1) || (it == 0 && !a.cold))) range_check();
-    wg_sync();                                     // the updated iterate's fragment and far field are out
+    if constexpr (CERT) lt[6 * 128] = jw2;         // this lane's part of ||w_0||^2
+    wg_sync();
+    for (int it = 0; it < a.n_iter; ++it) {
+      const double beta = a.betas[it];
+      cert_it = it;
+      backward(beta);
+      wg_sync();
+      forward();
+      float sq = jsq, l1 = jl1;                     // this lane's samples -> this wave's half of the problem
+      sq += __shfl_xor(sq, 16, 64);
+      l1 += __shfl_xor(l1, 16, 64);
+      sq += __shfl_xor(sq, 32, 64);
+      l1 += __shfl_xor(l1, 32, 64);
+      float t = 0.0f;
+      if constexpr (CERT) {
+        // this half's part of  sum v^2 - tol^2 (||w_k||^2 / p1 + 4 ||w_{k+1}||^2 / p2)
+        t = cvsq - cert_t2 * ((1.0001f / CP1) * lt[6 * 128] + (4.0001f / CP2) * jw2);
+        t += __shfl_xor(t, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        lt[6 * 128] = jw2;
+      }
+      xj[(ROLE * 3 + 0) * 64 + lane] = sq;
+      xj[(ROLE * 3 + 1) * 64 + lane] = l1;
+      if constexpr (CERT) xj[(ROLE * 3 + 2) * 64 + lane] = t;
+      wg_sync();                                   // (the barrier of the forward pass: the halves of the cost meet here)
+      sq += xj[((1 - ROLE) * 3 + 0) * 64 + lane];
+      l1 += xj[((1 - ROLE) * 3 + 1) * 64 + lane];
+      if (ROLE == 0 && live && g == 0 && (!CERT || (a.J != nullptr && !cflag))) a.J[(int64_t)p * a.ldj + it] = fmaf(jq, sq, jl * l1);
+      if constexpr (CERT) {
+        t += xj[((1 - ROLE) * 3 + 2) * 64 + lane];
+        cflag = cflag | ((it >= 7) & !(t >= cert_lim));      // NaN-safe; the same verdict in both waves
+      }
+      if (PB_MFMA_CHECKS && (((it & 7) == 7) || (it == a.n_iter - 1) || (it == 0 && !a.cold))) range_check();
+    }
   }
 
   // ---- guards over the whole series, store ---------------------------------------------------------------------
@@ -390,7 +504,7 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
     guard = (guard < 60000.0f && go < 60000.0f) ? fmaxf(guard, go) : 65504.0f;      // NaN on either side: out of range
     wlast = fmaxf(wlast, wo);
   }
-  const bool bad = !(guard < 60000.0f) || (a.rho_guard && wlast > 0.0f && (float)th > MFMA_RHO_MAX * wlast);
+  const bool bad = !(guard < 60000.0f) || (a.rho_guard && wlast > 0.0f && (float)th > MFMA_RHO_MAX * wlast) || (CERT && cflag);
   if (live && !bad) {
     double* wrow = a.w + (int64_t)p * a.ldw;
 #pragma unroll
@@ -405,19 +519,22 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
 }
 
 // one workgroup = two waves = 16 problems; the wave index picks the half (a scalar branch: each wave runs one role)
-template <int NBA, int NBB, bool TAPS_DEV = false>
+template <int NBA, int NBB, bool TAPS_DEV = false, bool WITH_J = false, bool CERT = false>
 __global__ __launch_bounds__(128) void fista_mfma2_kernel(FistaArgs a, MfmaTaps tp) {
   extern __shared__ __attribute__((aligned(16))) char mf2_smem[];
-  if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) mfma2_role<NBA, NBB, TAPS_DEV, 0>(a, tp, mf2_smem);
-  else mfma2_role<NBA, NBB, TAPS_DEV, 1>(a, tp, mf2_smem);
+  if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) mfma2_role<NBA, NBB, TAPS_DEV, 0, WITH_J, CERT>(a, tp, mf2_smem);
+  else mfma2_role<NBA, NBB, TAPS_DEV, 1, WITH_J, CERT>(a, tp, mf2_smem);
 }
 
-// Plain solves (no stop rule, no cost trace), HRFs of up to 33 taps, 32 (NBA+NBB-1) < N <= 32 (NBA+NBB).
+// Plain solves, with or without the cost trace, and the window rule (wind = 6) as a no-fire certificate; HRFs of up to
+// 33 taps, 32 (NBA+NBB-1) < N <= 32 (NBA+NBB).  The shared-HRF z-step (taps in device memory): plain only.
 template <int NBA, int NBB>
-int launch_mfma2(const FistaArgs& a, const double* taps, int K, hipStream_t st) {
+int launch_mfma2(const FistaArgs& a, const double* taps, int K, bool with_j, hipStream_t st) {
   constexpr int NB = NBA + NBB;
   if (a.N > 32 * NB || a.N <= 32 * (NB - 1) || K < 1 || K > 33) return 1;
-  if (a.stop_mode != PB_STOP_NONE || a.J || !a.n_done) return 1;
+  const bool cert = a.stop_mode == PB_STOP_WINDOW;
+  if ((a.stop_mode != PB_STOP_NONE && !cert) || !a.n_done) return 1;
+  if ((with_j || cert) && a.taps_pp) return 1;
   const int64_t groups = ((int64_t)(a.P - a.p0) + 15) / 16;
   const dim3 grid((unsigned)groups), block(128);
   const size_t lds = mfma2_lds_bytes(NBB);
@@ -427,7 +544,9 @@ int launch_mfma2(const FistaArgs& a, const double* taps, int K, hipStream_t st) 
     return 0;
   }
   const MfmaTaps tp = make_mfma_taps(taps, K);
-  hipLaunchKernelGGL((fista_mfma2_kernel<NBA, NBB, false>), grid, block, lds, st, a, tp);
+  if (cert) hipLaunchKernelGGL((fista_mfma2_kernel<NBA, NBB, false, true, true>), grid, block, lds, st, a, tp);
+  else if (with_j) hipLaunchKernelGGL((fista_mfma2_kernel<NBA, NBB, false, true, false>), grid, block, lds, st, a, tp);
+  else hipLaunchKernelGGL((fista_mfma2_kernel<NBA, NBB, false>), grid, block, lds, st, a, tp);
   return 0;
 }
 

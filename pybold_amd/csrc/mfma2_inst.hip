@@ -5,5 +5,5 @@
 #error "compile with -DPB_NBA=<blocks of the left wave> -DPB_NBB=<blocks of the right wave>"
 #endif
 namespace pb {
-template int launch_mfma2<PB_NBA, PB_NBB>(const FistaArgs&, const double*, int, hipStream_t);
+template int launch_mfma2<PB_NBA, PB_NBB>(const FistaArgs&, const double*, int, bool, hipStream_t);
 }

@@ -38,6 +38,8 @@ _FORCE = {None: 0, "generic": PB_FLAG_FORCE_GENERIC, "fast": PB_FLAG_FORCE_FAST,
           # pb_fista_solve_path, measurement aids: only the dense list's launch / only the sparse list's
           "path_dense": _lib.PB_FLAG_FORCE_MFMA, "path_sparse": PB_FLAG_FORCE_PAIR,
           "mfma2": _lib.PB_FLAG_FORCE_MFMA2, "mfma2only": _lib.PB_FLAG_FORCE_MFMA2 | _lib.PB_FLAG_CERT_NO_RESOLVE,
+          "mfma2cert": _lib.PB_FLAG_FORCE_MFMA2 | PB_FLAG_FORCE_CERT,
+          "mfma2certonly": _lib.PB_FLAG_FORCE_MFMA2 | PB_FLAG_FORCE_CERT | _lib.PB_FLAG_CERT_NO_RESOLVE,
           # intermediate solve of an outer loop: the matrix-pipe form keeps sparse iterates (no accuracy guard)
           "intermediate": _lib.PB_FLAG_NO_RHO_GUARD,
           "intermediate_noresolve": _lib.PB_FLAG_NO_RHO_GUARD | _lib.PB_FLAG_CERT_NO_RESOLVE,   # measurement aid

@@ -67,23 +67,25 @@ def test_version_and_dispatch_table(lib):
     assert lib.pb_fista_which_kernel(300, 30, 100000, 0, 2, 5) == 0      # other windows: LDS kernel (the Python layer warns)
     assert lib.pb_fista_which_kernel(300, 30, 1, 0, 0, 6) == 3           # a few short series: one per wave
     assert lib.pb_fista_which_kernel(300, 30, 10000, 0, 0, 6) == 5       # config 2: half a round on the split matrix-pipe form (round 4) + left-overs
-    assert lib.pb_fista_which_kernel(300, 30, 10000, 1, 0, 6) == 4       # ... with the cost trace: one (partial) round of one-wave matrix-pipe waves
+    assert lib.pb_fista_which_kernel(300, 30, 10000, 1, 0, 6) == 5       # ... with the cost trace too
     assert lib.pb_fista_which_kernel(300, 30, 4096, 0, 0, 6) == 1        # single-row kernel
     assert lib.pb_fista_which_kernel(300, 30, 12500, 0, 0, 6) == 4       # config 3's shard on 8 GPUs
     assert lib.pb_fista_which_kernel(300, 30, 8000, 0, 0, 6) == 5        # under half a round: one pass of the split matrix-pipe form
-    assert lib.pb_fista_which_kernel(300, 30, 8000, 1, 0, 6) == 2        # ... with the cost trace: the vector forms
+    assert lib.pb_fista_which_kernel(300, 30, 8000, 1, 0, 6) == 5        # ... with the cost trace too
     assert lib.pb_fista_which_kernel(240, 27, 50000, 0, 0, 6) == 4       # 129..320 scans, up to 33 taps
     assert lib.pb_fista_which_kernel(128, 16, 50000, 0, 0, 6) == 2       # shorter series: pair form
-    assert lib.pb_fista_which_kernel(300, 30, 8192, 1, 2, 6) == 2        # the deconv default call, half a round: pair form
+    assert lib.pb_fista_which_kernel(300, 30, 8192, 1, 2, 6) == 5        # the deconv default call, half a round: one pass of the split form (certificate)
     assert lib.pb_fista_which_kernel(300, 30, 50000, 1, 2, 6) == 4       # ... whole rounds: matrix-pipe form
     assert lib.pb_fista_which_kernel(300, 30, 8192, 1, 1, 6) == 1        # _loops_deconv rule: single-row kernel
     assert lib.pb_fista_which_kernel(300, 30, 3, 1, 2, 6) == 3           # ... or one problem per wave
     assert lib.pb_fista_which_kernel(600, 30, 100000, 0, 0, 6) == 5      # 600 scans: the matrix pipe, every series split over two waves (round 4)
-    assert lib.pb_fista_which_kernel(600, 30, 100000, 1, 0, 6) == 2      # ... with the cost trace: the halves of a series in the two slots of a row
-    assert lib.pb_fista_which_kernel(600, 30, 100000, 1, 2, 6) == 2      # ... with the window rule as a certificate
+    assert lib.pb_fista_which_kernel(600, 30, 100000, 1, 0, 6) == 5      # ... with the cost trace
+    assert lib.pb_fista_which_kernel(600, 30, 100000, 1, 2, 6) == 5      # ... and with the window rule as a certificate (the reference-default call)
+    assert lib.pb_fista_which_kernel(600, 30, 100000, 1, 2, 4) in (1, 3) # other windows: the exact rule on a vector form
+    assert lib.pb_fista_which_kernel(600, 30, 100000, 1, 1, 6) in (1, 3) # the _loops_deconv rule on long series: vector forms
     assert lib.pb_fista_which_kernel(600, 30, 500, 0, 0, 6) in (1, 3)    # few long series: latency-bound forms
     assert lib.pb_fista_which_kernel(640, 30, 100000, 0, 0, 6) == 5      # up to 640 scans on the split matrix-pipe form
-    assert lib.pb_fista_which_kernel(640, 30, 100000, 1, 0, 6) == 3      # beyond 32 x 19 scans with the cost trace: one problem per wave
+    assert lib.pb_fista_which_kernel(640, 30, 100000, 1, 0, 6) == 5      # ... with the cost trace too
     assert lib.pb_fista_which_kernel(641, 30, 100000, 0, 0, 6) == 3
     assert lib.pb_fista_which_kernel(5000, 30, 10, 0, 0, 6) == 0
 

@@ -187,9 +187,7 @@ def test_split_pair_form_matches_oracle(solver, n, k):
     n_iter = 300
     Wr = orc.fista_batch(Y.astype(np.float32).astype(np.float64), hrf, 0.7, 1.0 / lip, n_iter)
     W, J, nd = solver.fista_solve(dev32(Y), hrf, 0.7, 1.0 / lip, n_iter, want_J=True, force="fast2")
-    if n > 320:       # with the cost trace the pair form over two slots; plain solves on the matrix pipe since round 4
-        assert "two problems per row" in solver.which_kernel(n, k, 5000, want_J=True)
-    assert "matrix pipe" in solver.which_kernel(n, k, 6000)
+    assert "matrix pipe" in solver.which_kernel(n, k, 6000)      # (the library's own choice since round 4; the pair form is forced here)
     assert rel_rows(W.cpu().numpy(), Wr) < EPS
     Xr, Zr = orc.fista_outputs(Wr, hrf)
     Jr = 0.5 * np.sum(np.square(Xr - Y.astype(np.float32)), axis=1) + 0.7 * np.abs(Wr).sum(axis=1)

@@ -348,3 +348,44 @@ def test_loops_rule_inside_the_matrix_pipe_kernel(solver, golden):
     _, ndo = orc.loops_batch(Yh, hrf, 2.0, 1.0 / lip1, 400, 2.7e-4)
     assert (ndl.cpu().numpy() == ndo[np.arange(16384 + 500) % 250]).all()      # (the remainder: single-row / one-per-wave forms)
     assert torch.equal(Wl[:250], Wl[250:500])
+
+
+@pytest.mark.parametrize("n,k", [(600, 30), (400, 27), (640, 33), (300, 30), (161, 16)])
+def test_split_form_cost_trace_and_window_rule(solver, n, k):
+    """`fista_mfma2_kernel<..., WITH_J, CERT>`: the cost trace (each wave adds up its half of ||r||^2 and ||w||_1, the
+    halves meet at the barrier of the forward pass) against the float64 oracle's; the window rule (wind = 6) as a
+    no-fire certificate with eight tracked samples per problem -- stop iterations and iterates of the exact rule, about
+    half of the series firing before n_iter (the uncleared ones are re-solved exactly by the library); at the default
+    tolerance nothing fires and the result is the plain + cost-trace solve, bit for bit."""
+    from oracle import c_oracle
+    rng = np.random.RandomState(n * 7 + k)
+    hrf = orc.spm_hrf(1.0, 1.0, float(k), False)[0][:k] if k >= 20 else np.hanning(k + 2)[1:-1] * 0.3
+    lip = orc.gram_lipschitz(hrf, n)
+    Yv = rng.randn(24, n)
+    Y32 = Yv.astype(np.float32).astype(np.float64)
+    Yd = torch.from_numpy(Yv.astype(np.float32)).cuda()
+    Wo, Jo, _ = c_oracle.fista_batch(Y32, hrf, 0.7, 1.0 / lip, 200, want_J=True, threads=4)
+    W, J, nd = solver.fista_solve(Yd, hrf, 0.7, 1.0 / lip, 200, want_J=True, force="mfma2only")
+    assert int(nd.min()) == 200 and rel_rows(W.cpu().numpy(), Wo).max() < 3e-6
+    np.testing.assert_allclose(J.cpu().numpy(), Jo, rtol=3e-5)
+    # the window rule: oracle stop iterations for a tolerance at which some series fire
+    tol = 0.01
+    n_fire = np.array([orc.deconv_fixed_lbda(Y32[v], hrf, 0.7, nb_iter=400, tol=tol, lipschitz=lip, dense=False)[4] for v in range(24)])
+    n_iter = int(np.median(n_fire))
+    out = [orc.deconv_fixed_lbda(Y32[v], hrf, 0.7, nb_iter=n_iter, tol=tol, lipschitz=lip, dense=False) for v in range(24)]
+    Wr, nr = np.stack([o[2] for o in out]), np.array([o[4] for o in out])
+    Ww, Jw, ndw = solver.fista_solve(Yd, hrf, 0.7, 1.0 / lip, n_iter, want_J=True, stop="window", tol=tol, wind=6, force="mfma2cert")
+    assert (ndw.cpu().numpy() == nr).all(), (ndw.cpu().numpy(), nr)
+    assert rel_rows(Ww.cpu().numpy(), Wr).max() < 1e-5
+    # what the certificate alone clears: every series that does not fire must not be flagged wrongly as "fired"
+    _, _, ndc = solver.fista_solve(Yd, hrf, 0.7, 1.0 / lip, n_iter, want_J=True, stop="window", tol=tol, wind=6, force="mfma2certonly")
+    ndc = ndc.cpu().numpy()
+    assert ((ndc == -1) | (ndc == n_iter)).all() and (ndc[nr < n_iter] == -1).all()
+    # the default tolerance: nothing fires, nothing is handed back, the plain + J result bit for bit
+    Wd, Jd, ndd = solver.fista_solve(Yd, hrf, 0.7, 1.0 / lip, 200, want_J=True, stop="window", tol=1e-6, wind=6, force="mfma2certonly")
+    assert int(ndd.min()) == 200 and torch.equal(Wd, W) and torch.equal(Jd, J)
+    if n > 320:                                     # the library's own dispatch for the reference-default call on long series
+        assert "split over two" in solver.which_kernel(n, k, 6000, want_J=True, stop="window")
+        Yb = torch.from_numpy(np.tile(Yv, (250, 1)).astype(np.float32)).cuda()
+        Wl, Jl, ndl = solver.fista_solve(Yb, hrf, 0.7, 1.0 / lip, 200, want_J=True, stop="window", tol=1e-6, wind=6)
+        assert int(ndl.min()) == 200 and torch.equal(Wl[:24], W) and torch.equal(Wl[-24:], W)

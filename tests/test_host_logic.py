@@ -173,8 +173,8 @@ def test_launch_plan_of_a_plain_solve():
               100000: (98304, mm, wave)}
     for P, want in expect.items():
         assert solver.launch_plan(300, 30, P) == want, P
-    # the cost trace and the window rule do not ride the split form: the round-3 plan
-    assert solver.launch_plan(300, 30, 10000, stop="window") == (0, None, mm)
+    # the window rule (as a certificate) rides the split form too
+    assert solver.launch_plan(300, 30, 10000, stop="window") == (8192, m2, wave)
     # series of 321..640 scans: the split form from 5 120 problems on (whole passes of 8 192, remainders above 2 560)
     assert solver.launch_plan(600, 30, 50000) == (49152, m2, wave) and solver.launch_plan(600, 30, 8192) == (0, None, m2)
     assert solver.launch_plan(600, 30, 4096)[2] == pair and solver.launch_plan(600, 30, 11000) == (0, None, m2)
