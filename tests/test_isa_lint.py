@@ -1,0 +1,31 @@
+"""CPU-only (hipcc cross-compiles): the ISA listings of the matrix-pipe kernels carry no register spill inside an
+exec-masked region -- the code-generation hazard that broke the certificate variant of the split form in round 4
+(a VGPR -> AGPR spill executed under an EMPTY exec mask on a cold start: its reload, an LDS address, was garbage;
+DESIGN 5.0b) -- and no scratch.  tools/isa_spill_lint.py is the check; `make -C pybold_amd/csrc build/mfma2_8_9.s`
+etc. produce the listings."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "pybold_amd", "csrc")
+
+
+@pytest.mark.parametrize("target", ["mfma2_8_9", "mfma_10"])
+def test_no_spill_under_a_partial_exec_mask(target):
+    if subprocess.call(["which", "hipcc"], stdout=subprocess.DEVNULL) != 0 and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    subprocess.check_call(["make", "-s", "-C", CSRC, "build/%s.s" % target])
+    lst = os.path.join(CSRC, "build", target + ".s")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_spill_lint.py"), lst], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    # the variants that matter run without scratch (the plain ones of both kernels, the split form's cost-trace / certificate ones)
+    res = open(os.path.join(CSRC, "build", target + ".res")).read()
+    names = re.findall(r"Function Name: (\S+)", res)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", res)]
+    assert len(names) == len(scratch) and len(names) >= 4
+    plain = [s for n, s in zip(names, scratch) if n.endswith("ILi10ELb0ELb0ELb0ELi2ELb0EEEvNS_9FistaArgsENS_8MfmaTapsE") or "mfma2_kernel" in n]
+    assert plain and max(plain) == 0, list(zip(names, scratch))
