@@ -104,14 +104,15 @@ mfma2_launch_fn pick_mfma2(int N, int K) {
   return tab[nb - 5];
 }
 typedef int (*mfma_launch_fn)(const pb::FistaArgs&, const double*, int, bool, hipStream_t);
-// the matrix-pipe form (fista_mfma.h): NB = ceil(N / 32) blocks of 32 samples, 129 <= N <= 320; K <= 33
-// with two near tiles (every variant), 34 <= K <= 65 with three (`extras` = window-rule certificate:
+// the matrix-pipe form (fista_mfma.h): NB = ceil(N / 31) blocks of 31 samples + one sum slot, 125 <= N <= 310; K <= 33
+// with two near tiles (every variant), 34 <= K <= 64 with three (`extras` = window-rule certificate:
 // not built for those)
-constexpr int MFMA_K2 = 33, MFMA_K3 = 65;
+constexpr int MFMA_K2 = 33, MFMA_K3 = 64;
+constexpr int MFMA1_NMAX = 10 * pb::MFMA_SPAN;   // longer series (up to 640 scans) run on the split form (fista_mfma2.h)
 mfma_launch_fn pick_mfma(int N, int K, bool extras = false) {
   static const mfma_launch_fn tab[] = {&pb::launch_mfma<5>, &pb::launch_mfma<6>, &pb::launch_mfma<7>,
                                        &pb::launch_mfma<8>, &pb::launch_mfma<9>, &pb::launch_mfma<10>};
-  const int nb = (N + 31) / 32;
+  const int nb = (N + pb::MFMA_SPAN - 1) / pb::MFMA_SPAN;
   if (K < 1 || K > MFMA_K3 || (K > MFMA_K2 && extras) || nb < 5 || nb > 10) return nullptr;
   return tab[nb - 5];
 }
@@ -463,7 +464,7 @@ constexpr int MFMA2_BESIDE_CHUNKS = 2;         // chunks of one one-problem wave
 // 1.58 ms against 1.93, 8 192 2.87 against 1.97 -- profiles/r4_split_form_passes.txt); whole passes of 8 192
 // problems, a remainder above 5/16 of a pass too, a smaller one on the one-problem-per-wave form.
 constexpr int MFMA2_LONG_MIN_P = 5120;
-bool mfma2_serves_long(int N, int K) { return N > 320 && pick_mfma2(N, K) != nullptr && pick_wide(N, K) != nullptr; }
+bool mfma2_serves_long(int N, int K) { return N > MFMA1_NMAX && pick_mfma2(N, K) != nullptr && pick_wide(N, K) != nullptr; }
 int mfma2_long_base(int P, bool one_launch) {
   const int pass = (int)wave_slots() * 4;            // 16 problems x (slots / 2 SIMDs / 2 waves)
   const int base = (P / pass) * pass;

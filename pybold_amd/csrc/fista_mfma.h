@@ -13,11 +13,22 @@
 // and is WORSE here: the 22-bit rounding of x then enters at the scale of y instead of the scale of
 // the residual -- 3e-6 instead of 2.5e-7 on diff_z, tools/r3_mfma_precision.py.)
 //
-// T_c is lower triangular Toeplitz with a CONSTANT far field, so per block of 32 samples
+// T_c is lower triangular Toeplitz with a CONSTANT far field, so per block of samples
 //   x_q = C0 w_q + C1 w_{q-1} + S 1 1^T (w_0 + ... + w_{q-2})
-// two near tiles (three for 34..65 taps) and a running "carry" accumulated by one more tile product
-// per block; the adjoint mirrors it.  No cross-lane instruction is left in the loop: the cumulative sums ride in
-// the matrix accumulators.
+// two near tiles (three for 34..64 taps) and the far field.  Round 3 carried the far field as a running "carry"
+// accumulated by one more tile product per block (3 of the 15 matrix instructions of a block and pass) and added to
+// the accumulators' start values on the vector pipe.  Round 4 (this file) lets it ride INSIDE the near products: a
+// block is 31 samples + one SUM SLOT (slot 31: lane group 3, j = 7).  As an OUTPUT row of tile 0 the slot adds up the
+// block (entries 2^-9, and 1 at [31][31]): D_{q+1} = 2^-9 sum(w_q) + D_q, the running prefix sum, which lands in the
+// very lane and register that hold the slot -- as an INPUT column of the last near tile (entries S 2^9) it feeds
+// S sum_{b <= q-NT} w_b to the 31 real rows of block q.  So a block costs 12 matrix instructions per pass instead of 15
+// (228 per iteration at 300 scans instead of 276), the accumulators start from -y itself (no carry to add), and the
+// price is one select + one addition + one more v_fma_mix per block and pass (the slot's value enters the float16
+// split together with the samples; what the 22-bit split drops of it is carried along and added back: the prefix sums
+// keep float32 precision, as the round-3 carry did).  The adjoint mirrors it (suffix sums of the residual; the slot of
+// the fetched fragment is patched with two v_perm_b32).  No cross-lane instruction is left in the loop: the cumulative
+// sums ride in the matrix accumulators.  The products of a block run OLDEST tile first, so that the fragment of the
+// block itself -- whose sum slot needs the finished accumulators of the block before -- is needed last.
 //
 // Precision: operands are split in two float16 parts (x = hi + lo, 22 bits; three products
 // hi.hi + hi.lo + lo.hi, float32 accumulation in the matrix unit), the iterate and its update
@@ -26,10 +37,10 @@
 // float16 range: every voxel is scaled by a power of two so that max|y| lies in [2^13, 2^14) (the
 // problem is scale-covariant, threshold included: exact), taps by a power of two given by the host.
 //
-// Mapping: one wave = 16 problems; lane (v = lane & 15, g = lane >> 4) owns samples
-// t = 32 q + 8 g + j (q < NB, j < 8) of problem v -- exactly the B-operand layout of the 16x16x32
-// instruction (k = 8 g + j), and, with the tile ROWS permuted (row 4 g + i of row-half r <-> time
-// 32 q + 8 g + 4 r + i: the tile is data, any row order is free), exactly its D layout too:
+// Mapping: one wave = 16 problems; lane (v = lane & 15, g = lane >> 4) owns slots k = 8 g + j (j < 8) of every
+// block q < NB of problem v, slot k < 31 holding sample t = 31 q + k -- exactly the B-operand layout of the 16x16x32
+// instruction (k = 8 g + j), and, with the tile ROWS permuted (row 4 g + i of row-half r <-> slot
+// 8 g + 4 r + i: the tile is data, any row order is free), exactly its D layout too:
 // operands and results never change lanes.  One wave per SIMD (the iterate alone is 160 VGPRs):
 // the matrix pipe and the vector pipe of the SAME wave overlap.
 //
@@ -48,16 +59,8 @@
 #ifndef PB_MFMA_SBK
 #define PB_MFMA_SBK 15
 #endif
-// PB_MFMA_YMAT (off): -y enters the residual through the matrix pipe (identity tile x float16 hi/lo
-// fragments of -2^a sigma y, kept in the accumulator file and read by the matrix instructions directly)
-// instead of 80 accumulator-file reads + 80 additions per iteration on the vector pipe, and the carry
-// becomes the C operand of the first product of a block: 4 more matrix instructions per block for 145
-// fewer vector instructions per iteration (no scratch, parity tests green, y held to 22 bits).
-// Measured 2.5 % SLOWER (profiles/r3_mfma_y_through_matrix_pipe_ab.txt): one more matrix instruction
-// costs this kernel ~23 cycles, one vector instruction less saves ~5.
-#ifndef PB_MFMA_YMAT
-#define PB_MFMA_YMAT 0
-#endif
+// (Round 3's PB_MFMA_YMAT experiment -- -y through the matrix pipe with an identity tile: 145 vector instructions fewer,
+// 40 matrix instructions more, 2.5 % slower, profiles/r3_mfma_y_through_matrix_pipe_ab.txt -- left with the carry tile.)
 #ifndef PB_MFMA_SB
 #define PB_MFMA_SB
 #endif
@@ -70,8 +73,11 @@ namespace pb {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
+typedef unsigned u3 __attribute__((ext_vector_type(3)));
 
 constexpr float MFMA_RHO_MAX = 0.02f;
+constexpr int MFMA_SPAN = 31;       // samples per block of 32 slots; slot 31 (lane group 3, j = 7) is the block's sum slot
+constexpr int MFMA_SSHIFT = 9;      // the sums ride scaled by 2^-9: below the largest sample for up to 512 of them
 
 struct MfmaTaps {
   float c[96];      // 2^a * cumsum(h)[m], m < 96 (constant from m = K-1 on; K <= 33 uses 64 of them)
@@ -182,7 +188,8 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
   if (__builtin_amdgcn_readfirstlane(wave) * 16 + a.p0 >= n_list) return;
   bool live;
   const int p = slot_to_problem(a, wave * 16 + v + a.p0, n_list, live);
-  const int tb = 8 * g;                          // this lane's offset inside a block of 32
+  const int tb = 8 * g;                          // this lane's first slot inside a block of 32 slots
+  const bool g3 = g == 3;                        // lane group 3 holds the sum slot (slot 31 = its j = 7)
 
   extern __shared__ __attribute__((aligned(16))) char mf_smem[];
   u4* lrf = reinterpret_cast<u4*>(mf_smem) + ((threadIdx.x >> 6) * NB * 2 * 64 + lane);
@@ -229,11 +236,14 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
   wave_sync();
 
   // ---- operator tiles (A operands): lane holds row rho = lane & 15, k = 8 (lane >> 4) + j ----
-  Frag An[2][NT], Bn[2][NT], Ff;                 // forward near [r][o], adjoint near [r][o], far field
-  h8 Eh[2];                                      // PB_MFMA_YMAT: identity tile of row half r
+  // Output slot ko = 8 gp + 4 r + i of the block, input slot ki = 8 kg + j of the block o blocks away.  Slot 31 is the
+  // sum slot: as an output row (tile 0 only) it adds up the block's samples, scaled by 2^-9, plus what the slot held
+  // ([31][31] = 1); as an input column (last tile only) it carries 2^9 S to the 31 real rows.
+  Frag An[2][NT], Bn[2][NT];                     // forward near [r][o], adjoint near [r][o]
   {
     const int rho = lane & 15, kg = lane >> 4, gp = rho >> 2, i = rho & 3;
     auto cval = [&](int lag) -> float { return lag < 0 ? 0.0f : lc[lag > LCW - 1 ? LCW - 1 : lag]; };
+    const float sfar = lc[LCW - 1] * (float)(1 << MFMA_SSHIFT), eps = 1.0f / (float)(1 << MFMA_SSHIFT);
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -241,25 +251,15 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
         float fa[8], fb[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          fa[j] = cval(32 * o + 8 * (gp - kg) + 4 * r + i - j);
-          fb[j] = cval(32 * o + 8 * (kg - gp) + j - 4 * r - i);
+          const int ko = 8 * gp + 4 * r + i, ki = 8 * kg + j;
+          const float vs = ko == 31 ? (o == 0 ? (ki == 31 ? 1.0f : eps) : 0.0f) : (o == NT - 1 ? sfar : 0.0f);
+          const bool special = ko == 31 || ki == 31;
+          fa[j] = special ? vs : cval(MFMA_SPAN * o + ko - ki);
+          fb[j] = special ? vs : cval(MFMA_SPAN * o + ki - ko);
         }
         An[r][o] = split8(fa);
         Bn[r][o] = split8(fb);
       }
-    float ff[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ff[j] = lc[LCW - 1];
-    Ff = split8(ff);
-#if PB_MFMA_YMAT
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {                  // identity (in the permuted row order): lag 0 only
-      float fe[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) fe[j] = (8 * (gp - kg) + 4 * r + i - j == 0) ? 1.0f : 0.0f;
-      Eh[r] = split8(fe).hi;
-    }
-#endif
   }
 
   // ---- load the problem, scale it into the float16 range ---------------------------------
@@ -267,6 +267,7 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
   float ysn[NB][8];                              // -2^a sigma y
   double w[NB][8];                               // sigma w
   float sigma = 1.0f, inv_sigma = 1.0f;
+  bool degenerate = false;                       // an all-zero (or non-finite) series with a warm start: no scale to work at
   {
     const float* yrow = a.y + (int64_t)(p / a.y_rep) * a.ldy;
     float m = 0.0f;
@@ -274,16 +275,21 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
     for (int q = 0; q < NB; ++q)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        // Only the LAST block can hold padding (32 (NB-1) < N): every other load is unconditional, the last block's
-        // are branch-free (clamped address + select).  A per-lane `if` around each load put 80 exec-masked regions
+        // Only the LAST block can hold padding (31 (NB-1) < N): every other load is unconditional, the last block's
+        // are branch-free (clamped address + select), and so is the sum slot (j = 7 of lane group 3: no sample).
+        // A per-lane `if` around each load put 80 exec-masked regions
         // into this prologue, and the compiler was seen to place a VGPR -> AGPR spill INSIDE such a region
         // (fista_mfma2.h, round 4: with the mask empty -- a cold start -- the spill never happened and its reload,
         // an LDS address, was garbage); tools/isa_spill_lint.py looks for that pattern in the listings.
-        const int t = 32 * q + tb + j;
+        const int t = MFMA_SPAN * q + tb + j;
         float yv;
         if (q == NB - 1) {
+          const bool ok = t < a.N && !(j == 7 && g3);
           const float yl = yrow[t < a.N ? t : a.N - 1];
-          yv = (t < a.N) ? yl : 0.0f;
+          yv = ok ? yl : 0.0f;
+        } else if (j == 7) {
+          const float yl = yrow[t];              // (lane group 3: the first sample of block q+1, a valid address)
+          yv = g3 ? 0.0f : yl;
         } else {
           yv = yrow[t];
         }
@@ -301,6 +307,10 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
       const float sg = ldexpf(1.0f, a.ybits - e) / y_scale, isg = ldexpf(1.0f, e - a.ybits) * y_scale;
       sigma = okm ? sg : 1.0f;
       inv_sigma = okm ? isg : 1.0f;
+      // y = 0 gives no scale: a warm start is then iterated as it comes, and a small one falls into the float16
+      // subnormals (its prefix sums first: they ride scaled by 2^-9).  Such a problem is handed back (n_done = -1) like
+      // one that left the float16 range; from a cold start the iterate stays exactly 0 and nothing is lost.
+      degenerate = !okm && !a.cold;
     }
     const float ys = -sigma * y_scale;
     const double* wrow = a.w + (int64_t)p * a.ldw;
@@ -316,23 +326,22 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
       for (int q = 0; q < NB; ++q)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const int t = 32 * q + tb + j;
+          const int t = MFMA_SPAN * q + tb + j;
           if (q == NB - 1) {
             const double wl = wrow[t < a.N ? t : a.N - 1] * (double)sigma;
-            w[q][j] = (t < a.N) ? wl : 0.0;
+            w[q][j] = (t < a.N && !(j == 7 && g3)) ? wl : 0.0;
+          } else if (j == 7) {
+            const double wl = wrow[t] * (double)sigma;
+            w[q][j] = g3 ? 0.0 : wl;             // the sum slot's own iterate stays 0 (its step is 0, see `update`)
           } else {
             w[q][j] = wrow[t] * (double)sigma;
           }
         }
     }
   }
-#if PB_MFMA_YMAT
-  Frag yf[NB];                                   // -2^a sigma y as float16 hi / lo fragments (B operands)
-#pragma unroll
-  for (int q = 0; q < NB; ++q) yf[q] = split8(ysn[q]);
-#endif
   const double th = lb * step * (double)sigma;
   const double nstep = -step * g_scale;
+  const double nstep7 = g3 ? 0.0 : nstep;        // j = 7: the sum slot of lane group 3 takes no step (its "gradient" is a sum)
   float guard = 0.0f;                            // largest |operand| seen by the range checks
   float wlast = 0.0f;                            // largest |sigma w| of this lane at the last check
   // cost trace: 0.5 ||r''||^2 / (2^a sigma)^2 + lbda ||w'||_1 / sigma
@@ -361,17 +370,10 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
 #pragma unroll
     for (int o = 0; o < NT; ++o)
       asm volatile("" : "+a"(An[r][o].hi), "+a"(An[r][o].lo), "+a"(Bn[r][o].hi), "+a"(Bn[r][o].lo));
-  asm volatile("" : "+a"(Ff.hi), "+a"(Ff.lo));
-#if PB_MFMA_YMAT
-  asm volatile("" : "+a"(Eh[0]), "+a"(Eh[1]));
-#pragma unroll
-  for (int q = 0; q < NB; ++q) asm volatile("" : "+a"(yf[q].hi), "+a"(yf[q].lo));
-#else
 #pragma unroll
   for (int q = 0; q < NB; ++q)
 #pragma unroll
     for (int j = 0; j < 8; ++j) asm volatile("" : "+a"(ysn[q][j]));
-#endif
 
   // The iteration is straight-line.  The matrix pipe takes one instruction per 16 cycles and holds
   // the vector issue port for 8 of them, so the source is software-pipelined BY HAND at that grain
@@ -387,45 +389,60 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
            : part == 1 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(A.hi, B.lo, acc, 0, 0, 0)
                        : __builtin_amdgcn_mfma_f32_16x16x32_f16(A.lo, B.hi, acc, 0, 0, 0);
   };
+  // two float32 -> float16 hi / lo as split_pair, and what the split drops of x1: rem = x1 - hi - lo (exact)
+  auto split_pair_rem = [](float x0, float x1, unsigned& hi, unsigned& lo, float& rem) __attribute__((always_inline)) {
+    hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+    float l0, l1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi), "v"(x1));
+    lo = pk_rne(l0, l1);
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rem) : "v"(lo), "v"(l1));
+  };
+  // slot order of the 6 NT products of a block: row half r = 1 - (slot & 1) (the half that holds the sum row finishes
+  // one slot before the end), tile o = NT-1 ... 0 (the block's own fragment last), the three split products in turn
   // ---- forward: r = T_c w - y, block by block (ascending); fragments of r go to LDS -------------
   auto forward = [&]() __attribute__((always_inline)) {
-    f4 carry = f4{0.f, 0.f, 0.f, 0.f};            // S * (sum of the blocks up to q-2), every row
     Frag wf[NB + 1];
     f4 acc[NB + 1][2];
     unsigned ph[NB + 1][4], pl[NB + 1][4];
     unsigned rh[NB][4], rl[NB][4];
+    float remf = 0.0f;                            // what the 22-bit split dropped of the last prefix sum
     if constexpr (WITH_J) { jsq = 0.0f; jl1 = 0.0f; }
     if constexpr (CERT) jw2 = 0.0f;
-    auto prep_pair = [&](auto qc, auto pc) {      // samples 2p, 2p+1 of block q -> float16 hi / lo
+    auto prep_pair = [&](auto qc, auto pc) {      // slots 2p, 2p+1 of block q -> float16 hi / lo
       constexpr int q = decltype(qc)::value, pp = decltype(pc)::value;
       float x0, x1;                               // (asm: the conversion stays HERE, not behind the update)
       asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(x0) : "v"(w[q][2 * pp]));
       asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(x1) : "v"(w[q][2 * pp + 1]));
-      if constexpr (WITH_J) jl1 += fabsf(x0) + fabsf(x1);
+      if constexpr (WITH_J) jl1 += fabsf(x0) + fabsf(x1);       // (the sum slot's own iterate is 0)
       if constexpr (CERT) jw2 = fmaf(x1, x1, fmaf(x0, x0, jw2));
-      split_pair(x0, x1, ph[q][pp], pl[q][pp]);
+      if constexpr (pp == 3 && q >= 1) {          // the sum slot: D_q = 2^-9 (w_0 + ... + w_{q-1}), finished by block q-1
+        const float d = acc[q - 1][1][3] + remf;
+        x1 = g3 ? d : x1;
+      }
+      if constexpr (pp == 3 && q + 1 < NB) split_pair_rem(x0, x1, ph[q][pp], pl[q][pp], remf);
+      else split_pair(x0, x1, ph[q][pp], pl[q][pp]);
       if constexpr (pp == 3) {
         wf[q].hi = __builtin_bit_cast(h8, u4{ph[q][0], ph[q][1], ph[q][2], ph[q][3]});
         wf[q].lo = __builtin_bit_cast(h8, u4{pl[q][0], pl[q][1], pl[q][2], pl[q][3]});
       }
     };
-    auto cinit = [&](auto qc, auto rc, const f4& cy) {   // accumulators of block q start from carry - y
+    auto cinit = [&](auto qc, auto rc) {          // accumulators of block q start from -y (the sum row: from 0)
       constexpr int q = decltype(qc)::value, r = decltype(rc)::value;
-#if PB_MFMA_YMAT
-      acc[q][r] = cy;                               // (-y follows through the matrix pipe, slots 3 + 6 NT ...)
-#else
-      acc[q][r] = f4{cy[0] + ysn[q][4 * r + 0], cy[1] + ysn[q][4 * r + 1], cy[2] + ysn[q][4 * r + 2],
-                     cy[3] + ysn[q][4 * r + 3]};
-#endif
+      acc[q][r] = f4{ysn[q][4 * r + 0], ysn[q][4 * r + 1], ysn[q][4 * r + 2], ysn[q][4 * r + 3]};
     };
-    auto finish_pair = [&](auto qc, auto pc) {    // residual samples 2p, 2p+1 of block q -> fragment
+    auto finish_pair = [&](auto qc, auto pc) {    // residual slots 2p, 2p+1 of block q -> fragment
       constexpr int q = decltype(qc)::value, pp = decltype(pc)::value;
       float x0 = acc[q][pp >> 1][(2 * pp) & 3], x1 = acc[q][pp >> 1][(2 * pp + 1) & 3];
-      if constexpr (q == NB - 1) {                // padding behind sample N-1 (last block only)
-        x0 = (32 * q + tb + 2 * pp < a.N) ? x0 : 0.0f;
-        x1 = (32 * q + tb + 2 * pp + 1 < a.N) ? x1 : 0.0f;
+      if constexpr (q == NB - 1) {                // padding behind sample N-1 and the sum slot (last block only)
+        x0 = (MFMA_SPAN * q + tb + 2 * pp < a.N) ? x0 : 0.0f;
+        x1 = (MFMA_SPAN * q + tb + 2 * pp + 1 < a.N && !(pp == 3 && g3)) ? x1 : 0.0f;
       }
-      if constexpr (WITH_J) jsq = fmaf(x1, x1, fmaf(x0, x0, jsq));
+      // (blocks before the last: the sum slot of the stored fragment holds the prefix sum; the adjoint pass patches it)
+      if constexpr (WITH_J) {
+        if constexpr (pp == 3 && q < NB - 1) jsq = fmaf(g3 ? 0.0f : x1, x1, fmaf(x0, x0, jsq));
+        else jsq = fmaf(x1, x1, fmaf(x0, x0, jsq));
+      }
       split_pair(x0, x1, rh[q][pp], rl[q][pp]);
       if constexpr (pp == 3) {
         // the residual fragments wait in LDS for the adjoint pass (each lane reads back only what
@@ -435,54 +452,71 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
       }
     };
     static_for<0, 4>([&](auto pc) { prep_pair(std::integral_constant<int, 0>{}, pc); });
-    cinit(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, carry);
-    cinit(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, carry);
+    cinit(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    cinit(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
     static_for<0, NB>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
-      f4 cn = carry;                              // carry of block q+1
-      static_for<0, 3 + 6 * NT + (PB_MFMA_YMAT ? 4 : 0)>([&](auto sc) {
+      static_for<0, 6 * NT>([&](auto sc) {
         constexpr int sl = decltype(sc)::value;
         // -- the matrix instruction of this slot
-        if constexpr (sl < 3) {                     // carry of block q+1: + S (sum of block q+1-NT)
-          if constexpr (q >= NT - 1 && q + 1 < NB) cn = mfma_part(Ff, wf[q >= NT - 1 ? q - (NT - 1) : 0], cn, sl);
-        } else if constexpr (sl >= 3 + 6 * NT) {    // PB_MFMA_YMAT: - 2^a sigma y of block q (hi, then lo part)
-#if PB_MFMA_YMAT
-          constexpr int e = sl - (3 + 6 * NT), r = e & 1;
-          acc[q][r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Eh[r], (e >> 1) == 0 ? yf[q].hi : yf[q].lo, acc[q][r], 0, 0, 0);
-#endif
-        } else {
-          constexpr int c = sl - 3, r = c & 1, k = c >> 1, o = k / 3;      // near tile o: block q-o
-          if constexpr (q >= o) acc[q][r] = mfma_part(An[r][o], wf[q >= o ? q - o : 0], acc[q][r], k - 3 * o);
-        }
-        // -- a slice of the neighbours' vector work
-        if constexpr (sl < 4) {
-          if constexpr (q + 1 < NB) prep_pair(std::integral_constant<int, q + 1>{}, sc);
-        } else if constexpr (sl < 8) {
-          if constexpr (q >= 1) finish_pair(std::integral_constant<int, q - 1>{}, std::integral_constant<int, sl - 4>{});
+        constexpr int r = 1 - (sl & 1), k = sl >> 1, o = NT - 1 - k / 3;     // near tile o: block q-o
+        if constexpr (q >= o) acc[q][r] = mfma_part(An[r][o], wf[q >= o ? q - o : 0], acc[q][r], k % 3);
+        // -- a slice of the neighbours' vector work (what reads the finished block q-1 comes two slots in)
+        if constexpr (sl == 2) {
+          if constexpr (q >= 1) prep_pair(qc, std::integral_constant<int, 3>{});
+        } else if constexpr (sl >= 3 && sl < 7) {
+          if constexpr (q >= 1) finish_pair(std::integral_constant<int, q - 1>{}, std::integral_constant<int, sl - 3>{});
+        } else if constexpr (sl >= 7 && sl < 10) {
+          if constexpr (q + 1 < NB) prep_pair(std::integral_constant<int, q + 1>{}, std::integral_constant<int, sl - 7>{});
         } else if constexpr (sl == 10 || sl == 11) {
-          if constexpr (q + 1 < NB) cinit(std::integral_constant<int, q + 1>{}, std::integral_constant<int, sl - 10>{}, cn);
+          if constexpr (q + 1 < NB) cinit(std::integral_constant<int, q + 1>{}, std::integral_constant<int, sl - 10>{});
         }
         if constexpr ((sl % PB_MFMA_SBK) == PB_MFMA_SBK - 1) PB_MFMA_SB;
       });
-      carry = cn;
     });
     static_for<0, 4>([&](auto pc) { finish_pair(std::integral_constant<int, NB - 1>{}, pc); });
   };
   // ---- adjoint and update: g = T_c^T r, block by block (descending) ------------------------------
   auto backward = [&](const double beta) __attribute__((always_inline)) {
     const double nb1 = -(1.0 + beta);
-    f4 carry = f4{0.f, 0.f, 0.f, 0.f};            // S * (sum of the residual blocks from q+2 on)
     f4 acc[NB + 1][2];
     Frag rf[NB + 2];
+    u3 fh[NB], fl[NB];                           // fetched fragments of the blocks before the last: words 0-2 ...
+    unsigned fh3[NB], fl3[NB];                    // ... and word 3
+    float remb = 0.0f;                            // what the 22-bit split dropped of the last suffix sum
+    // v_perm_b32 selector: lane group 3 takes the upper half-word (slot 7) from the new value, every other lane keeps its own
+    const unsigned psel = g3 ? 0x07060100u : 0x03020100u;
     auto fetch = [&](auto qc) {                   // residual fragment of block q: LDS -> registers
       constexpr int q = decltype(qc)::value;
-      rf[q].hi = __builtin_bit_cast(h8, lrf[(2 * q) * 64]);
-      rf[q].lo = __builtin_bit_cast(h8, lrf[(2 * q + 1) * 64]);
+      if constexpr (q == NB - 1) {                // (the last block's sum slot was zeroed by the forward pass)
+        rf[q].hi = __builtin_bit_cast(h8, lrf[(2 * q) * 64]);
+        rf[q].lo = __builtin_bit_cast(h8, lrf[(2 * q + 1) * 64]);
+      } else {
+        // words 0-2 and word 3 apart: word 3 (slots 6, 7) is rebuilt by `patch`, and a fragment loaded in one piece
+        // was seen to be copied register by register to make room for the new word
+        const unsigned* ph3 = reinterpret_cast<const unsigned*>(&lrf[(2 * q) * 64]);
+        const unsigned* pl3 = reinterpret_cast<const unsigned*>(&lrf[(2 * q + 1) * 64]);
+        fh[q] = *reinterpret_cast<const u3*>(ph3);
+        fl[q] = *reinterpret_cast<const u3*>(pl3);
+        fh3[q] = ph3[3];
+        fl3[q] = pl3[3];
+      }
+    };
+    auto patch = [&](auto qc) {                   // the sum slot of block q: 2^-9 (r_{q+1} + ... + r_{NB-1}), finished by block q+1
+      constexpr int q = decltype(qc)::value;
+      const float d = acc[q + 1][1][3] + remb;
+      const unsigned h2 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(d, d));
+      float l;
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h2), "v"(d));
+      const unsigned l2 = pk_rne(l, l);
+      if constexpr (q >= 1) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(remb) : "v"(l2), "v"(l));
+      rf[q].hi = __builtin_bit_cast(h8, u4{fh[q][0], fh[q][1], fh[q][2], __builtin_amdgcn_perm(h2, fh3[q], psel)});
+      rf[q].lo = __builtin_bit_cast(h8, u4{fl[q][0], fl[q][1], fl[q][2], __builtin_amdgcn_perm(l2, fl3[q], psel)});
     };
     auto update = [&](auto qc, auto jc) {
       constexpr int q = decltype(qc)::value, j = decltype(jc)::value;
       const double gj = (double)acc[q][j >> 2][j & 3];
-      const double u = fma(nstep, gj, w[q][j]);
+      const double u = fma(j == 7 ? nstep7 : nstep, gj, w[q][j]);
       const double d = fmin(fmax(u, -th), th);
       w[q][j] = fma(nb1, d, u);
       if constexpr (LOOPS) {
@@ -498,22 +532,23 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
     fetch(std::integral_constant<int, NB - 1>{});
     static_for<0, NB>([&](auto qq) {
       constexpr int q = NB - 1 - decltype(qq)::value;
-      f4 cn = carry;                              // carry of block q-1
-      if constexpr (q >= 1) fetch(std::integral_constant<int, q - 1>{});   // one block ahead
-      static_for<0, 3 + 6 * NT>([&](auto sc) {
+      constexpr int omax = (NT - 1 < NB - 1 - q) ? NT - 1 : NB - 1 - q;     // the oldest tile this block has
+      static_for<0, 6 * NT>([&](auto sc) {
         constexpr int sl = decltype(sc)::value;
-        if constexpr (sl < 3) {                     // carry of block q-1: + S (sum of block q-1+NT)
-          if constexpr (q >= 1 && q - 1 + NT < NB) cn = mfma_part(Ff, rf[q - 1 + NT < NB ? q - 1 + NT : 0], cn, sl);
-        } else {
-          constexpr int c = sl - 3, r = c & 1, k = c >> 1, o = k / 3;      // near tile o: block q+o
-          if constexpr (k == 0) acc[q][r] = mfma_part(Bn[r][0], rf[q], carry, 0);
-          else if constexpr (q + o < NB) acc[q][r] = mfma_part(Bn[r][o], rf[q + o < NB ? q + o : 0], acc[q][r], k - 3 * o);
+        constexpr int r = 1 - (sl & 1), k = sl >> 1, o = NT - 1 - k / 3;     // near tile o: block q+o
+        if constexpr (o <= omax) {
+          if constexpr (o == omax && (k % 3) == 0) acc[q][r] = mfma_part(Bn[r][o], rf[q + o], f4{0.f, 0.f, 0.f, 0.f}, 0);
+          else acc[q][r] = mfma_part(Bn[r][o], rf[q + o], acc[q][r], k % 3);
         }
-        if constexpr ((sl & 1) == 0 && sl < 16 && q + 1 < NB)
-          update(std::integral_constant<int, q + 1>{}, std::integral_constant<int, sl / 2>{});
+        if constexpr (sl == 0) {
+          if constexpr (q + 1 < NB) fetch(std::integral_constant<int, q>{});   // (needed from slot 6 on: the older tile runs first)
+        } else if constexpr (sl == 2) {
+          if constexpr (q + 1 < NB) patch(std::integral_constant<int, q>{});
+        } else if constexpr (sl >= 3 && sl < 11) {
+          if constexpr (q + 1 < NB) update(std::integral_constant<int, q + 1>{}, std::integral_constant<int, sl - 3>{});
+        }
         if constexpr ((sl % PB_MFMA_SBK) == PB_MFMA_SBK - 1) PB_MFMA_SB;
       });
-      carry = cn;
     });
     static_for<0, 8>([&](auto jc) { update(std::integral_constant<int, 0>{}, jc); });
     if constexpr (CERT) {
@@ -580,7 +615,7 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
           gq = fmaxf(gq, __shfl_xor(gq, 32, 64));
           wq = fmaxf(wq, __shfl_xor(wq, 16, 64));
           wq = fmaxf(wq, __shfl_xor(wq, 32, 64));
-          const bool badq = !(gq < 60000.0f) || (a.rho_guard && wq > 0.0f && (float)th > MFMA_RHO_MAX * wq);
+          const bool badq = !(gq < 60000.0f) || (a.rho_guard && wq > 0.0f && (float)th > MFMA_RHO_MAX * wq) || degenerate;
           if (fire) {
             lactive = false;
             if (live && !badq) {
@@ -589,8 +624,8 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
               for (int q = 0; q < NB; ++q)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                  const int t = 32 * q + tb + j;
-                  if (t < a.N) wrow[t] = w[q][j] * (double)inv_sigma;
+                  const int t = MFMA_SPAN * q + tb + j;
+                  if (t < a.N && !(j == 7 && g3)) wrow[t] = w[q][j] * (double)inv_sigma;
                 }
             }
             if (live && a.n_done && g == 0) a.n_done[p] = badq ? -1 : it + 1;
@@ -640,7 +675,7 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
   // (tools/r3_mfma_precision.py): <= 2e-6 on diff_z for th / max|w| < 0.03, up to 1.5e-5 beyond 0.1.
   // Problems above MFMA_RHO_MAX (sparse solutions, lambda near lambda_max) go back to the float32
   // operators like those that left the float16 range.
-  const bool bad = !(guard < 60000.0f) ||        // NaN-safe (float16: 65504)
+  const bool bad = !(guard < 60000.0f) || degenerate ||        // NaN-safe (float16: 65504)
                    (a.rho_guard && wlast > 0.0f && (float)th > MFMA_RHO_MAX * wlast) || (CERT && cflag);
   if (live && !bad && (!LOOPS || lactive)) {
     double* wrow = a.w + (int64_t)p * a.ldw;
@@ -648,8 +683,8 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
     for (int q = 0; q < NB; ++q)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int t = 32 * q + tb + j;
-        if (t < a.N) wrow[t] = w[q][j] * (double)inv_sigma;
+        const int t = MFMA_SPAN * q + tb + j;
+        if (t < a.N && !(j == 7 && g3)) wrow[t] = w[q][j] * (double)inv_sigma;
       }
   }
   if (live && a.n_done && g == 0 && (!LOOPS || lactive)) a.n_done[p] = bad ? -1 : a.n_iter;
@@ -700,10 +735,10 @@ int launch_mfma_nt(const FistaArgs& a, const double* taps, int K, bool with_j, h
 
 template <int NB>
 int launch_mfma(const FistaArgs& a, const double* taps, int K, bool with_j, hipStream_t st) {
-  if (a.N > 32 * NB || a.N <= 32 * (NB - 1) || K < 1) return 1;
+  if (a.N > MFMA_SPAN * NB || a.N <= MFMA_SPAN * (NB - 1) || K < 1) return 1;
   if (K <= 33) return launch_mfma_nt<NB, 2>(a, taps, K, with_j, st);
 #if PB_MFMA_NT3
-  if (K <= 65) return launch_mfma_nt<NB, 3>(a, taps, K, with_j, st);
+  if (K <= 64) return launch_mfma_nt<NB, 3>(a, taps, K, with_j, st);
 #endif
   return 1;
 }
