@@ -58,16 +58,19 @@ def executed_flops_per_voxel_iter(n, k):
 
 def mfma_per_wave_iteration(n, k, split=False):
     """v_mfma_f32_16x16x32_f16 instructions per iteration and 16 problems: one wave of fista_mfma_kernel
-    (NB = ceil(N/32) blocks, NT near tiles (2 for K <= 33, 3 for K <= 65), three split products per tile
-    and row half, three for the running far-field carry; both passes; pybold_amd/csrc/fista_mfma.h --
-    276 at N = 300, K = 30, the count SQ_INSTS_MFMA reports, profiles/r3_pmc_mfma.json) or, `split`,
-    the two waves of fista_mfma2_kernel together (fista_mfma2.h: floor(NB/2) + ceil(NB/2) blocks; the
-    waves' carry chains restart at the cut: 270 at N = 300)."""
-    nb, nt = (n + 31) // 32, (2 if k <= 33 else 3)
+    (NB = ceil(N/31) blocks of 31 samples + one sum slot, NT near tiles (2 for K <= 33, 3 for K <= 64), three
+    split products per tile and row half, both passes; the far field rides in the sum slot and costs no
+    instruction of its own; pybold_amd/csrc/fista_mfma.h -- 228 at N = 300, K = 30, the count SQ_INSTS_MFMA
+    reports, profiles/r4_pmc_mfma.json; round 3's carry-tile form: 276) or, `split`, the two waves of
+    fista_mfma2_kernel together (fista_mfma2.h: floor(NB/2) + ceil(NB/2) blocks of 32 samples with the
+    carry tile; the waves' carry chains restart at the cut: 270 at N = 300)."""
+    nt = 2 if k <= 33 else 3
     if split:
+        nb = (n + 31) // 32
         a, b = nb // 2, nb - nb // 2
         return (3 * (a - 2) + 6 * a + 6 * (a - 1)) + (3 * (b - 1) + 12 * b) + (3 * (b - 2) + 6 * b + 6 * (b - 1)) + (3 * (a - 1) + 12 * a)
-    return 2 * (3 * (nb - nt) + 6 * sum(nb - o for o in range(nt)))
+    nb = (n + 30) // 31
+    return 2 * 6 * sum(nb - o for o in range(nt))
 
 
 MFMA_FLOP = 2.0 * 16 * 16 * 32       # one v_mfma_f32_16x16x32_f16

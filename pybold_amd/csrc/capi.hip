@@ -90,7 +90,9 @@ PB_MFMA2(6, 7) PB_MFMA2(7, 7) PB_MFMA2(7, 8) PB_MFMA2(8, 8) PB_MFMA2(8, 9) PB_MF
 }
 namespace {
 // the matrix-pipe form with one series split over the two waves of a workgroup (fista_mfma2.h): nb = ceil(N / 32)
-// blocks, 5 <= nb <= 20 (129 .. 640 scans), floor(nb / 2) of them in the left wave; K <= 33; plain solves, the cost
+// blocks of 32 samples (it keeps round 3's carry tile: its waves are bound by the vector work of the exchange, not by
+// their matrix instructions -- the sum-slot form of fista_mfma.h measured 4 % slower there), 5 <= nb <= 20
+// (129 .. 640 scans), floor(nb / 2) of them in the left wave; K <= 33; plain solves, the cost
 // trace and the window rule (wind = 6) as a no-fire certificate; the shared-HRF z-step plain only
 typedef int (*mfma2_launch_fn)(const pb::FistaArgs&, const double*, int, bool, hipStream_t);
 mfma2_launch_fn pick_mfma2(int N, int K) {
@@ -104,7 +106,7 @@ mfma2_launch_fn pick_mfma2(int N, int K) {
   return tab[nb - 5];
 }
 typedef int (*mfma_launch_fn)(const pb::FistaArgs&, const double*, int, bool, hipStream_t);
-// the matrix-pipe form (fista_mfma.h): NB = ceil(N / 31) blocks of 31 samples + one sum slot, 125 <= N <= 310; K <= 33
+// the matrix-pipe form (fista_mfma.h): NB = ceil(N / 31) blocks of 31 samples + one sum slot, 129 <= N <= 310; K <= 33
 // with two near tiles (every variant), 34 <= K <= 64 with three (`extras` = window-rule certificate:
 // not built for those)
 constexpr int MFMA_K2 = 33, MFMA_K3 = 64;
@@ -113,7 +115,7 @@ mfma_launch_fn pick_mfma(int N, int K, bool extras = false) {
   static const mfma_launch_fn tab[] = {&pb::launch_mfma<5>, &pb::launch_mfma<6>, &pb::launch_mfma<7>,
                                        &pb::launch_mfma<8>, &pb::launch_mfma<9>, &pb::launch_mfma<10>};
   const int nb = (N + pb::MFMA_SPAN - 1) / pb::MFMA_SPAN;
-  if (K < 1 || K > MFMA_K3 || (K > MFMA_K2 && extras) || nb < 5 || nb > 10) return nullptr;
+  if (K < 1 || K > MFMA_K3 || (K > MFMA_K2 && extras) || N <= 128 || nb > 10) return nullptr;   // (129 .. 310 scans: 5 .. 10 blocks)
   return tab[nb - 5];
 }
 }  // namespace
@@ -459,7 +461,7 @@ int plan_pieces(int P, bool has_pair, bool has_wide, bool one_launch, bool one_s
 //   beyond                               one more pass of the one-wave form, as before
 constexpr int MFMA2_MIN_R = 4608;
 constexpr int MFMA2_BESIDE_CHUNKS = 2;         // chunks of one one-problem wave per SIMD beside a split-form pass
-// Series of 321 .. 640 scans (11 .. 20 blocks) run on the split form from this many problems on (below, the
+// Series of 311 .. 640 scans (10 .. 20 blocks) run on the split form from this many problems on (below, the
 // pair form over two slots or the latency-bound one-problem-per-wave form finish first: N = 600, 4 096 problems
 // 1.58 ms against 1.93, 8 192 2.87 against 1.97 -- profiles/r4_split_form_passes.txt); whole passes of 8 192
 // problems, a remainder above 5/16 of a pass too, a smaller one on the one-problem-per-wave form.
@@ -835,7 +837,7 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
                           !(flags & (PB_FLAG_FORCE_GENERIC | PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_FORCE_WIDE |
                                      PB_FLAG_DIRECT_FIR | PB_FLAG_NO_MFMA)) && mfma_serves_plain(N, K);
   // The matrix-pipe form with every series split over two waves (fista_mfma2.h): plain solves without cost trace.
-  // Series of 321..640 scans run on it from MFMA2_LONG_MIN_P problems on: whole passes (and a remainder above a
+  // Series of 311..640 scans run on it from MFMA2_LONG_MIN_P problems on: whole passes (and a remainder above a
   // quarter of a pass), the rest and whatever its guards hand back on the one-problem-per-wave form.  Shorter series
   // meet it as a piece of the plan below (small batches, remainders) or through PB_FLAG_FORCE_MFMA2.
   // (the window rule rides it as the no-fire certificate of the one-wave form: wind = 6, far from firing)

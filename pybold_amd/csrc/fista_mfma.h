@@ -285,10 +285,12 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
         float yv;
         if (q == NB - 1) {
           const bool ok = t < a.N && !(j == 7 && g3);
-          const float yl = yrow[t < a.N ? t : a.N - 1];
+          float yl = yrow[t < a.N ? t : a.N - 1];
+          asm volatile("" : "+v"(yl));           // (the load stays unconditional)
           yv = ok ? yl : 0.0f;
         } else if (j == 7) {
-          const float yl = yrow[t];              // (lane group 3: the first sample of block q+1, a valid address)
+          float yl = yrow[t];                    // (lane group 3: the first sample of block q+1, a valid address)
+          asm volatile("" : "+v"(yl));
           yv = g3 ? 0.0f : yl;
         } else {
           yv = yrow[t];
@@ -328,10 +330,12 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
         for (int j = 0; j < 8; ++j) {
           const int t = MFMA_SPAN * q + tb + j;
           if (q == NB - 1) {
-            const double wl = wrow[t < a.N ? t : a.N - 1] * (double)sigma;
+            double wl = wrow[t < a.N ? t : a.N - 1] * (double)sigma;
+            asm volatile("" : "+v"(wl));         // (the load stays unconditional: no exec-masked region, see above)
             w[q][j] = (t < a.N && !(j == 7 && g3)) ? wl : 0.0;
           } else if (j == 7) {
-            const double wl = wrow[t] * (double)sigma;
+            double wl = wrow[t] * (double)sigma;
+            asm volatile("" : "+v"(wl));
             w[q][j] = g3 ? 0.0 : wl;             // the sum slot's own iterate stays 0 (its step is 0, see `update`)
           } else {
             w[q][j] = wrow[t] * (double)sigma;
