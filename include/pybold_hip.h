@@ -95,8 +95,9 @@ int pb_fista_has_fast_path(int N, int K);
  * LDS kernel, 1 = register-resident, one problem per 16-lane row (fista_fast_kernel),
  * 2 = register-resident, two problems per row (fista_pair_kernel), 3 = register-resident,
  * one problem per wave (long series), 4 = register-resident, 16 problems per wave, both operators
- * on the matrix pipe (fista_mfma_kernel: 129..320 scans; HRFs of up to 48 taps, the window-rule certificate up to
- * 33; one lambda for the batch; assumes n_done_dev is given).  Host-only query. */
+ * on the matrix pipe (fista_mfma_kernel: 129..310 scans; HRFs of up to 48 taps, the window-rule certificate up to
+ * 33; one lambda for the batch; assumes n_done_dev is given), 5 = the same with every series split over the two waves
+ * of a workgroup (fista_mfma2_kernel: small batches, and series of 311..640 scans).  Host-only query. */
 int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mode, int wind);
 
 /* How pb_fista_solve (no flags) lays P problems out: problems [0, *n_main) in one launch of
@@ -162,11 +163,12 @@ int pb_fista_plan_ex(int N, int K, int P, int stop_mode, int wind, unsigned flag
  *       series scaled by a per-problem power of two into the float16 range (exact: the problem is
  *       scale-covariant).
  * (b) is chosen for plain solves (PB_STOP_NONE, or PB_STOP_WINDOW as a certificate with tol * n_iter < 0.02)
- * of 129..320 scans with ONE lambda for the call (lbda_dev == NULL, or per-problem lambdas with the dense
+ * of 129..310 scans (up to 640 on the split form) with ONE lambda for the call (lbda_dev == NULL, or per-problem lambdas with the dense
  * part of a regularisation path: see below) -- AND ONLY IF n_done_dev IS GIVEN: the matrix-pipe kernel
  * reports through n_done the problems it must not keep, namely
  *   - range: a residual fragment reached 2^15 or |sigma w| reached 60000 (checked after the first pass of a
  *     warm start, every 8th iteration and at the end), and
+ *   - scale: an all-zero series with a warm start (no scale to bring the iterate into the float16 range), and
  *   - accuracy: the solution is too sparse for 22-bit operators, lbda * step > 0.02 * max|w| at the end (an
  *     error eps in the gradient moves a solution entry by ~eps * threshold, so the relative error of ANY
  *     arithmetic grows with threshold / max|w|; measured <= 3e-6 on diff_z below that bound, up to 1.5e-5
@@ -201,7 +203,7 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep,
  * dense_ratio <= 0 selects PB_PATH_DENSE_RATIO (calibrated on block-signal paths, profiles/r4_path_partition.txt: the
  * guard hands back 0.3 % of the problems at lambda / lambda_max = 0.11, 5 % at 0.14, 24 % at 0.18, 62 % at 0.23).  work_dev: int32 scratch of at least pb_fista_path_work_len(P)
  * entries (index lists and counts; contents meaningless afterwards).  lmax_dev == NULL, work_dev == NULL or a
- * shape outside the matrix-pipe form (129..320 scans, <= 33 taps): the call is pb_fista_solve with lbda_dev.
+ * shape outside the matrix-pipe form (129..310 scans, <= 33 taps): the call is pb_fista_solve with lbda_dev.
  */
 #define PB_PATH_DENSE_RATIO 0.13
 int64_t pb_fista_path_work_len(int P);

@@ -240,12 +240,12 @@ constexpr int SPLIT_MIN_P = 1024;
 
 // Plain solves (no stop rule) of a shape the matrix-pipe form serves AND some vector form can back up
 // (remainders, re-solves of what its guards hand back): they go to the matrix pipe before the split-pair form
-// is considered -- 305..320 scans fit ten blocks of 32 samples but have no single-slot pair entry, and one
+// is considered -- 305..310 scans fit ten blocks of 31 samples but have no single-slot pair entry, and one
 // matrix-pipe wave beats the pair form over two slots.
 bool mfma_serves_plain(int N, int K) {
   return pick_mfma(N, K) != nullptr && (pick_fast(N, K) != nullptr || pick_wide(N, K) != nullptr);
 }
-// without a single-row entry (305..320 scans and more than 32 taps) the remainder of the whole rounds goes to the
+// without a single-row entry (305..310 scans and more than 32 taps) the remainder of the whole rounds goes to the
 // one-problem-per-wave form when it is small, else everything runs on the matrix pipe (a partial last pass)
 double wave_slots();
 int mfma_wide_base(int P, bool one_launch) {
@@ -916,7 +916,7 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
   const bool cert = fe && stop_mode == PB_STOP_WINDOW && wind == 6 && fe->fn_pair_cert && n_done_dev &&
                     P >= 2 && !(flags & (PB_FLAG_NO_PAIR | PB_FLAG_NO_CERT | PB_FLAG_DIRECT_FIR)) &&
                     ((flags & PB_FLAG_FORCE_CERT) || tol * (double)n_iter < 0.5);
-  // plain solves (cost trace or not) of 129..320 scans, HRFs up to 33 taps (34..65: no certificate): both operators on the
+  // plain solves (cost trace or not) of 129..310 scans, HRFs up to 33 taps (34..65: no certificate): both operators on the
   // matrix pipe (fista_mfma.h).  Needs n_done_dev: a problem whose scaled operands left the float16
   // range comes back with n_done = -1 and is re-solved on the single-row form.
   // Not with one lambda per problem, unless asked for (PB_FLAG_FORCE_MFMA): along a regularisation
@@ -1045,7 +1045,7 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
       return fail(PB_ERR_HIP, "pb_fista_solve: join of the side stream failed");
     return finish(rc_all);
   }
-  // 305..320 scans with more than 32 taps: no single-row entry, but ten blocks of 32 samples fit the matrix-pipe
+  // 305..310 scans with more than 32 taps: no single-row entry, but ten blocks of 31 samples fit the matrix-pipe
   // form -- whole rounds (or everything) on it, a small remainder and the problems its guards hand back on the
   // one-problem-per-wave form
   if (!fe && mfma_plain) {

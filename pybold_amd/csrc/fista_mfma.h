@@ -64,6 +64,11 @@
 #ifndef PB_MFMA_SB
 #define PB_MFMA_SB
 #endif
+// PB_MFMA_REM (on): what the 22-bit split of a prefix / suffix sum drops is carried along and added back to the next sum
+// (one v_fma_mix_f32 + one addition per block and pass), so that the sums keep float32 precision.  A/B build: 0.
+#ifndef PB_MFMA_REM
+#define PB_MFMA_REM 1
+#endif
 #ifndef PB_MFMA_CHECKS
 #define PB_MFMA_CHECKS 1
 #endif
@@ -149,8 +154,8 @@ __device__ __forceinline__ f4 mma3(const Frag& A, const Frag& B, f4 acc) {
   return acc;
 }
 
-// NB blocks of 32 samples per series, 32 (NB - 1) < N <= 32 NB (only the last block can hold
-// padding), HRFs of up to 33 taps (NT = 2 near tiles) or 65 taps (NT = 3: one more near tile per block and
+// NB blocks of 31 samples + one sum slot per series, 31 (NB - 1) < N <= 31 NB (only the last block can hold
+// padding), HRFs of up to 33 taps (NT = 2 near tiles) or 64 taps (NT = 3: one more near tile per block and
 // pass, the far field starts one block further away; every variant but CERT).  No stop rule.
 // WITH_J: cost trace, J[it] = 0.5 ||T_c w_{it+1} - y||^2 + lbda ||w_{it+1}||_1 (pybold/bold_signal.py:74-77)
 //   from the residual of the NEXT forward pass (the loop is rotated: one forward pass in front).
@@ -175,7 +180,7 @@ __device__ __forceinline__ f4 mma3(const Frag& A, const Frag& B, f4 acc) {
 //   discarded -- as in fista_fast.h.  Plain variant only (no cost trace, taps as kernel arguments, two near tiles).
 template <int NB, bool WITH_J = false, bool TAPS_DEV = false, bool CERT = false, int NT = 2, bool LOOPS = false>
 __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs a, MfmaTaps tp) {
-  static_assert(NT == 2 || NT == 3, "two near tiles (K <= 33) or three (K <= 65)");
+  static_assert(NT == 2 || NT == 3, "two near tiles (K <= 33) or three (K <= 64)");
   static_assert(!LOOPS || (!WITH_J && !TAPS_DEV && !CERT && NT == 2), "the stop rule rides the plain variant");
   constexpr int LCW = NT == 2 ? 64 : 96;           // cumulative taps kept per wave: lags 0 .. 32 NT - 1
   static_assert(!CERT || (WITH_J && !TAPS_DEV), "the certificate runs in the rotated (cost trace) loop");
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
     double run = 0.0, run2 = 0.0;
     for (int k = 0; k <= lane && k < a.K; ++k) run += (double)(float)a.taps_pp[k];
     float cm = fabsf((float)run);
-    if constexpr (NT == 3) {                       // lags 64 .. 95 (K <= 65: sum of the first lane + 65 taps)
+    if constexpr (NT == 3) {                       // lags 64 .. 95 (K <= 64: sum of the first lane + 65 taps)
       run2 = run;
       for (int k = lane + 1; k <= lane + 64 && k < a.K; ++k) run2 += (double)(float)a.taps_pp[k];
       cm = fmaxf(cm, fabsf((float)run2));
@@ -424,7 +429,7 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
         const float d = acc[q - 1][1][3] + remf;
         x1 = g3 ? d : x1;
       }
-      if constexpr (pp == 3 && q + 1 < NB) split_pair_rem(x0, x1, ph[q][pp], pl[q][pp], remf);
+      if constexpr (PB_MFMA_REM && pp == 3 && q + 1 < NB) split_pair_rem(x0, x1, ph[q][pp], pl[q][pp], remf);
       else split_pair(x0, x1, ph[q][pp], pl[q][pp]);
       if constexpr (pp == 3) {
         wf[q].hi = __builtin_bit_cast(h8, u4{ph[q][0], ph[q][1], ph[q][2], ph[q][3]});
@@ -465,15 +470,19 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
         // -- the matrix instruction of this slot
         constexpr int r = 1 - (sl & 1), k = sl >> 1, o = NT - 1 - k / 3;     // near tile o: block q-o
         if constexpr (q >= o) acc[q][r] = mfma_part(An[r][o], wf[q >= o ? q - o : 0], acc[q][r], k % 3);
-        // -- a slice of the neighbours' vector work (what reads the finished block q-1 comes two slots in)
-        if constexpr (sl == 2) {
+        // -- a slice of the neighbours' vector work.  The first two slots get work that depends on nothing just finished
+        // (the next block's fragment); what reads the finished block q-1 comes two slots in -- the sum slot first: the
+        // block's own fragment is needed from slot 6 on
+        if constexpr (sl < 2) {
+          if constexpr (q + 1 < NB) prep_pair(std::integral_constant<int, q + 1>{}, sc);
+        } else if constexpr (sl == 2) {
           if constexpr (q >= 1) prep_pair(qc, std::integral_constant<int, 3>{});
         } else if constexpr (sl >= 3 && sl < 7) {
           if constexpr (q >= 1) finish_pair(std::integral_constant<int, q - 1>{}, std::integral_constant<int, sl - 3>{});
-        } else if constexpr (sl >= 7 && sl < 10) {
-          if constexpr (q + 1 < NB) prep_pair(std::integral_constant<int, q + 1>{}, std::integral_constant<int, sl - 7>{});
-        } else if constexpr (sl == 10 || sl == 11) {
-          if constexpr (q + 1 < NB) cinit(std::integral_constant<int, q + 1>{}, std::integral_constant<int, sl - 10>{});
+        } else if constexpr (sl == 7) {
+          if constexpr (q + 1 < NB) prep_pair(std::integral_constant<int, q + 1>{}, std::integral_constant<int, 2>{});
+        } else if constexpr (sl == 8 || sl == 9) {
+          if constexpr (q + 1 < NB) cinit(std::integral_constant<int, q + 1>{}, std::integral_constant<int, sl - 8>{});
         }
         if constexpr ((sl % PB_MFMA_SBK) == PB_MFMA_SBK - 1) PB_MFMA_SB;
       });
@@ -513,7 +522,7 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
       float l;
       asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h2), "v"(d));
       const unsigned l2 = pk_rne(l, l);
-      if constexpr (q >= 1) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(remb) : "v"(l2), "v"(l));
+      if constexpr (PB_MFMA_REM && q >= 1) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(remb) : "v"(l2), "v"(l));
       rf[q].hi = __builtin_bit_cast(h8, u4{fh[q][0], fh[q][1], fh[q][2], __builtin_amdgcn_perm(h2, fh3[q], psel)});
       rf[q].lo = __builtin_bit_cast(h8, u4{fl[q][0], fl[q][1], fl[q][2], __builtin_amdgcn_perm(l2, fl3[q], psel)});
     };
@@ -544,16 +553,22 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
           if constexpr (o == omax && (k % 3) == 0) acc[q][r] = mfma_part(Bn[r][o], rf[q + o], f4{0.f, 0.f, 0.f, 0.f}, 0);
           else acc[q][r] = mfma_part(Bn[r][o], rf[q + o], acc[q][r], k % 3);
         }
+        // vector slices: the update of block q+1 needs its finished accumulators, so its last three samples wait for the
+        // first slots of the NEXT block -- where nothing else is ready yet (the iterate is not needed before the next pass)
         if constexpr (sl == 0) {
           if constexpr (q + 1 < NB) fetch(std::integral_constant<int, q>{});   // (needed from slot 6 on: the older tile runs first)
-        } else if constexpr (sl == 2) {
+        }
+        if constexpr (sl < 3) {
+          if constexpr (q + 2 < NB) update(std::integral_constant<int, q + 2>{}, std::integral_constant<int, sl + 5>{});
+        } else if constexpr (sl == 3) {
           if constexpr (q + 1 < NB) patch(std::integral_constant<int, q>{});
-        } else if constexpr (sl >= 3 && sl < 11) {
-          if constexpr (q + 1 < NB) update(std::integral_constant<int, q + 1>{}, std::integral_constant<int, sl - 3>{});
+        } else if constexpr (sl >= 4 && sl < 9) {
+          if constexpr (q + 1 < NB) update(std::integral_constant<int, q + 1>{}, std::integral_constant<int, sl - 4>{});
         }
         if constexpr ((sl % PB_MFMA_SBK) == PB_MFMA_SBK - 1) PB_MFMA_SB;
       });
     });
+    if constexpr (NB >= 2) static_for<5, 8>([&](auto jc) { update(std::integral_constant<int, 1>{}, jc); });
     static_for<0, 8>([&](auto jc) { update(std::integral_constant<int, 0>{}, jc); });
     if constexpr (CERT) {
       // the window combination on this lane's tracked sample (see fista_pair_ffa.h): float32 from
@@ -604,7 +619,7 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
       if constexpr (LOOPS) { ldsq0 = ldsq1 = lwsq0 = lwsq1 = 0.0; }
       backward(beta);
       if constexpr (LOOPS) {
-        double num = ldsq0 + ldsq1, den = lwsq0 + lwsq1;     // this lane's 8 NB samples -> the problem's 32 NB
+        double num = ldsq0 + ldsq1, den = lwsq0 + lwsq1;     // this lane's 8 NB slots -> the problem's 32 NB
         num += __shfl_xor(num, 16, 64);
         den += __shfl_xor(den, 16, 64);
         num += __shfl_xor(num, 32, 64);
@@ -649,7 +664,7 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
       cert_it = it;
       backward(beta);
       forward();
-      float sq = jsq, l1 = jl1;                   // this lane's 8 NB samples -> the problem's 32 NB
+      float sq = jsq, l1 = jl1;                   // this lane's 8 NB slots -> the problem's 32 NB
       sq += __shfl_xor(sq, 16, 64);
       l1 += __shfl_xor(l1, 16, 64);
       sq += __shfl_xor(sq, 32, 64);
@@ -695,7 +710,7 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
 }
 
 // 16 problems per wave, 4 waves per workgroup, one wave per SIMD.  NT near tiles: 2 for K <= 33, 3 for
-// K <= 65 (PB_MFMA_NT3; plain solves with or without cost trace and the shared-HRF z-step; not the
+// K <= 64 (PB_MFMA_NT3; plain solves with or without cost trace and the shared-HRF z-step; not the
 // window-rule certificate).
 #ifndef PB_MFMA_NT3
 #define PB_MFMA_NT3 1
@@ -718,7 +733,7 @@ int launch_mfma_nt(const FistaArgs& a, const double* taps, int K, bool with_j, h
   }
   if (cert && (!a.n_done || a.taps_pp)) return 1;
   if (NT == 3 && cert) return 1;               // (the certificate's state spills beside three near tiles: 260 B per lane)
-  const size_t lds = (size_t)4 * NB * 2 * 64 * sizeof(u4) + 4 * (NT == 2 ? 64 : 96) * sizeof(float) +    // residual fragments (8 KB per block of 32 samples), taps
+  const size_t lds = (size_t)4 * NB * 2 * 64 * sizeof(u4) + 4 * (NT == 2 ? 64 : 96) * sizeof(float) +    // residual fragments (8 KB per block of 32 slots), taps
                      (cert ? 7 * 256 * sizeof(float) : 0);                                // certificate state
   if (a.taps_pp) {                              // shared HRF and step in device memory; no cost trace
     const MfmaTaps none{};

@@ -4,7 +4,7 @@
 // updated iterate -- so an odd block goes to the right wave and that work hides in the left wave's slack).  Two uses:
 //   * series of 321 .. 640 scans (11 .. 20 blocks): they do not fit one wave (the float64 iterate alone would be
 //     304+ registers) -- the reference's own shipped demo is 600 scans (examples/synth_data/deconv.py:46);
-//   * small batches and remainders of 225 .. 320 scans: a pass of the one-wave form lasts what 16 problems x NB
+//   * small batches and remainders of 129 .. 320 scans: a pass of the one-wave form lasts what 16 problems x NB
 //     blocks last on ONE SIMD whatever the batch size; split over two SIMDs an iteration takes about half as long
 //     (8 192 problems per pass instead of 16 384).
 //

@@ -72,7 +72,7 @@ def test_version_and_dispatch_table(lib):
     assert lib.pb_fista_which_kernel(300, 30, 12500, 0, 0, 6) == 4       # config 3's shard on 8 GPUs
     assert lib.pb_fista_which_kernel(300, 30, 8000, 0, 0, 6) == 5        # under half a round: one pass of the split matrix-pipe form
     assert lib.pb_fista_which_kernel(300, 30, 8000, 1, 0, 6) == 5        # ... with the cost trace too
-    assert lib.pb_fista_which_kernel(240, 27, 50000, 0, 0, 6) == 4       # 129..320 scans, up to 33 taps
+    assert lib.pb_fista_which_kernel(240, 27, 50000, 0, 0, 6) == 4       # 129..310 scans, up to 33 taps
     assert lib.pb_fista_which_kernel(128, 16, 50000, 0, 0, 6) == 2       # shorter series: pair form
     assert lib.pb_fista_which_kernel(300, 30, 8192, 1, 2, 6) == 5        # the deconv default call, half a round: one pass of the split form (certificate)
     assert lib.pb_fista_which_kernel(300, 30, 50000, 1, 2, 6) == 4       # ... whole rounds: matrix-pipe form

@@ -59,10 +59,12 @@ def test_golden_grid_on_the_matrix_pipe(solver, golden):
     assert worst < 3e-6
 
 
-@pytest.mark.parametrize("n,k", [(129, 16), (160, 27), (200, 30), (224, 27), (225, 27), (240, 27), (256, 33),
-                                 (257, 20), (284, 28), (288, 27), (289, 27), (300, 30), (304, 33), (320, 32)])
+@pytest.mark.parametrize("n,k", [(129, 16), (155, 27), (156, 27), (160, 27), (186, 30), (187, 30), (200, 30), (217, 27), (218, 27),
+                                 (224, 27), (225, 27), (240, 27), (248, 33), (249, 20), (256, 33), (257, 20), (279, 28), (280, 27),
+                                 (284, 28), (288, 27), (289, 27), (300, 30), (304, 33), (310, 33), (310, 32), (311, 30), (320, 32)])
 def test_series_lengths_and_tap_counts(solver, n, k):
-    """129..320 scans (5..10 blocks of 32 samples, padding in the last block only), up to 33 taps;
+    """129..310 scans on the one-wave form (5..10 blocks of 31 samples + one sum slot, padding in the last block only:
+    every block boundary is in the list), 311..320 on the split form; up to 33 taps;
     one lambda per problem, shared series (y_rep), warm start; vs the float64 C oracle."""
     rng = np.random.RandomState(n)
     hrf = orc.spm_hrf(1.0, 1.0, float(k), False)[0][:k]

@@ -161,7 +161,7 @@ def test_launch_plan_of_a_plain_solve():
               29000: (24576, pair, row), 50000: (49152, pair, wave), 100000: (98304, pair, wave)}
     for P, want in expect.items():
         assert solver.launch_plan(300, 30, P, force="valu") == want, P
-    # with the matrix-pipe forms (129..320 scans, up to 33 taps): whole rounds of 16 384 problems on the one-wave form
+    # with the matrix-pipe forms (129..310 scans, up to 33 taps): whole rounds of 16 384 problems on the one-wave form
     # (round 3); what they leave (round 4): up to 4 608 problems on the vector forms' plan, up to half a round as ONE
     # pass of the split form (every series over two waves: half the latency), up to half a round + 2 048 as that pass
     # with one-problem waves beside and behind it, anything larger as one more pass of the one-wave form

@@ -12,7 +12,7 @@ rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 worst = {}
 t0 = time.time()
 for case in range(n_cases):
-    N = int(rng.choice([rng.randint(1, 305), rng.randint(129, 321), rng.randint(1, 700), rng.randint(700, 2433)], p=[0.3, 0.4, 0.2, 0.1]))
+    N = int(rng.choice([rng.randint(1, 305), rng.randint(129, 311), rng.randint(1, 700), rng.randint(700, 2433)], p=[0.3, 0.4, 0.2, 0.1]))
     K = int(min(rng.randint(1, 49), max(1, N)))
     V = int(rng.randint(1, 120))
     y_rep = int(rng.choice([1, 1, 1, 3, 20]))
@@ -42,7 +42,7 @@ for case in range(n_cases):
         forms += [None, "fast1", "fast2", "fast2d", "seq", "one"]
     if N <= 2432 and K <= 48:
         forms += ["wide"]
-    if 128 < N <= 320 and solver.has_fast_path(N, K):              # round 3: the matrix-pipe form (guards + re-solve
+    if 128 < N <= 310 and solver.has_fast_path(N, K):              # round 3: the matrix-pipe form (guards + re-solve
         forms += ["mfma", "valu"]                                  # included), and the dispatch without it
     for force in forms:
         try:
