@@ -377,8 +377,10 @@ def run(args):
                       "matrix_pipe_busy_estimate": n_mfma * 16.0 / 16.0 * float(P_dom) * n_iter /
                                                    (1024.0 * 2.1e9 * dom_ms * 1e-3),
                       "note": "three float16 split products per tile (hi.hi, hi.lo, lo.hi), scans folded into the "
-                              "tiles: 47 % of the tile entries are structural zeros; the kernel is bound by the vector "
-                              "issue port the matrix instructions share (8 of their 16 cycles), not by the matrix pipe"}
+                              "tiles (a third of the tile entries are structural zeros); one-wave form: the far field rides "
+                              "in a sum slot of the near tiles (no product of its own), split form: one carry tile per block.  "
+                              "The kernel is bound by the issue of one wave per SIMD (the matrix instructions hold the "
+                              "vector issue port for 8 of their 16 cycles) at the package power limit, not by the matrix pipe"}
     alg_bytes = BYTES_PER_VOXEL_ITER_PER_SCAN * N * float(P_dom) * n_iter
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
@@ -517,10 +519,12 @@ def roofline_block(matrix_pipe, kernel, dom_ms, P_dom, n_iter, N, K, flops_launc
                 "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                 "frac_algorithmic": flops_launch / sec / 1e12 / peak,
                 "executed_flops_per_launch": exec_launch}
-        binding = ("issue of ONE wave per SIMD: 993 vector + 276 matrix instructions per 16 voxel-iterations at N = 300 "
-                   "(profiles/r3_pmc_sq.json: 0.63 of the cycles issuing, 0.20 waiting on matrix results; matrix "
-                   "pipe busy 0.55) -- neither HBM nor the MFMA peak; the split form (fista_mfma2_kernel: two waves per "
-                   "16 problems) adds two workgroup barriers per iteration")
+        binding = ("issue of ONE wave per SIMD: 999 vector + 228 matrix instructions per 16 voxel-iterations at N = 300 "
+                   "(profiles/r4_pmc_sq.json: 0.66 of the cycles issuing, 0.14 waiting on matrix results; matrix "
+                   "pipe busy 0.49) at the package power limit -- neither HBM nor the MFMA peak.  Round 4 removed the "
+                   "rank-one far-field products (276 -> 228 matrix instructions): fewer EXECUTED flops in less time, so "
+                   "`frac` fell (0.52 -> 0.48) while the rate rose 7 %; the split form (fista_mfma2_kernel: two waves per "
+                   "16 problems, carry-tile form) adds two workgroup barriers per iteration")
     else:
         ach, peak = flops_launch / sec / 1e12, VALU_FP32_PEAK_TFLOPS
         head = {"bound": "valu_fp32", "pipe": "vector fp32 (v_pk_fma_f32)", "achieved": ach, "peak": peak,
