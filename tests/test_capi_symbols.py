@@ -84,6 +84,10 @@ def test_version_and_dispatch_table(lib):
     assert lib.pb_fista_which_kernel(600, 30, 100000, 1, 2, 4) in (1, 3) # other windows: the exact rule on a vector form
     assert lib.pb_fista_which_kernel(600, 30, 100000, 1, 1, 6) in (1, 3) # the _loops_deconv rule on long series: vector forms
     assert lib.pb_fista_which_kernel(600, 30, 500, 0, 0, 6) in (1, 3)    # few long series: latency-bound forms
+    assert lib.pb_fista_which_kernel(310, 30, 100000, 0, 0, 6) == 4      # ten blocks of 31 samples: the one-wave form ...
+    assert lib.pb_fista_which_kernel(311, 30, 100000, 0, 0, 6) == 5      # ... one scan more: the split form (blocks of 32 samples)
+    assert lib.pb_fista_which_kernel(320, 33, 100000, 0, 0, 6) == 5
+    assert lib.pb_fista_which_kernel(129, 30, 100000, 0, 0, 6) == 4      # five blocks
     assert lib.pb_fista_which_kernel(640, 30, 100000, 0, 0, 6) == 5      # up to 640 scans on the split matrix-pipe form
     assert lib.pb_fista_which_kernel(640, 30, 100000, 1, 0, 6) == 5      # ... with the cost trace too
     assert lib.pb_fista_which_kernel(641, 30, 100000, 0, 0, 6) == 3

@@ -1,7 +1,7 @@
 """A/B of single-pass times: one-wave and split matrix-pipe forms at a few shapes (development aid)."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import pybold_oracle as orc
 from pybold_amd import data, solver
 dev = torch.device("cuda")
