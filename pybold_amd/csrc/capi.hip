@@ -461,6 +461,10 @@ int plan_pieces(int P, bool has_pair, bool has_wide, bool one_launch, bool one_s
 //   beyond                               one more pass of the one-wave form, as before
 constexpr int MFMA2_MIN_R = 4608;
 constexpr int MFMA2_BESIDE_CHUNKS = 2;         // chunks of one one-problem wave per SIMD beside a split-form pass
+// ... for series of ten blocks; shorter series take one chunk at most: a pass of the one-wave form is cheaper for them
+// relative to a chunk (round 4, sum-slot kernel: N = 240, 10 000 problems 1.36 ms as split pass + two chunks against
+// 1.21 ms as one pass of the one-wave form; N = 300: 1.52 against 1.59 -- profiles/r4_split_form_passes.txt)
+inline int beside_chunks_for(int N) { return N > 9 * pb::MFMA_SPAN ? MFMA2_BESIDE_CHUNKS : 1; }
 // Series of 311 .. 640 scans (10 .. 20 blocks) run on the split form from this many problems on (below, the
 // pair form over two slots or the latency-bound one-problem-per-wave form finish first: N = 600, 4 096 problems
 // 1.58 ms against 1.93, 8 192 2.87 against 1.97 -- profiles/r4_split_form_passes.txt); whole passes of 8 192
@@ -472,7 +476,7 @@ int mfma2_long_base(int P, bool one_launch) {
   const int base = (P / pass) * pass;
   return (one_launch || P - base > pass * 5 / 16) ? P : base;
 }
-int plan_pieces_mfma(int P, bool has_pair, bool has_wide, bool one_launch, bool one_stream, bool has_mfma2, Piece* out) {
+int plan_pieces_mfma(int P, bool has_pair, bool has_wide, bool one_launch, bool one_stream, bool has_mfma2, int beside_chunks, Piece* out) {
   const int round = (int)wave_slots() * 8;           // 16 problems x (slots / 2) waves
   const int whole = (P / round) * round;
   const int R = P - whole;
@@ -484,7 +488,7 @@ int plan_pieces_mfma(int P, bool has_pair, bool has_wide, bool one_launch, bool 
       out[n++] = Piece{FORM_MFMA2, whole, P, false, false};
       return n;
     }
-    if (R > half && has_wide && R - half <= (one_stream ? wide_max : MFMA2_BESIDE_CHUNKS * (wide_max / 2))) {
+    if (R > half && has_wide && R - half <= beside_chunks * (wide_max / 2)) {
       // The left-overs as one-problem waves BESIDE the split-form pass, on the side stream: a wave of the N <= 320
       // split form holds 355 registers, ONE 88-register one-problem wave fits next to it on a SIMD and issues in the
       // gaps the pass's barriers leave.  One per SIMD and no more: with two, 355 + 2 x 88 registers no longer fit and
@@ -706,7 +710,7 @@ int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mod
   if (fe && (pair_carries(fe, stop_mode, wind) || stop_mode == PB_STOP_NONE || (stop_mode == PB_STOP_LOOPS && !with_cost_trace)) &&
       pick_mfma(N, K, stop_mode != PB_STOP_NONE)) {   // plain solves, the window-rule certificate, the _loops_deconv rule
     Piece pc[6];
-    plan_pieces_mfma(P, fe->fn_pair != nullptr && stop_mode != PB_STOP_LOOPS, pick_wide_small(N, K) != nullptr, false, false, mfma2_ok, pc);
+    plan_pieces_mfma(P, fe->fn_pair != nullptr && stop_mode != PB_STOP_LOOPS, pick_wide_small(N, K) != nullptr, false, false, mfma2_ok, beside_chunks_for(N), pc);
     return pc[0].form;
   }
   if (fe && stop_mode == PB_STOP_WINDOW && (!ring_wind(wind) || fe->S > 20)) fe = nullptr;
@@ -751,7 +755,7 @@ int pb_fista_plan_ex(int N, int K, int P, int stop_mode, int wind, unsigned flag
              pick_mfma(N, K, stop_mode != PB_STOP_NONE)) {
     Piece pc[6];
     const int npc = plan_pieces_mfma(P, pick_fast(N, K)->fn_pair != nullptr && stop_mode != PB_STOP_LOOPS, pick_wide_small(N, K) != nullptr,
-                                     (flags & PB_FLAG_ONE_LAUNCH) != 0, (flags & PB_FLAG_ONE_STREAM) != 0, mfma2_ok, pc);
+                                     (flags & PB_FLAG_ONE_LAUNCH) != 0, (flags & PB_FLAG_ONE_STREAM) != 0, mfma2_ok, beside_chunks_for(N), pc);
     int i = 1;
     while (i < npc && pc[i].form == pc[0].form) ++i;
     if (i < npc) {
@@ -997,7 +1001,7 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
     const bool one_stream = (flags & PB_FLAG_ONE_STREAM) != 0 || stream_is_capturing((hipStream_t)stream);
     const int npc = mfma ? plan_pieces_mfma(P, pair_ok, pick_wide_small(N, K) != nullptr,
                                             (flags & PB_FLAG_ONE_LAUNCH) != 0, one_stream,
-                                            mfma2 != nullptr && (stop_mode == PB_STOP_NONE || mfma_cert), pc)
+                                            mfma2 != nullptr && (stop_mode == PB_STOP_NONE || mfma_cert), beside_chunks_for(N), pc)
                          : plan_pieces(P, pair_ok, pick_wide_small(N, K) != nullptr,
                                        (flags & PB_FLAG_ONE_LAUNCH) != 0, one_stream, pc);
     bool any_side = false;
