@@ -134,6 +134,7 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
   float ysn[NBW][8];
   double w[NBW][8];
   float sigma = 1.0f, inv_sigma = 1.0f;
+  bool degenerate = false;                         // an all-zero series with a warm start: no scale to work at (fista_mfma.h)
   {
     const float* yrow = a.y + (int64_t)(p / a.y_rep) * a.ldy;
     float m = 0.0f;
@@ -168,6 +169,7 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
       const float sg = ldexpf(1.0f, a.ybits - e) / y_scale, isg = ldexpf(1.0f, e - a.ybits) * y_scale;
       sigma = okm ? sg : 1.0f;
       inv_sigma = okm ? isg : 1.0f;
+      degenerate = !okm && !a.cold;                // (the same in both waves: m is the maximum over the whole series)
     }
     const float ys = -sigma * y_scale;
     const double* wrow = a.w + (int64_t)p * a.ldw;
@@ -504,7 +506,7 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
     guard = (guard < 60000.0f && go < 60000.0f) ? fmaxf(guard, go) : 65504.0f;      // NaN on either side: out of range
     wlast = fmaxf(wlast, wo);
   }
-  const bool bad = !(guard < 60000.0f) || (a.rho_guard && wlast > 0.0f && (float)th > MFMA_RHO_MAX * wlast) || (CERT && cflag);
+  const bool bad = !(guard < 60000.0f) || degenerate || (a.rho_guard && wlast > 0.0f && (float)th > MFMA_RHO_MAX * wlast) || (CERT && cflag);
   if (live && !bad) {
     double* wrow = a.w + (int64_t)p * a.ldw;
 #pragma unroll
