@@ -546,7 +546,7 @@ def roofline_block(matrix_pipe, kernel, dom_ms, P_dom, n_iter, N, K, flops_launc
                 "multi-iteration kernel: a launch reads y once and writes w once (`traffic`), so SURVEY 8d's "
                 "algorithmic-byte rate exceeds the HBM peak (hbm_algorithmic_frac > 1 is not a utilisation figure).  "
                 "The peaks assume 2.4 GHz; under these kernels the package sits at its power limit and the shader clock "
-                "at 2.04-2.20 GHz (profiles/r2_clock_and_power_during_solve.txt)."})
+                "at 2.04-2.33 GHz depending on the box (profiles/r4_clock_and_power_during_solve.txt)."})
     head.update(extra)
     return head
 
