@@ -404,6 +404,7 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
            : part == 1 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(A.hi, B.lo, acc, 0, 0, 0)
                        : __builtin_amdgcn_mfma_f32_16x16x32_f16(A.lo, B.hi, acc, 0, 0, 0);
   };
+  Frag rlast;                                    // residual fragment of the last block, forward pass -> adjoint pass
   // two float32 -> float16 hi / lo as split_pair, and what the split drops of x1: rem = x1 - hi - lo (exact)
   auto split_pair_rem = [](float x0, float x1, unsigned& hi, unsigned& lo, float& rem) __attribute__((always_inline)) {
     hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
@@ -464,6 +465,10 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
         // it wrote: no barrier); in registers they would cost 80 accumulator-file copies per iteration
         lrf[(2 * q) * 64] = u4{rh[q][0], rh[q][1], rh[q][2], rh[q][3]};
         lrf[(2 * q + 1) * 64] = u4{rl[q][0], rl[q][1], rl[q][2], rl[q][3]};
+        if constexpr (q == NB - 1) {                // the adjoint pass starts with this block: it takes the fragment as it is
+          rlast.hi = __builtin_bit_cast(h8, u4{rh[q][0], rh[q][1], rh[q][2], rh[q][3]});      // (no LDS round trip at the turn of the passes)
+          rlast.lo = __builtin_bit_cast(h8, u4{rl[q][0], rl[q][1], rl[q][2], rl[q][3]});
+        }
       }
     };
     static_for<0, 4>([&](auto pc) { prep_pair(std::integral_constant<int, 0>{}, pc); });
@@ -548,7 +553,7 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
         cw = (g == gq) ? w[q][j] : cw;
       }
     };
-    fetch(std::integral_constant<int, NB - 1>{});
+    rf[NB - 1] = rlast;                             // (the last block's fragment never left the registers)
     static_for<0, NB>([&](auto qq) {
       constexpr int q = NB - 1 - decltype(qq)::value;
       constexpr int omax = (NT - 1 < NB - 1 - q) ? NT - 1 : NB - 1 - q;     // the oldest tile this block has
@@ -576,11 +581,12 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
           if constexpr (q + 1 < NB) patch(std::integral_constant<int, q>{});
         } else if constexpr (sl >= 4 && sl < 9) {
           if constexpr (q + 1 < NB) update(std::integral_constant<int, q + 1>{}, std::integral_constant<int, sl - 4>{});
+        } else if constexpr (sl >= 9 && sl < 12) {   // (the last block of the pass has no block behind it to wait for)
+          if constexpr (q == 0 && NB >= 2) update(std::integral_constant<int, 1>{}, std::integral_constant<int, sl - 4>{});
         }
         if constexpr ((sl % PB_MFMA_SBK) == PB_MFMA_SBK - 1) PB_MFMA_SB;
       });
     });
-    if constexpr (NB >= 2) static_for<5, 8>([&](auto jc) { update(std::integral_constant<int, 1>{}, jc); });
     static_for<0, 8>([&](auto jc) { update(std::integral_constant<int, 0>{}, jc); });
     if constexpr (CERT) {
       // the window combination on this lane's tracked sample (see fista_pair_ffa.h): float32 from
