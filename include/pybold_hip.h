@@ -324,7 +324,11 @@ int pb_spm_hrf(const double* deltas_dev, int M, const double* t_dev, int K,
  * (pybold/bold_signal.py:217-222, :329-333).
  *
  * pb_fista_solve_d    pb_fista_solve in float64 end to end: y float64, cost trace J float64
- *                     [P][ldj].  Register-resident kernel (one problem per wave,
+ *                     [P][ldj].  The only entry point that takes NEGATIVE lambdas: the reference's
+ *                     noise-driven search (pybold/bold_signal.py:141-145) drives alpha, hence
+ *                     lambda = 1 / (2 alpha), below zero, and `sign(u) max(|u| - th, 0)` (:66) then
+ *                     GROWS every non-zero entry by |th|; these kernels restate that expression,
+ *                     the float32-y kernels clamp (pb_fista_solve rejects a negative scalar lbda).  Register-resident kernel (one problem per wave,
  *                     fista_exact_kernel) for series of up to 640 scans with HRFs of up to
  *                     32 taps when taps_host is given (window rule: wind = 6); otherwise, or
  *                     with PB_FLAG_FORCE_GENERIC, the any-size LDS kernel, which reads the taps

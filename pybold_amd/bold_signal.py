@@ -187,6 +187,12 @@ def _deconv_auto_lbda(y, hrf, early_stopping, tol, wind, nb_iter, nb_sub_iter, v
     J, R, G = [], [], []
     W = torch.zeros((V, n), dtype=torch.float64, device=dev)
     for i in range(nb_iter):
+        if Y.dtype != torch.float64 and (lbda < 0).any():
+            # alpha -- hence lambda -- went negative (it does in the reference's default call on the golden
+            # series); :66 then grows every entry, which only the float64 kernels restate
+            solver.warn_once("auto-lambda-negative", "deconv(lbda=None): the search drove lambda below zero; the batch "
+                             "continues on the all-float64 kernel, which takes the reference's prox for it")
+            Y = Y.double()
         W_new, _, _ = solver.fista_solve(Y, hrf, lbda, step, int(nb_sub_iter), W0=W, stop=stop,
                                          tol=tol, wind=wind)
         if active.all():
@@ -216,6 +222,8 @@ def _deconv_auto_lbda(y, hrf, early_stopping, tol, wind, nb_iter, nb_sub_iter, v
             active &= ~(diff < tol)
             if not active.any():
                 break
+    if Y.dtype != torch.float64 and (lbda < 0).any():
+        Y = Y.double()
     W, _, _ = solver.fista_solve(Y, hrf, lbda, step, int(nb_sub_iter), W0=W, stop=stop, tol=tol,
                                  wind=wind)
     X, Z = solver.fista_outputs(W, hrf)

@@ -812,6 +812,9 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
   if (ldy < N || ldw < N) return fail(PB_ERR_INVALID, "pb_fista_solve: leading dimension < N");
   if (J_dev && ldj < n_iter) return fail(PB_ERR_INVALID, "pb_fista_solve: ldj < n_iter");
   if (!(step > 0.0)) return fail(PB_ERR_INVALID, "pb_fista_solve: step must be positive");
+  // the reference's prox with a negative threshold grows every entry (its lambda search gets there); only
+  // pb_fista_solve_d restates that -- these kernels clamp
+  if (!lbda_dev && lbda < 0.0) return fail(PB_ERR_INVALID, "pb_fista_solve: negative lbda (float64 entry point only)");
   if (stop_mode < PB_STOP_NONE || stop_mode > PB_STOP_WINDOW)
     return fail(PB_ERR_INVALID, "pb_fista_solve: unknown stop_mode %d", stop_mode);
   if (stop_mode == PB_STOP_WINDOW && wind < 2)

@@ -18,6 +18,16 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
+// d = u - prox(u), the prox written as pybold/bold_signal.py:66 writes it: sign(u) * max(|u| - th, 0).
+// th >= 0: the clamp every kernel uses.  th < 0: the noise-driven lambda search (:141-145) lets alpha -- hence
+// lambda = 1 / (2 alpha) -- go NEGATIVE (it does in the reference's default call on the golden series), and the
+// reference's expression then GROWS every entry by |th| (sign(0) = 0 keeps zeros).  Only the float64 kernels
+// (that search runs on them) reproduce this; th is uniform over the problem's lanes: a scalar branch.
+__device__ __forceinline__ double prox_excess_ref(double u, double th) {
+  if (th >= 0.0) return fmin(fmax(u, -th), th);
+  return u > 0.0 ? th : (u < 0.0 ? -th : 0.0);
+}
+
 // DPP controls (wave64, rows of 16 lanes).  Out-of-row source lanes read 0
 // (bound_ctrl), which is exactly the causal zero padding of the Toeplitz
 // operator and the identity of the scans.

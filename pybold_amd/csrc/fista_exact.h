@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void fista_exact_kernel(FistaArgs a, TapsD<KT>
 #pragma unroll
       for (int j = 0; j < S; ++j) {
         const double u = fma(nstep, g[j], w[j]);
-        const double d = fmin(fmax(u, -th), th);
+        const double d = prox_excess_ref(u, th);
         w[j] = fma(nb1, d, u);
       }
     } else {
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void fista_exact_kernel(FistaArgs a, TapsD<KT>
 #pragma unroll
       for (int j = 0; j < S; ++j) {
         const double u = fma(nstep, g[j], w[j]);
-        const double d = fmin(fmax(u, -th), th);
+        const double d = prox_excess_ref(u, th);
         const double wn = fma(nb1, d, u);
         if constexpr (STOP == 1) {            // _loops_deconv rule (pybold/bold_signal.py:267-273)
           const double diff = wn - u;

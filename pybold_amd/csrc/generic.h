@@ -500,7 +500,7 @@ __global__ __launch_bounds__(GEN_THREADS) void fista_generic_kernel(FistaArgs a_
     double num = 0.0, den = 0.0;
     for (int i = threadIdx.x; i < N; i += GEN_THREADS) {
       const double u = fma(-stp, a[i], w[i]);
-      const double d = fmin(fmax(u, -th), th);
+      const double d = prox_excess_ref(u, th);
       const double wn = fma(nb1, d, u);
       w[i] = wn;
       if (stop == 1) {

@@ -230,6 +230,10 @@ def fista_solve(Y, hrf, lbda, step, n_iter, W0=None, want_J=False, stop=None,
             raise ValueError("W0 must be %s, got %s" % ((P, N), tuple(W.shape)))
     lbda_dev = None
     lbda_scalar = 0.0
+    if not f64 and not (torch.is_tensor(lbda) and lbda.is_cuda) and (np.asarray(lbda) < 0).any():
+        # pybold/bold_signal.py:66 with a negative threshold GROWS every entry (its lambda search gets there,
+        # :141-145); only the float64 kernels restate that expression, the float32-FIR kernels clamp
+        raise ValueError("negative lbda: only the float64 path (float64 Y) reproduces the reference's prox for it")
     if np.ndim(lbda) == 0 and not torch.is_tensor(lbda):
         lbda_scalar = float(lbda)
     else:
