@@ -113,8 +113,8 @@ int oracle_fista_batch(const double* Y, int V, int N, const double* h, int K, do
 }
 
 /* ---- deconv(lbda=None): noise-driven lambda search (pybold/bold_signal.py:99-214) --------
- * C form of oracle/pybold_oracle.py::deconv_auto_lbda (UNPINNED like it: the reference
- * branch needs PyWavelets).  Inner solve = the fixed-lambda recurrence WITHOUT cost trace,
+ * C form of oracle/pybold_oracle.py::deconv_auto_lbda (pinned like it since round 5: the
+ * reference's own branch run with sigma injected, tests/golden/auto_lbda.npz).  Inner solve = the fixed-lambda recurrence WITHOUT cost trace,
  * t restarted, warm-started, windowed stop on the stored iterates [u_{k-wind+2} .. u_k,
  * w_{k+1}] (:125-138; the aliasing of :65/:72 is why all but the newest entry are gradient
  * points).  Outer loop: alpha += mu (||x - y||^2 - N sigma^2), lbda = 1/(2 alpha) (:141-145),

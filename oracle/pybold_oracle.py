@@ -8,9 +8,13 @@ the HIP library behind ``include/pybold_hip.h``.
 Parity status: PINNED.  Every function below is checked in
 ``tests/test_oracle_golden.py`` against fixtures under ``tests/golden/`` that
 were produced by importing the real reference (``/root/reference``) in the
-build container with ``tests/golden/make_golden.py``.  Two parts of the
-reference could not be executed there and are therefore *unpinned*:
-``deconv(lbda=None)`` (needs ``pywt``) and true Numba code generation for
+build container with ``tests/golden/make_golden.py`` (``_r2``, ``_r5``).  Two
+things could not be executed there and are therefore *unpinned*: the noise
+estimate ``mad_daub_noise_est`` (needs ``pywt``; the ``deconv(lbda=None)``
+branch that calls it IS pinned since round 5 -- the reference's own loop run
+with that one scalar injected, ``tests/golden/auto_lbda.npz``: alpha / lambda
+updates incl. negative lambdas, warm-started inner solves, both stop windows,
+the default 1000 x 1000 call) and true Numba code generation for
 ``_loops_deconv`` (its body was executed as plain NumPy).
 
 All ``file:line`` citations are relative to the reference checkout.
@@ -438,7 +442,7 @@ def bd(y, t_r, lbda=1.0, theta_0=None, z_0=None, hrf_dur=20.0, bounds=None,
 
 
 # --------------------------------------------------------------------------
-# noise-driven lambda search (deconv with lbda=None)  -- UNPINNED
+# noise-driven lambda search (deconv with lbda=None)  -- pinned with sigma injected; the db3 estimate itself UNPINNED
 # --------------------------------------------------------------------------
 # db3 decomposition high-pass filter (PyWavelets' Wavelet('db3').dec_hi)
 DB3_DEC_HI = np.array([-0.3326705529509569, 0.8068915093133388, -0.4598775021193313,
@@ -496,7 +500,9 @@ def deconv_auto_lbda(y, hrf, sigma, lipschitz, early_stopping=True, tol=1.0e-6, 
     ``alpha += mu (||x - y||^2 - N sigma^2)``, ``lbda = 1 / (2 alpha)`` (:141-145)
     around warm-started inner solves, windowed stop on ``alpha`` (:164-178), final
     inner solve (:181-209).  Returns ``(x, z, w, J, R, G)`` as lists like the
-    reference.  UNPINNED (the reference branch needs pywt and could not be run)."""
+    reference.  Pinned: 108 runs of the reference's own branch with ``sigma`` injected
+    (tests/golden/auto_lbda.npz), <= 1e-10 (one default run that drives alpha through 7e-4:
+    over the outer iterations before that)."""
     y = np.asarray(y, dtype=np.float64)
     n = len(y)
     hrf = np.asarray(hrf, dtype=np.float64)

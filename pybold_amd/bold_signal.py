@@ -16,9 +16,10 @@ Deviations from the reference, all deliberate:
     does at :261; every caller rebinds the returned array);
   * ``deconv(lbda=None)`` (noise-driven lambda search, :99-214) estimates the
     noise level with an in-package db3 detail band instead of PyWavelets
-    (``utils.mad_daub_noise_est``; parity of that estimate is unpinned); with early
-    stopping it computes in float64 end to end, batches included (see
-    ``_deconv_auto_lbda``).
+    (``utils.mad_daub_noise_est``; parity of that estimate is unpinned -- everything
+    else of the branch is pinned against the reference with the estimate injected,
+    tests/golden/auto_lbda.npz); it computes in float64 end to end, batches included
+    (see ``_deconv_auto_lbda``).
 There is no CPU fallback: without the HIP library or a GPU these raise.
 """
 import os
@@ -153,20 +154,21 @@ def _deconv_auto_lbda(y, hrf, early_stopping, tol, wind, nb_iter, nb_sub_iter, v
     y_host = y.detach().cpu().numpy() if torch.is_tensor(y) else np.asarray(y, dtype=np.float64)
     sigma = np.atleast_1d(mad_daub_noise_est(y_host))
     Y, one_d = _y_to_device(y)
-    if early_stopping and Y.dtype != torch.float64:
+    if Y.dtype != torch.float64:
         if Y.shape[0] >= 1024:
             solver.warn_once("auto-lambda-f64",
-                             "deconv(lbda=None, early_stopping=True) on %d voxels runs on the all-float64 kernel "
-                             "(one problem per wave, ~3x slower than the float32-FIR batch kernels; the LDS kernel "
-                             "beyond 640 scans / 32 taps): its stop decisions sit on a rounding knife edge. "
-                             "early_stopping=False keeps the batch kernels." % Y.shape[0])
-        # The inner window rule compares iterates with gradient points (the aliasing of
-        # :65/:72), so its criterion tends to a CONSTANT proportional to lambda instead of 0;
-        # the lambda search drives lambda down until that constant crosses `tol`, i.e. the
-        # decision "stop the inner solve after 8 iterations or run all of them" sits on a
-        # knife edge where the 1e-7 rounding of the float32-FIR kernels flips it (measured:
-        # whole trajectories diverge).  This branch therefore runs on the all-float64 kernel
-        # (one workgroup per voxel), which takes the reference's decisions.
+                             "deconv(lbda=None) on %d voxels runs on the all-float64 kernel (one problem per wave, ~3x "
+                             "slower than the float32-FIR batch kernels; the LDS kernel beyond 640 scans / 32 taps): "
+                             "the decisions of this branch sit on rounding knife edges." % Y.shape[0])
+        # Two knife edges (both pinned against the reference: tests/golden/auto_lbda.npz).  (1) The inner window rule
+        # compares iterates with gradient points (the aliasing of :65/:72), so its criterion tends to a CONSTANT
+        # proportional to lambda instead of 0; the search drives lambda down until that constant crosses `tol`, i.e.
+        # "stop the inner solve after 8 iterations or run all of them" flips on the 1e-7 rounding of the float32-FIR
+        # kernels (measured: whole trajectories diverge).  (2) alpha -- hence lambda = 1/(2 alpha) -- goes NEGATIVE
+        # in the reference (:141-145; it does in its default call on the golden series) and :66 with a negative
+        # threshold is discontinuous at 0: sign(u) |th|.  The reference keeps the last sample of diff_z EXACTLY 0
+        # (h[0] = 0); a float32 residue there is blown up to |th| per iteration.  So the whole branch runs on the
+        # float64 kernels, which restate :66 and keep that zero (fista_exact.h, generic.h), batches included.
         if torch.is_tensor(y) and y.is_cuda:                 # already on the device: widen there
             Y = Y.double() if y.dtype != torch.float64 else torch.atleast_2d(y).contiguous()
         else:
@@ -187,12 +189,6 @@ def _deconv_auto_lbda(y, hrf, early_stopping, tol, wind, nb_iter, nb_sub_iter, v
     J, R, G = [], [], []
     W = torch.zeros((V, n), dtype=torch.float64, device=dev)
     for i in range(nb_iter):
-        if Y.dtype != torch.float64 and (lbda < 0).any():
-            # alpha -- hence lambda -- went negative (it does in the reference's default call on the golden
-            # series); :66 then grows every entry, which only the float64 kernels restate
-            solver.warn_once("auto-lambda-negative", "deconv(lbda=None): the search drove lambda below zero; the batch "
-                             "continues on the all-float64 kernel, which takes the reference's prox for it")
-            Y = Y.double()
         W_new, _, _ = solver.fista_solve(Y, hrf, lbda, step, int(nb_sub_iter), W0=W, stop=stop,
                                          tol=tol, wind=wind)
         if active.all():
@@ -222,8 +218,6 @@ def _deconv_auto_lbda(y, hrf, early_stopping, tol, wind, nb_iter, nb_sub_iter, v
             active &= ~(diff < tol)
             if not active.any():
                 break
-    if Y.dtype != torch.float64 and (lbda < 0).any():
-        Y = Y.double()
     W, _, _ = solver.fista_solve(Y, hrf, lbda, step, int(nb_sub_iter), W0=W, stop=stop, tol=tol,
                                  wind=wind)
     X, Z = solver.fista_outputs(W, hrf)

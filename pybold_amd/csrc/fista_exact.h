@@ -56,6 +56,26 @@ __device__ __forceinline__ double wave_prefix_incl_f64(double t) {
   return t;
 }
 
+__device__ __forceinline__ double readlane_f64(double v, int lane);
+
+// sum over the lanes ABOVE this one, built from additions only (in-row suffix scan + the totals of the rows above):
+// where every lane above holds 0 the result is EXACTLY 0, as in the reference's flip-cumsum-flip
+// (pybold/linear.py:43).  `total - inclusive prefix` leaves a rounding residue of ~1e-16 |total| there instead, and
+// the last sample of a series has gradient exactly 0 (every SPM HRF has h[0] = 0): with a NEGATIVE threshold the
+// reference's prox is discontinuous at 0 (sign(u) |th|), so that residue grew into a 1e-3 error (round 5).
+__device__ __forceinline__ double wave_suffix_excl_f64(double v) {
+  double s = v;
+  s += dpp_f64<DPP_ROW_SHL + 1>(s);
+  s += dpp_f64<DPP_ROW_SHL + 2>(s);
+  s += dpp_f64<DPP_ROW_SHL + 4>(s);
+  s += dpp_f64<DPP_ROW_SHL + 8>(s);                 // lane 0 of a row: the row's total
+  const double t3 = readlane_f64(s, 48), t2 = readlane_f64(s, 32), t1 = readlane_f64(s, 16);
+  const int row = (threadIdx.x & 63) >> 4;
+  const double t23 = t2 + t3;
+  const double above = row == 3 ? 0.0 : (row == 2 ? t3 : (row == 1 ? t23 : t1 + t23));
+  return dpp_f64<DPP_ROW_SHL + 1>(s) + above;        // lanes above within the row (0 for the row's last lane) + rows above
+}
+
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
   const long long b = __builtin_bit_cast(long long, v);
   const int lo = __builtin_amdgcn_readlane((int)b, lane);
@@ -193,8 +213,7 @@ __global__ __launch_bounds__(256) void fista_exact_kernel(FistaArgs a, TapsD<KT>
 #pragma unroll
     for (int j = S - 2; j >= 0; --j) g[j] += g[j + 1];
     {
-      const double incl = wave_prefix_incl_f64(g[0]);
-      const double off = readlane_f64(incl, 63) - incl;      // sum of the lanes above
+      const double off = wave_suffix_excl_f64(g[0]);         // sum of the lanes above, exactly 0 above the last sample
 #pragma unroll
       for (int j = 0; j < S; ++j) g[j] += off;
     }
