@@ -66,6 +66,9 @@ extern "C" {
                                      161..640 scans, HRFs of up to 33 taps, plain solves), one launch */
 #define PB_FLAG_NO_MFMA 8192u      /* plain solves: never the matrix-pipe form (fista_mfma_kernel), vector forms only */
 #define PB_FLAG_FORCE_CERT 1024u   /* PB_STOP_WINDOW, wind = 6: certificate path whatever tol * n_iter is */
+#define PB_FLAG_NO_PARTITION 4096u  /* never partition a call on the device (see pb_fista_solve_ex): the host-side plan of round 4 */
+#define PB_FLAG_ONLY_DENSE 131072u  /* measurement aids for a partitioned call: only the dense class / only the sparse */
+#define PB_FLAG_ONLY_SPARSE 262144u /*   class is solved; the other class's rows of w and n_done are left untouched */
 #define PB_FLAG_ONE_LAUNCH 32u    /* never split a plain solve into a full-rounds launch and a
                                      remainder launch (see pb_fista_solve) */
 
@@ -190,6 +193,50 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep,
                    unsigned flags, void* stream);
 
 /*
+ * pb_fista_solve with the caller's workspace: the call that NEVER solves a problem twice (round 5).
+ *
+ * The matrix-pipe form (b) holds eps only where the solution is dense (threshold <= 0.02 max|w|, see above); for a
+ * lambda near lambda_max,v = || H^T y_v ||_inf it used to be solved on (b), handed back and solved again on (a), one
+ * handed-back problem per wave -- slower than never using (b) (profiles/r4_path_partition.txt).  Since round 5 every
+ * call that (b) can carry (129..310 scans; plain, cost trace, window-rule certificate, _loops_deconv rule; ONE lambda or
+ * one per problem) is PARTITIONED ON THE DEVICE before it is solved, without a host synchronisation:
+ *     lbda_p < dense_ratio * lmax[p / y_rep]    -> dense class:  matrix-pipe form (b)
+ *     otherwise                                 -> sparse class: float32 vector forms (a)
+ * (lmax = pb_lambda_max of every series: lmax_dev if the caller has it -- a regularisation path does --, else one extra
+ * pass over y, ~0.05 ms per 100 k series).  Three small launches build two order-preserving index lists in work_dev; a
+ * one-thread kernel turns their lengths into the launch plans pb_fista_plan would give a call of that many problems
+ * (csrc/plan.h: the same functions compiled for the device); every kernel form is then launched with a worst-case
+ * grid and reads the slots it solves from device memory -- the waves of an empty launch leave at once.  What a guard
+ * or certificate still hands back (n_done = -1) is compacted the same way and re-solved by the exact vector forms at
+ * full occupancy.  Results, n_done and J are those of pb_fista_solve; the call allocates nothing.
+ *
+ * work_dev    int32 scratch of at least pb_fista_work_len(P, y_rep) entries, 8-byte aligned (contents meaningless
+ *             afterwards); NULL or too small: no partition (the plan of pb_fista_solve with PB_FLAG_NO_PARTITION).
+ * lmax_dev    float64 [ceil(P / y_rep)] or NULL.       dense_ratio <= 0: PB_PATH_DENSE_RATIO.
+ * pb_fista_solve itself partitions too, on a workspace of the library's own (one per device and stream, grown on
+ * demand with hipMalloc -- the one allocation this library makes; never under stream capture, where it runs unpartitioned).
+ * Calls of fewer than 4 096 problems, shapes outside form (b), PB_FLAG_FORCE_* / _ONE_LAUNCH / _NO_PARTITION: the
+ * host-side plan as before.
+ */
+int64_t pb_fista_work_len(int P, int y_rep);
+/* Host-only query: the device-side plan of a LIST of n problems (kind 1: a dense class, matrix-pipe form + vector
+ * remainder; kind 2: vector forms only) as the slots [ranges[2c], ranges[2c+1]) of each of the PB_CAND_COUNT candidate
+ * launches (csrc/plan.h: MFMA, PAIR0, FAST0 | fork | MFMA2, PAIR1, FAST1, WIDE | side stream: WIDE0, WIDE1, FAST), and
+ * the grid bound of each candidate for lists of at most n_max problems.  The same functions run on the device. */
+#define PB_CAND_COUNT 10
+int pb_fista_list_plan(int kind, int n, int n_max, int has_pair, int has_wide, int one_stream, int has_mfma2,
+                       int beside_chunks, int32_t* ranges, int32_t* bounds);
+int pb_fista_solve_ex(const float* y_dev, int64_t ldy, int y_rep,
+                      double* w_dev, int64_t ldw, int P, int N,
+                      const double* taps_host, const double* taps_dev, int K,
+                      double step, double lbda, const double* lbda_dev,
+                      const double* betas_dev, int n_iter,
+                      float* J_dev, int64_t ldj,
+                      int stop_mode, double tol, int wind, int32_t* n_done_dev,
+                      unsigned flags, void* stream,
+                      const double* lmax_dev, double dense_ratio, int32_t* work_dev, int64_t work_len);
+
+/*
  * Regularisation path: P = V * y_rep problems (voxel v, lambda_{v,i}), lbda_dev[p] the lambda of problem p, all
  * lambdas of a voxel sharing its series (row p / y_rep of y_dev).  The reference has no such routine: its lambda
  * lists are hard-coded "already grid-search" values (examples/icassp_2019/simulation.py:113-114,
@@ -204,6 +251,7 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep,
  * guard hands back 0.3 % of the problems at lambda / lambda_max = 0.11, 5 % at 0.14, 24 % at 0.18, 62 % at 0.23).  work_dev: int32 scratch of at least pb_fista_path_work_len(P)
  * entries (index lists and counts; contents meaningless afterwards).  lmax_dev == NULL, work_dev == NULL or a
  * shape outside the matrix-pipe form (129..310 scans, <= 33 taps): the call is pb_fista_solve with lbda_dev.
+ * (Round 5: = pb_fista_solve_ex with lbda_dev, no cost trace, no stop rule; kept for callers of round 4.)
  */
 #define PB_PATH_DENSE_RATIO 0.13
 int64_t pb_fista_path_work_len(int P);

@@ -23,10 +23,13 @@ PB_FLAG_COLD_START = 256
 PB_FLAG_NO_CERT = 512
 PB_FLAG_FORCE_CERT = 1024
 PB_FLAG_CERT_NO_RESOLVE = 2048
+PB_FLAG_NO_PARTITION = 4096
 PB_FLAG_NO_MFMA = 8192
 PB_FLAG_FORCE_MFMA = 16384
 PB_FLAG_NO_RHO_GUARD = 32768
 PB_FLAG_FORCE_MFMA2 = 65536
+PB_FLAG_ONLY_DENSE = 131072
+PB_FLAG_ONLY_SPARSE = 262144
 PB_STOP_NONE = 0
 PB_STOP_LOOPS = 1
 PB_STOP_WINDOW = 2
@@ -54,6 +57,18 @@ SIGNATURES = {
         _ptr, _c_i64,                    # J_dev, ldj
         _c_int, _c_dbl, _c_int, _ptr,    # stop_mode, tol, wind, n_done_dev
         ctypes.c_uint, _ptr]),           # flags, stream
+    "pb_fista_work_len": (_c_i64, [_c_int, _c_int]),
+    "pb_fista_list_plan": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _ptr, _ptr]),
+    "pb_fista_solve_ex": (_c_int, [
+        _ptr, _c_i64, _c_int,            # y_dev, ldy, y_rep
+        _ptr, _c_i64, _c_int, _c_int,    # w_dev, ldw, P, N
+        _ptr, _ptr, _c_int,              # taps_host, taps_dev, K
+        _c_dbl, _c_dbl, _ptr,            # step, lbda, lbda_dev
+        _ptr, _c_int,                    # betas_dev, n_iter
+        _ptr, _c_i64,                    # J_dev, ldj
+        _c_int, _c_dbl, _c_int, _ptr,    # stop_mode, tol, wind, n_done_dev
+        ctypes.c_uint, _ptr,             # flags, stream
+        _ptr, _c_dbl, _ptr, _c_i64]),    # lmax_dev, dense_ratio, work_dev, work_len
     "pb_fista_path_work_len": (_c_i64, [_c_int]),
     "pb_fista_solve_path": (_c_int, [
         _ptr, _c_i64, _c_int,            # y_dev, ldy, y_rep

@@ -254,24 +254,10 @@ int mfma_wide_base(int P, bool one_launch) {
   return (one_launch || P - base > round / 4) ? P : base;
 }
 
-// ---- dispatch of a plain solve (no stop rule) over the register-resident forms --------
-// All forms keep two waves per SIMD and are VALU-issue bound, so a launch costs "rounds":
-// waves / (CUs x 4 SIMDs x 2), a last partial round at most half full costing ~0.56 of a
-// round (its waves run alone on their SIMDs), a fuller one a whole round, plus a fixed
-// ~0.03-0.05 for launch, prologue and epilogue.  Unit = one full round of the pair kernel
-// (16 384 problems, ~2.73 ms for 500 iterations of N = 300, K = 30 on MI355X).  Measured
-// (tools/ab_forms.py, profiles/r2_ab_forms.txt):
-//   pair   8 problems per wave   1.00 per round (2-parallel fast FIRs)
-//   fast1  4 problems per wave   0.63 per round of half as many problems
-//   wide   1 problem  per wave   0.19 per round of an eighth as many (short series only)
-// A problem count that is not a whole number of rounds is therefore split: whole rounds on
-// the pair (or single-row) kernel, the remainder on whichever form finishes it first, as a
-// second launch on the same stream (the first launch ends with every SIMD draining at once,
-// so running the remainder after it costs what overlapping would) -- or, when the remainder
-// exceeds half a round of pair waves, as a concurrent group (plan_pieces below).
-constexpr double COST_FAST1 = 0.63, COST_WIDE = 0.19, COST_PARTIAL = 0.56;
-constexpr double COST_LAUNCH = 0.03, COST_LAUNCH_WIDE = 0.05;
-enum Form { FORM_GENERIC = 0, FORM_FAST1 = 1, FORM_PAIR = 2, FORM_WIDE = 3, FORM_MFMA = 4, FORM_MFMA2 = 5 };
+// ---- launch plans: plan.h (host + device); here the host-side wrappers with this device's wave slots --------
+using pb::Piece; using pb::Plan;
+using pb::FORM_GENERIC; using pb::FORM_FAST1; using pb::FORM_PAIR; using pb::FORM_WIDE; using pb::FORM_MFMA; using pb::FORM_MFMA2;
+using pb::MFMA2_MIN_R; using pb::MFMA2_BESIDE_CHUNKS;
 
 double wave_slots() {
   static const double slots = [] {
@@ -283,55 +269,8 @@ double wave_slots() {
   }();
   return slots;
 }
-
-int problems_per_wave(int form) { return form == FORM_PAIR ? 8 : (form == FORM_FAST1 ? 4 : 1); }
-
-double form_cost(int form, int P) {
-  const double unit = form == FORM_PAIR ? 1.0 : (form == FORM_FAST1 ? COST_FAST1 : COST_WIDE);
-  const double r = std::ceil((double)P / problems_per_wave(form)) / wave_slots();
-  const double whole = std::floor(r), part = r - whole;
-  return (form == FORM_WIDE ? COST_LAUNCH_WIDE : COST_LAUNCH) +
-         unit * (whole + (part == 0.0 ? 0.0 : (part <= 0.5 ? COST_PARTIAL : 1.0)));
-}
-
-// cheapest single form for P problems among those available
-int best_form(int P, bool has_pair, bool has_wide, double* cost = nullptr) {
-  int best = FORM_FAST1;
-  double c = form_cost(FORM_FAST1, P);
-  if (has_pair && P >= 2 && form_cost(FORM_PAIR, P) < c) { best = FORM_PAIR; c = form_cost(FORM_PAIR, P); }
-  if (has_wide && form_cost(FORM_WIDE, P) < c) { best = FORM_WIDE; c = form_cost(FORM_WIDE, P); }
-  if (cost) *cost = c;
-  return best;
-}
-
-struct Plan {          // problems [0, n_main) on `main_form`, [n_main, P) on `tail_form`
-  int n_main;
-  int main_form;
-  int tail_form;
-};
-
-Plan plan_plain(int P, bool has_pair, bool has_wide, bool one_launch) {
-  double c_best;
-  Plan best{0, FORM_GENERIC, best_form(P, has_pair, has_wide, &c_best)};
-  if (one_launch) return best;
-  for (int main_form : {FORM_PAIR, FORM_FAST1}) {
-    if (main_form == FORM_PAIR && !has_pair) continue;
-    // main launch = a whole number of rounds, or of half rounds (every wave alone on its SIMD)
-    const int half = (int)wave_slots() * problems_per_wave(main_form) / 2;
-    for (int unit : {2 * half, half}) {
-      const int n_main = (P / unit) * unit;
-      if (n_main == 0 || n_main == P) continue;
-      double c_tail;
-      const int tail = best_form(P - n_main, has_pair, has_wide, &c_tail);
-      const double c = form_cost(main_form, n_main) + c_tail;
-      if (c < c_best) {
-        c_best = c;
-        best = Plan{n_main, main_form, tail};
-      }
-    }
-  }
-  return best;
-}
+int best_form(int P, bool has_pair, bool has_wide, double* cost = nullptr) { return pb::best_form(P, has_pair, has_wide, wave_slots(), cost); }
+Plan plan_plain(int P, bool has_pair, bool has_wide, bool one_launch) { return pb::plan_plain(P, has_pair, has_wide, one_launch, wave_slots()); }
 
 // ---- a side stream per device for remainders that fit BESIDE the main launch -----------
 // When a plain solve has between one and two half rounds of pair waves (8 192 < P < 16 384
@@ -381,86 +320,9 @@ bool stream_is_capturing(hipStream_t st) {
   return cs != hipStreamCaptureStatusNone;
 }
 
-struct Piece {
-  int form, p0, p1;
-  bool side;                             // runs on the side stream ...
-  bool group;                            // ... as part of the concurrent group that closes the plan
-};
-
-// Plan of a plain solve as up to four pieces.  Sequential part: plan_plain.  If what remains
-// after the whole rounds of pair waves lies between one and two half rounds, the whole rounds
-// go first (one launch) and the rest becomes a concurrent group: half a round of pair waves
-// with the remainder beside it on the side stream (forked after the whole rounds).
 int plan_pieces(int P, bool has_pair, bool has_wide, bool one_launch, bool one_stream, Piece* out) {
-  int n = 0;
-  const int half = (int)wave_slots() * 4;          // problems in half a round of pair waves
-  const int round = 2 * half;
-  const int whole = (P / round) * round;
-  const int R = P - whole;                         // what the whole rounds leave
-  if (has_pair && !one_launch && !one_stream && R > half) {
-    const int rest = R - half;                     // < half
-    const int quarter = half / 2;                  // single-row waves: one per SIMD
-    const int wide_round = (int)wave_slots() / 2;  // one-problem waves: one per SIMD
-    const int g0 = whole, g1 = whole + half;
-    int m = 0;
-    Piece grp[3];
-    if (has_wide && rest < 2 * wide_round) {       // at most two one-problem waves per SIMD
-      grp[m++] = Piece{FORM_PAIR, g0, g1, false, true};
-      grp[m++] = Piece{FORM_WIDE, g1, P, true, true};
-    } else if (rest <= quarter) {                  // at most one single-row wave per SIMD
-      grp[m++] = Piece{FORM_PAIR, g0, g1, false, true};
-      grp[m++] = Piece{FORM_FAST1, g1, P, true, true};
-    } else if (has_wide && rest - quarter <= 2 * wide_round) {
-      // (both on the one side stream, in a fixed order.  On a stream of their own the left-overs
-      // land wherever the dispatcher happens to put them: 2.46-2.78 ms, tools/conc_probe4.py)
-      // The left-overs go FIRST on the side stream: they are latency-bound (0.37 ms whatever
-      // their number) and so are the pair waves while alone on their SIMDs, so the two overlap
-      // for free; behind the single-row waves they would run alone at the very end
-      // (tools/conc_probe5.py: 2.33 ms instead of 2.44 for 12 500 problems).
-      grp[m++] = Piece{FORM_PAIR, g0, g1, false, true};
-      grp[m++] = Piece{FORM_WIDE, g1 + quarter, P, true, true};
-      grp[m++] = Piece{FORM_FAST1, g1, g1 + quarter, true, true};
-    }
-    if (m > 0) {
-      if (whole > 0) out[n++] = Piece{FORM_PAIR, 0, whole, false, false};
-      for (int i = 0; i < m; ++i) out[n++] = grp[i];
-      return n;
-    }
-  }
-  // Between a quarter and three eighths of a round (4 096 < R <= 6 144): one single-row wave per
-  // SIMD with up to two one-problem waves beside it, instead of pair waves alone on their SIMDs
-  // (tools/conc_probe7.py: 5 000 problems 1.14 ms against 1.31, 6 000 1.39 against 1.59).
-  if (has_pair && has_wide && !one_launch && !one_stream) {
-    const int quarter = half / 2, wide_round = (int)wave_slots() / 2;
-    // (behind whole rounds only with ONE left-over wave per SIMD: two measured no gain there)
-    if (R > quarter && R - quarter <= (whole > 0 ? 1 : 2) * wide_round) {
-      if (whole > 0) out[n++] = Piece{FORM_PAIR, 0, whole, false, false};
-      out[n++] = Piece{FORM_FAST1, whole, whole + quarter, false, true};
-      out[n++] = Piece{FORM_WIDE, whole + quarter, P, true, true};
-      return n;
-    }
-  }
-  const Plan pl = plan_plain(P, has_pair, has_wide, one_launch);
-  if (pl.n_main > 0) out[n++] = Piece{pl.main_form, 0, pl.n_main, false, false};
-  out[n++] = Piece{pl.tail_form, pl.n_main, P, false, false};
-  return n;
+  return pb::plan_pieces(P, has_pair, has_wide, one_launch, one_stream, wave_slots(), out);
 }
-
-// Plan with the matrix-pipe form as the main form (plain solves, cost trace or not): one wave per
-// SIMD carries 16 problems, so a round is the same 16 384 problems as a round of pair waves but takes
-// ~0.68 of its time (measured, tools/r3_mfma_probe.py), and -- the waves being alone on their SIMDs --
-// ANY remainder launched on it costs a full round.  Whole rounds therefore go to the matrix pipe,
-// a remainder above half a round too; a smaller one keeps the plan of the vector forms
-// (plan_pieces: pair waves alone on their SIMDs, single-row and one-problem waves beside them).
-// A pass of the split form (fista_mfma2.h: 16 problems on TWO SIMDs, 8 192 problems per pass) lasts about 0.55 of a
-// one-wave pass (measured: profiles/r4_split_form_passes.txt).  With it (`has_mfma2`: plain solves without cost trace)
-// what the whole rounds leave is closed as
-//   R <= MFMA2_MIN_R                     the vector plan (latency-bound forms finish a few thousand problems sooner)
-//   MFMA2_MIN_R < R <= half a round      one pass of the split form
-//   half < R <= half + one-problem waves half a round on the split form, then the left-overs one problem per wave
-//   beyond                               one more pass of the one-wave form, as before
-constexpr int MFMA2_MIN_R = 4608;
-constexpr int MFMA2_BESIDE_CHUNKS = 2;         // chunks of one one-problem wave per SIMD beside a split-form pass
 // ... for series of ten blocks; shorter series take one chunk at most: a pass of the one-wave form is cheaper for them
 // relative to a chunk (round 4, sum-slot kernel: N = 240, 10 000 problems 1.36 ms as split pass + two chunks against
 // 1.21 ms as one pass of the one-wave form; N = 300: 1.52 against 1.59 -- profiles/r4_split_form_passes.txt)
@@ -477,53 +339,43 @@ int mfma2_long_base(int P, bool one_launch) {
   return (one_launch || P - base > pass * 5 / 16) ? P : base;
 }
 int plan_pieces_mfma(int P, bool has_pair, bool has_wide, bool one_launch, bool one_stream, bool has_mfma2, int beside_chunks, Piece* out) {
-  const int round = (int)wave_slots() * 8;           // 16 problems x (slots / 2) waves
-  const int whole = (P / round) * round;
-  const int R = P - whole;
-  int n = 0;
-  if (has_mfma2 && !one_launch && R > 0) {
-    const int half = round / 2, wide_max = (int)wave_slots();
-    if (R > MFMA2_MIN_R && R <= half) {
-      if (whole > 0) out[n++] = Piece{FORM_MFMA, 0, whole, false, false};
-      out[n++] = Piece{FORM_MFMA2, whole, P, false, false};
-      return n;
-    }
-    if (R > half && has_wide && R - half <= beside_chunks * (wide_max / 2)) {
-      // The left-overs as one-problem waves BESIDE the split-form pass, on the side stream: a wave of the N <= 320
-      // split form holds 355 registers, ONE 88-register one-problem wave fits next to it on a SIMD and issues in the
-      // gaps the pass's barriers leave.  One per SIMD and no more: with two, 355 + 2 x 88 registers no longer fit and
-      // the waves that wait block the placement of the two-wave workgroups (measured: 1 808 left-overs in one launch
-      // beside the pass 2.25 ms, one after the other 1.62 ms; 808 beside it 1.15 ms) -- so they go in chunks of one
-      // per SIMD, one chunk after the other on the side stream (a chunk beside the pass lasts about twice what it lasts
-      // alone: 10 000 problems 1.52 ms, 9 000 1.14 ms; three chunks, 11 000 problems, 1.87 ms: slower than one pass of
-      // the one-wave form, so two at most).
-      if (whole > 0) out[n++] = Piece{FORM_MFMA, 0, whole, false, false};
-      out[n++] = Piece{FORM_MFMA2, whole, whole + half, false, !one_stream};
-      if (one_stream) {
-        out[n++] = Piece{FORM_WIDE, whole + half, P, false, false};
-      } else {
-        for (int c0 = whole + half; c0 < P; c0 += wide_max / 2)
-          out[n++] = Piece{FORM_WIDE, c0, c0 + wide_max / 2 < P ? c0 + wide_max / 2 : P, true, true};
-      }
-      return n;
-    }
+  return pb::plan_pieces_mfma(P, has_pair, has_wide, one_launch, one_stream, has_mfma2, beside_chunks, wave_slots(), out);
+}
+
+// ---- workspace of a partitioned solve (int32 units) -----------------------------------------------------------
+//   [0, P) the lists   [P] length of the front list   [P+1, P+1+nblk) block counts   ranges of the three lists'
+//   candidate launches   lambda_max of every series (float64, when the caller has none)
+struct WorkLayout { int64_t ranges, lmax, total; };
+WorkLayout work_layout(int P, int V) {
+  const int64_t nblk = ((int64_t)P + pb::PATH_PER_BLOCK - 1) / pb::PATH_PER_BLOCK;
+  WorkLayout w;
+  w.ranges = ((int64_t)P + 1 + nblk + 8 + 1) & ~(int64_t)1;
+  w.lmax = w.ranges + 3 * 2 * pb::CAND_COUNT + 2;           // (even: 8-byte aligned when the buffer is)
+  w.total = w.lmax + 2 * (int64_t)V + 8;
+  return w;
+}
+// below this many problems a call is latency-bound and keeps the host-side plan (a partition costs ~8 small launches)
+constexpr int PART_MIN_P = 4096;
+
+// pb_fista_solve without a caller's workspace: one buffer per (device, stream), grown on demand, never freed
+int32_t* own_workspace(void* stream, int64_t need, int64_t* len) {
+  static std::mutex mu;
+  static std::map<std::pair<int, void*>, std::pair<int32_t*, int64_t>> cache;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  std::lock_guard<std::mutex> lock(mu);
+  auto& e = cache[std::make_pair(dev, stream)];
+  if (e.second < need) {
+    int32_t* fresh = nullptr;
+    const int64_t want = need + need / 4;
+    if (hipMalloc((void**)&fresh, (size_t)want * sizeof(int32_t)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    // (the old buffer may still be read by work in flight on this stream: it is kept, not freed -- buffers grow by a
+    // quarter at least, so what is retired over a process's life is a small multiple of the largest one)
+    e.first = fresh;
+    e.second = want;
   }
-  // a remainder costs one matrix-pipe pass (1.74 ms per 500 iterations at N = 300) whatever its size; the
-  // vector plan closes up to half a round of pair waves + one one-problem wave per SIMD beside them in
-  // 1.55 ms, so it keeps remainders up to round/2 + round/16
-  const bool has_side = has_pair && has_wide && !one_stream;
-  if (one_launch || R == 0 || R > round / 2 + (has_side ? round / 16 : 0)) {
-    out[n++] = Piece{FORM_MFMA, 0, P, false, false};
-    return n;
-  }
-  // (the remainder as one-problem waves on the side stream from the START -- an 84-register wave
-  // fits beside a matrix-pipe wave's 416 -- measured slower: 12.67 against 11.88 ms per step of
-  // config 3, profiles/r3_remainder_beside_mfma_ab.txt: it goes behind the whole rounds)
-  if (whole > 0) out[n++] = Piece{FORM_MFMA, 0, whole, false, false};
-  Piece sub[4];
-  const int m = plan_pieces(R, has_pair, has_wide, false, one_stream, sub);
-  for (int i = 0; i < m; ++i) out[n++] = Piece{sub[i].form, sub[i].p0 + whole, sub[i].p1 + whole, sub[i].side, sub[i].group};
-  return n;
+  *len = e.second;
+  return e.first;
 }
 
 template <int KIND>
@@ -797,12 +649,13 @@ int pb_fista_plan_ex(int N, int K, int P, int stop_mode, int wind, unsigned flag
   return PB_OK;
 }
 
-int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, int64_t ldw, int P,
-                   int N, const double* taps_host, const double* taps_dev, int K, double step,
-                   double lbda,
-                   const double* lbda_dev, const double* betas_dev, int n_iter, float* J_dev,
-                   int64_t ldj, int stop_mode, double tol, int wind, int32_t* n_done_dev,
-                   unsigned flags, void* stream) {
+static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, int64_t ldw, int P,
+                      int N, const double* taps_host, const double* taps_dev, int K, double step,
+                      double lbda,
+                      const double* lbda_dev, const double* betas_dev, int n_iter, float* J_dev,
+                      int64_t ldj, int stop_mode, double tol, int wind, int32_t* n_done_dev,
+                      unsigned flags, void* stream, const double* lmax_dev, double dense_ratio,
+                      int32_t* work_dev, int64_t work_len) {
   if (P < 0 || N < 1 || K < 1 || n_iter < 0 || y_rep < 1)
     return fail(PB_ERR_INVALID, "pb_fista_solve: bad size (P=%d N=%d K=%d n_iter=%d y_rep=%d)", P,
                 N, K, n_iter, y_rep);
@@ -988,6 +841,127 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
       return check_launch("fista_fast_kernel(re-solve)");
     };
     if (flags & PB_FLAG_NO_PAIR) return run(FORM_FAST1, 0, P);
+    // ---- round 5: partition BEFORE solving (dense class -> matrix pipe, sparse class -> float32 vector forms) and a
+    // compacted re-solve of what a guard or certificate hands back; list lengths and launch plans live on the device
+    // (path.h, plan.h).  For every call the matrix-pipe form would carry: one lambda or one per problem, cost trace,
+    // window-rule certificate, _loops_deconv rule.  Without it a batch whose lambda lies near lambda_max was solved
+    // twice -- matrix pipe, then one handed-back problem per wave (profiles/r4_path_partition.txt: 2.05 against 3.20e9).
+    const bool part_forces = (flags & (PB_FLAG_FORCE_PAIR | PB_FLAG_ONE_LAUNCH | PB_FLAG_FORCE_MFMA2 | PB_FLAG_CERT_NO_RESOLVE |
+                                       PB_FLAG_NO_PARTITION)) != 0 ||
+                             ((flags & PB_FLAG_FORCE_MFMA) && !lmax_dev);       // ("everything on the matrix pipe", as before)
+    const bool part_mfma = mfma != nullptr || (fe && (stop_mode == PB_STOP_NONE || mfma_cert || mfma_loops) && n_done_dev && lbda_dev &&
+                                               !(flags & (PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_DIRECT_FIR | PB_FLAG_NO_MFMA)) &&
+                                               pick_mfma(N, K, stop_mode != PB_STOP_NONE) != nullptr);
+    if (part_mfma && !part_forces && work_dev && P >= PART_MIN_P && K <= pb::LMAX_KT && N <= 640 &&
+        work_len >= work_layout(P, (P + y_rep - 1) / y_rep).total) {
+      const mfma_launch_fn mfma_p = mfma ? mfma : pick_mfma(N, K, stop_mode != PB_STOP_NONE);
+      const mfma2_launch_fn mfma2_p = (mfma2 || !lbda_dev) ? mfma2 : (((stop_mode == PB_STOP_NONE || mfma2_cert) && K <= MFMA_K2) ? pick_mfma2(N, K) : nullptr);
+      const int V = (P + y_rep - 1) / y_rep;
+      const WorkLayout wl = work_layout(P, V);
+      hipStream_t user = (hipStream_t)stream;
+      const bool one_stream = (flags & PB_FLAG_ONE_STREAM) != 0 || stream_is_capturing(user);
+      // lambda_max of every series, unless the caller has it
+      const double* lmax = lmax_dev;
+      if (!lmax) {
+        double* lm = reinterpret_cast<double*>(work_dev + wl.lmax);
+        pb::LmaxTaps lt;
+        for (int k = 0; k < pb::LMAX_KT; ++k) lt.h[k] = k < K ? (float)taps_host[k] : 0.0f;
+        const dim3 grid((unsigned)((V + 3) / 4)), block(256);
+        if (N <= 320) hipLaunchKernelGGL((pb::lmax_wave_kernel<5>), grid, block, 4 * (64 * 5 + pb::LMAX_KT) * sizeof(float), user, y_dev, ldy, V, N, lt, K, lm);
+        else hipLaunchKernelGGL((pb::lmax_wave_kernel<10>), grid, block, 4 * (64 * 10 + pb::LMAX_KT) * sizeof(float), user, y_dev, ldy, V, N, lt, K, lm);
+        lmax = lm;
+      }
+      const int nblk = (P + pb::PATH_PER_BLOCK - 1) / pb::PATH_PER_BLOCK;
+      const double slots = wave_slots();
+      const bool has_wide = pick_wide_small(N, K) != nullptr;
+      const bool pair_plain = fe->fn_pair != nullptr && stop_mode == PB_STOP_NONE;
+      const bool has_mfma2 = mfma2_p != nullptr && (stop_mode == PB_STOP_NONE || mfma_cert);
+      int32_t* rg_dense = work_dev + wl.ranges;
+      int32_t* rg_sparse = rg_dense + 2 * pb::CAND_COUNT;
+      int32_t* rg_flag = rg_sparse + 2 * pb::CAND_COUNT;
+      {
+        pb::ClassPred cp{lbda_dev, lbda, lmax, y_rep, dense_ratio > 0.0 ? dense_ratio : PB_PATH_DENSE_RATIO, nullptr};
+        hipLaunchKernelGGL(pb::path_count_kernel, dim3(nblk), dim3(pb::PATH_THREADS), 0, user, cp, P, work_dev);
+        hipLaunchKernelGGL(pb::path_scan_kernel, dim3(1), dim3(pb::PATH_THREADS), 0, user, P, nblk, work_dev);
+        hipLaunchKernelGGL(pb::path_scatter_kernel, dim3(nblk), dim3(pb::PATH_THREADS), 0, user, cp, P, work_dev);
+        const pb::PlanSpec dense{1, (pair_plain || cert) ? 1 : 0, has_wide ? 1 : 0, 0, one_stream ? 1 : 0, has_mfma2 ? 1 : 0, beside_chunks_for(N), slots};
+        const pb::PlanSpec sparse{2, (pair_plain || cert) ? 1 : 0, has_wide ? 1 : 0, 0, one_stream ? 1 : 0, 0, 0, slots};
+        hipLaunchKernelGGL(pb::plan_kernel, dim3(1), dim3(1), 0, user, dense, sparse, P, work_dev, rg_dense, rg_sparse);
+        const int rc = check_launch("partition");
+        if (rc != PB_OK) return rc;
+      }
+      SideStream* ss = nullptr;
+      std::unique_lock<std::mutex> lock(g_side_mutex, std::defer_lock);
+      if (!one_stream) {
+        lock.lock();
+        ss = side_stream_locked();
+      }
+      // one candidate launch of a list's device-side plan
+      auto cand = [&](int c, const int32_t* ranges, int side, const int32_t* perm, int n_max, int stop_here, bool exact_rule) -> int {
+        const int form = pb::cand_form(c);
+        const int bound = pb::cand_max_slots(c, n_max, slots);
+        if (bound <= 0) return PB_OK;
+        pb::FistaArgs b = a;
+        b.perm = perm;
+        b.n_dense = work_dev + P;
+        b.perm_side = side;
+        b.range = ranges + 2 * c;
+        b.grid_slots = bound;
+        b.stop_mode = stop_here;
+        hipStream_t st = (pb::cand_side(c) && ss) ? ss->stream : user;
+        const bool wj = J_dev != nullptr;
+        int bad = 0;
+        const char* what = "";
+        if (form == FORM_MFMA) { bad = mfma_p(b, taps_host, K, wj, st); what = "fista_mfma_kernel(list)"; }
+        else if (form == FORM_MFMA2) { bad = mfma2_p(b, taps_host, K, wj, st); what = "fista_mfma2_kernel(list)"; }
+        else if (form == FORM_PAIR && cert && !exact_rule) { bad = fe->fn_pair_cert(b, taps_host, K, st); what = "fista_pair_ffa_kernel(cert, list)"; }
+        else if (form == FORM_PAIR) { bad = fe->fn_pair_ffa(b, taps_host, K, wj, st); what = "fista_pair_ffa_kernel(list)"; }
+        else if (form == FORM_WIDE) { bad = pick_wide_small(N, K)->fn(b, taps_host, K, wj, stop_here, st); what = "fista_fast_kernel(wide, list)"; }
+        else { bad = fe->fn(b, taps_host, K, wj, stop_here, st); what = "fista_fast_kernel(list)"; }
+        if (bad) return fail(PB_ERR_INVALID, "pb_fista_solve: %s rejected the launch", what);
+        return check_launch(what);
+      };
+      // a whole list: the candidates in their static order, the side-stream ones forked after the whole rounds
+      auto solve_list = [&](const int32_t* ranges, int side, const int32_t* perm, bool with_mfma, bool with_pair, bool exact_rule) -> int {
+        const int stop_here = stop_mode;
+        int rc = PB_OK;
+        bool forked = false;
+        for (int c = 0; c < pb::CAND_COUNT && rc == PB_OK; ++c) {
+          const int form = pb::cand_form(c);
+          if ((form == FORM_MFMA && !with_mfma) || (form == FORM_MFMA2 && !(with_mfma && has_mfma2)) || (form == FORM_PAIR && !with_pair) ||
+              (form == FORM_WIDE && !has_wide) || (pb::cand_side(c) && !ss))
+            continue;
+          if (c >= pb::CAND_FIRST_AFTER_FORK && !forked && ss) {
+            if (hipEventRecord(ss->fork, user) != hipSuccess || hipStreamWaitEvent(ss->stream, ss->fork, 0) != hipSuccess)
+              return fail(PB_ERR_HIP, "pb_fista_solve: fork to the side stream failed");
+            forked = true;
+          }
+          rc = cand(c, ranges, side, perm, P, stop_here, exact_rule);
+        }
+        if (forked && (hipEventRecord(ss->join, ss->stream) != hipSuccess || hipStreamWaitEvent(user, ss->join, 0) != hipSuccess))
+          return fail(PB_ERR_HIP, "pb_fista_solve: join of the side stream failed");
+        return rc;
+      };
+      const bool only_dense = (flags & PB_FLAG_ONLY_DENSE) != 0, only_sparse = (flags & PB_FLAG_ONLY_SPARSE) != 0;   // (measurement aids)
+      int rc = PB_OK;
+      if (!only_sparse) rc = solve_list(rg_dense, 1, work_dev, true, pair_plain || cert, false);
+      if (rc == PB_OK && !only_dense) rc = solve_list(rg_sparse, 2, work_dev, false, pair_plain || cert, false);
+      if (rc != PB_OK || only_dense || only_sparse) return rc;
+      // what the guards / certificates handed back (n_done = -1): compacted, then the exact vector forms at full occupancy
+      {
+        pb::ClassPred cp{nullptr, 0.0, nullptr, 1, 0.0, n_done_dev};
+        hipLaunchKernelGGL(pb::path_count_kernel, dim3(nblk), dim3(pb::PATH_THREADS), 0, user, cp, P, work_dev);
+        hipLaunchKernelGGL(pb::path_scan_kernel, dim3(1), dim3(pb::PATH_THREADS), 0, user, P, nblk, work_dev);
+        hipLaunchKernelGGL(pb::path_scatter_kernel, dim3(nblk), dim3(pb::PATH_THREADS), 0, user, cp, P, work_dev);
+        const pb::PlanSpec flagged{2, 0, has_wide ? 1 : 0, 0, 1, 0, 0, slots};
+        const pb::PlanSpec none{0, 0, 0, 0, 1, 0, 0, slots};
+        hipLaunchKernelGGL(pb::plan_kernel, dim3(1), dim3(1), 0, user, flagged, none, P, work_dev, rg_flag, (int32_t*)nullptr);
+        rc = check_launch("partition(handed back)");
+        if (rc != PB_OK) return rc;
+        ss = nullptr;                                  // (one stream: a few per cent of the batch at most)
+        return solve_list(rg_flag, 3, work_dev, false, false, true);
+      }
+    }
     if (flags & PB_FLAG_FORCE_PAIR) {
       if (cert) {
         const int rc = run(FORM_PAIR, 0, P);
@@ -1115,6 +1089,57 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
     hipLaunchKernelGGL((pb::fista_generic_kernel<false>), dim3(P), dim3(pb::GEN_THREADS), lds,
                        (hipStream_t)stream, a, taps_dev, K, wind);
   return check_launch("fista_generic_kernel");
+}
+
+int pb_fista_list_plan(int kind, int n, int n_max, int has_pair, int has_wide, int one_stream, int has_mfma2,
+                       int beside_chunks, int32_t* ranges, int32_t* bounds) {
+  if (kind < 1 || kind > 2 || n < 0 || n_max < n) return fail(PB_ERR_INVALID, "pb_fista_list_plan: bad argument");
+  Piece pc[pb::MAX_PIECES];
+  int npc = 0;
+  const double slots = wave_slots();
+  if (n > 0 && kind == 1) npc = pb::plan_pieces_mfma(n, has_pair != 0, has_wide != 0, false, one_stream != 0, has_mfma2 != 0, beside_chunks, slots, pc);
+  else if (n > 0) npc = pb::plan_pieces(n, has_pair != 0, has_wide != 0, false, one_stream != 0, slots, pc);
+  int32_t rg[2 * pb::CAND_COUNT];
+  const int rc = pb::plan_to_candidates(pc, npc, rg);
+  for (int c = 0; c < pb::CAND_COUNT; ++c) {
+    if (ranges) { ranges[2 * c] = rg[2 * c]; ranges[2 * c + 1] = rg[2 * c + 1]; }
+    if (bounds) bounds[c] = pb::cand_max_slots(c, n_max, slots);
+  }
+  if (rc != 0) return fail(PB_ERR_INVALID, "pb_fista_list_plan: a piece of the plan found its candidate launch taken (n=%d)", n);
+  g_err[0] = 0;
+  return PB_OK;
+}
+
+int64_t pb_fista_work_len(int P, int y_rep) {
+  if (P < 0 || y_rep < 1) return 0;
+  return work_layout(P, (P + y_rep - 1) / y_rep).total;
+}
+
+int pb_fista_solve_ex(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, int64_t ldw, int P,
+                      int N, const double* taps_host, const double* taps_dev, int K, double step,
+                      double lbda, const double* lbda_dev, const double* betas_dev, int n_iter, float* J_dev,
+                      int64_t ldj, int stop_mode, double tol, int wind, int32_t* n_done_dev,
+                      unsigned flags, void* stream, const double* lmax_dev, double dense_ratio,
+                      int32_t* work_dev, int64_t work_len) {
+  return solve_impl(y_dev, ldy, y_rep, w_dev, ldw, P, N, taps_host, taps_dev, K, step, lbda, lbda_dev, betas_dev, n_iter,
+                    J_dev, ldj, stop_mode, tol, wind, n_done_dev, flags, stream, lmax_dev, dense_ratio, work_dev, work_len);
+}
+
+int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, int64_t ldw, int P,
+                   int N, const double* taps_host, const double* taps_dev, int K, double step,
+                   double lbda,
+                   const double* lbda_dev, const double* betas_dev, int n_iter, float* J_dev,
+                   int64_t ldj, int stop_mode, double tol, int wind, int32_t* n_done_dev,
+                   unsigned flags, void* stream) {
+  // a workspace of the library's own for the partition (grown on demand, one per device and stream; never while the
+  // stream is being captured: an allocation cannot be captured -- such calls, and calls that fail to get memory, run
+  // without the partition.  pb_fista_solve_ex takes the caller's workspace instead and allocates nothing.)
+  int32_t* work = nullptr;
+  int64_t len = 0;
+  if (P >= PART_MIN_P && N <= 640 && n_done_dev && !(flags & PB_FLAG_NO_PARTITION) && !stream_is_capturing((hipStream_t)stream))
+    work = own_workspace(stream, work_layout(P, (P + (y_rep > 0 ? y_rep : 1) - 1) / (y_rep > 0 ? y_rep : 1)).total, &len);
+  return solve_impl(y_dev, ldy, y_rep, w_dev, ldw, P, N, taps_host, taps_dev, K, step, lbda, lbda_dev, betas_dev, n_iter,
+                    J_dev, ldj, stop_mode, tol, wind, n_done_dev, flags, stream, nullptr, 0.0, work, len);
 }
 
 int pb_fista_solve_d(const double* y_dev, int64_t ldy, int y_rep, double* w_dev, int64_t ldw,
@@ -1547,76 +1572,19 @@ int pb_fista_solve_pp(const float* y_dev, int64_t ldy, double* w_dev, int64_t ld
   return check_launch("fista_generic_kernel(pp)");
 }
 
-int64_t pb_fista_path_work_len(int P) {
-  return P >= 0 ? (int64_t)P + 1 + (P + pb::PATH_PER_BLOCK - 1) / pb::PATH_PER_BLOCK + 8 : 0;
-}
+int64_t pb_fista_path_work_len(int P) { return P >= 0 ? work_layout(P, P).total : 0; }     // (enough for any y_rep)
 
 int pb_fista_solve_path(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, int64_t ldw, int P, int N,
                         const double* taps_host, const double* taps_dev, int K, double step,
                         const double* lbda_dev, const double* lmax_dev, double dense_ratio,
                         const double* betas_dev, int n_iter, int32_t* n_done_dev, int32_t* work_dev,
                         int64_t work_len, unsigned flags, void* stream) {
-  if (P < 0 || N < 1 || K < 1 || n_iter < 0 || y_rep < 1)
-    return fail(PB_ERR_INVALID, "pb_fista_solve_path: bad size (P=%d N=%d K=%d n_iter=%d y_rep=%d)", P, N, K, n_iter, y_rep);
-  if (P > (1 << 25)) return fail(PB_ERR_INVALID, "pb_fista_solve_path: more than 2^25 problems per launch");
-  if (ldy < N || ldw < N) return fail(PB_ERR_INVALID, "pb_fista_solve_path: leading dimension < N");
-  if (!(step > 0.0)) return fail(PB_ERR_INVALID, "pb_fista_solve_path: step must be positive");
-  if (P == 0) return PB_OK;
-  if (!y_dev || !w_dev || !taps_host || !lbda_dev || !n_done_dev || (n_iter > 0 && !betas_dev))
+  // (round 4's entry point for regularisation paths; since round 5 every call shape is partitioned:
+  // pb_fista_solve_ex with per-problem lambdas, the caller's lambda_max and workspace)
+  if (P > 0 && (!lbda_dev || !n_done_dev))
     return fail(PB_ERR_INVALID, "pb_fista_solve_path: NULL pointer (per-problem lambdas and n_done are required)");
-  const FastEntry* fe = pick_fast(N, K);
-  const mfma_launch_fn mfma = (fe && fe->fn_pair_ffa && !(flags & PB_FLAG_NO_MFMA)) ? pick_mfma(N, K) : nullptr;
-  // no partition possible (no lambda_max, no workspace, a shape outside the matrix-pipe form or the pair form): the
-  // plain dispatch of per-problem lambdas (vector forms)
-  if (!mfma || !lmax_dev || !work_dev || work_len < pb_fista_path_work_len(P))
-    return pb_fista_solve(y_dev, ldy, y_rep, w_dev, ldw, P, N, taps_host, taps_dev, K, step, 0.0, lbda_dev, betas_dev,
-                          n_iter, nullptr, 0, PB_STOP_NONE, 0.0, 0, n_done_dev, flags, stream);
-  const double ratio = dense_ratio > 0.0 ? dense_ratio : PB_PATH_DENSE_RATIO;
-  hipStream_t st = (hipStream_t)stream;
-  const int nblk = (P + pb::PATH_PER_BLOCK - 1) / pb::PATH_PER_BLOCK;
-  hipLaunchKernelGGL(pb::path_count_kernel, dim3(nblk), dim3(pb::PATH_THREADS), 0, st, lbda_dev, lmax_dev, y_rep, ratio, P, work_dev);
-  hipLaunchKernelGGL(pb::path_scan_kernel, dim3(1), dim3(pb::PATH_THREADS), 0, st, P, nblk, work_dev);
-  hipLaunchKernelGGL(pb::path_scatter_kernel, dim3(nblk), dim3(pb::PATH_THREADS), 0, st, lbda_dev, lmax_dev, y_rep, ratio, P, work_dev);
-  int rc = check_launch("path_partition");
-  if (rc != PB_OK) return rc;
-
-  pb::FistaArgs a;
-  a.y = y_dev; a.y64 = nullptr; a.ldy = ldy; a.w = w_dev; a.ldw = ldw; a.lbda_vec = lbda_dev;
-  a.betas = betas_dev; a.J = nullptr; a.J64 = nullptr; a.ldj = 0; a.n_done = n_done_dev;
-  a.step = step; a.lbda = 0.0; a.tol = 0.0;
-  a.y_rep = y_rep; a.P = P; a.N = N; a.n_iter = n_iter; a.stop_mode = PB_STOP_NONE;
-  a.taps_pp = nullptr; a.ldt = 0; a.step_vec = nullptr; a.step_shared = 0; a.K = K; a.p0 = 0;
-  a.cold = (flags & PB_FLAG_COLD_START) ? 1 : 0;
-  a.rho_guard = (flags & PB_FLAG_NO_RHO_GUARD) ? 0 : 1;
-  a.perm = work_dev;
-  a.n_dense = work_dev + P;
-  // dense list on the matrix pipe, sparse list on the pair form: both launches cover P slots, the waves beyond a
-  // list's length (read on the device) leave at once
-  // (measurement aids: PB_FLAG_FORCE_MFMA = the dense list's launch only, PB_FLAG_FORCE_PAIR = the sparse list's only;
-  // the other class is then left unsolved)
-  const bool only_dense = (flags & PB_FLAG_FORCE_MFMA) != 0, only_sparse = (flags & PB_FLAG_FORCE_PAIR) != 0;
-  if (!only_sparse) {
-    a.perm_side = 1;
-    if (mfma(a, taps_host, K, false, st) != 0) return fail(PB_ERR_INVALID, "pb_fista_solve_path: matrix-pipe kernel rejected the launch");
-    rc = check_launch("fista_mfma_kernel(path, dense list)");
-    if (rc != PB_OK) return rc;
-  }
-  if (!only_dense) {
-    a.perm_side = 2;
-    if (fe->fn_pair_ffa(a, taps_host, K, false, st) != 0) return fail(PB_ERR_INVALID, "pb_fista_solve_path: pair kernel rejected the launch");
-    rc = check_launch("fista_pair_ffa_kernel(path, sparse list)");
-    if (rc != PB_OK) return rc;
-  }
-  if (!(flags & PB_FLAG_CERT_NO_RESOLVE) && !only_dense && !only_sparse) {       // what the guards of the matrix-pipe form handed back: exact re-solve
-    a.perm_side = 0;
-    a.perm = nullptr;
-    a.n_dense = nullptr;
-    a.only_flagged = 1;
-    if (fe->fn(a, taps_host, K, false, PB_STOP_NONE, st) != 0)
-      return fail(PB_ERR_INVALID, "pb_fista_solve_path: no single-row form for the re-solve");
-    rc = check_launch("fista_fast_kernel(path, re-solve)");
-  }
-  return rc;
+  return solve_impl(y_dev, ldy, y_rep, w_dev, ldw, P, N, taps_host, taps_dev, K, step, 0.0, lbda_dev, betas_dev, n_iter,
+                    nullptr, 0, PB_STOP_NONE, 0.0, 6, n_done_dev, flags, stream, lmax_dev, dense_ratio, work_dev, work_len);
 }
 
 }  // extern "C"

@@ -73,19 +73,38 @@ struct FistaArgs {
   const int32_t* perm = nullptr;
   const int32_t* n_dense = nullptr;
   int perm_side = 0;
+  // Device-side plan (round 5, plan.h): range[0], range[1] = the slots [s0, s1) of its list this launch solves, read on
+  // the device; the grid covers `grid_slots` slots (the worst case the host can bound) and the waves beyond s1 - s0
+  // leave at once.  nullptr: the slots [p0, length of the list) as before.
+  const int32_t* range = nullptr;
+  int grid_slots = 0;
 };
+
+// problems the host sizes the grid for
+inline int64_t launch_count(const FistaArgs& a) { return a.range ? (int64_t)a.grid_slots : (int64_t)(a.P - a.p0); }
 
 // slots of this launch's list (the whole batch without a partition)
 __device__ __forceinline__ int list_length(const FistaArgs& a) {
   if (a.perm_side == 0) return a.P;
+  if (a.perm_side == 3) return a.P;              // (a list of its own, e.g. the handed-back problems: bounded by `range`)
   const int nd = *a.n_dense;
   return a.perm_side == 1 ? nd : a.P - nd;
+}
+// first slot and end of the slots this launch solves
+__device__ __forceinline__ void launch_slots(const FistaArgs& a, int& s0, int& s1) {
+  if (a.range) {
+    s0 = a.range[0];
+    s1 = a.range[1];
+  } else {
+    s0 = a.p0;
+    s1 = list_length(a);
+  }
 }
 // slot -> problem; `live` = the slot is inside the list (a dead slot maps to a valid problem whose data may be read)
 __device__ __forceinline__ int slot_to_problem(const FistaArgs& a, int slot, int n_list, bool& live) {
   live = slot < n_list;
   if (a.perm_side == 0) return live ? slot : a.P - 1;
-  return live ? a.perm[a.perm_side == 1 ? slot : a.P - 1 - slot] : 0;
+  return live ? a.perm[a.perm_side == 2 ? a.P - 1 - slot : slot] : 0;        // (sides 1 and 3: ascending from the front)
 }
 
 // Tap pairs as kernel arguments (read with scalar loads, kept in SGPRs).
@@ -154,9 +173,12 @@ __global__ __launch_bounds__(256) void fista_fast_kernel(FistaArgs a, TapPairs<K
 
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int sub = threadIdx.x & (LPV - 1);  // lane within the problem's segment
-  const int prob = (int)(gid / LPV) + a.p0;
-  bool live = prob < a.P;
-  const int p = live ? prob : a.P - 1;
+  int s0, s1;
+  launch_slots(a, s0, s1);
+  // the whole wave lies beyond this launch's slots (a candidate launch of a device-side plan that got nothing): leave
+  if ((int)((gid - (threadIdx.x & 63)) / LPV) + s0 >= s1) return;
+  bool live;
+  const int p = slot_to_problem(a, (int)(gid / LPV) + s0, s1, live);
   const int base = sub * S;
   // re-solve pass behind the certificate / matrix-pipe kernels: only flagged problems; a wave
   // none of whose rows is flagged leaves at once (no barrier anywhere in this kernel)

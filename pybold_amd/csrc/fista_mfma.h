@@ -193,12 +193,13 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
   const int lane = threadIdx.x & 63;
   const int v = lane & 15, g = lane >> 4;
   const int wave = (int)((blockIdx.x * 256 + threadIdx.x) >> 6);
-  const int n_list = list_length(a);              // (a.P without a partition; else the length of this launch's list)
+  int s0, n_list;                                 // this launch's slots [s0, n_list) of its list (the batch itself without a partition)
+  launch_slots(a, s0, n_list);
   // the whole wave lies beyond the list: leave (no workgroup barrier anywhere below; a SCALAR branch -- the wave index is
   // the same in every lane -- so that the body does not run under a saved exec mask)
-  if (__builtin_amdgcn_readfirstlane(wave) * 16 + a.p0 >= n_list) return;
+  if (__builtin_amdgcn_readfirstlane(wave) * 16 + s0 >= n_list) return;
   bool live;
-  const int p = slot_to_problem(a, wave * 16 + v + a.p0, n_list, live);
+  const int p = slot_to_problem(a, wave * 16 + v + s0, n_list, live);
   const int tb = 8 * g;                          // this lane's first slot inside a block of 32 slots
   const bool g3 = g == 3;                        // lane group 3 holds the sum slot (slot 31 = its j = 7)
 
@@ -735,7 +736,7 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
 #endif
 template <int NB, int NT>
 int launch_mfma_nt(const FistaArgs& a, const double* taps, int K, bool with_j, hipStream_t st) {
-  const int64_t waves = ((int64_t)(a.P - a.p0) + 15) / 16;
+  const int64_t waves = (launch_count(a) + 15) / 16;
   const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
   const bool cert = a.stop_mode == PB_STOP_WINDOW;
   if (a.stop_mode == PB_STOP_LOOPS) {            // the exact _loops_deconv rule: plain variant with two near tiles only

@@ -50,9 +50,10 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
   constexpr int NBT = NBA + NBB;
   const int lane = threadIdx.x & 63;
   const int v = lane & 15, g = lane >> 4;
-  const int prob = (int)blockIdx.x * 16 + v + a.p0;
-  const bool live = prob < a.P;
-  const int p = live ? prob : a.P - 1;
+  int s0, s1;                                      // this launch's slots of its list (fista_fast.h: launch_slots)
+  launch_slots(a, s0, s1);
+  bool live;
+  const int p = slot_to_problem(a, (int)blockIdx.x * 16 + v + s0, s1, live);
   const int tb = 8 * g;
 
   // ---- LDS: residual fragments of both waves, the exchange areas, the taps --------------------------------
@@ -524,6 +525,9 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
 template <int NBA, int NBB, bool TAPS_DEV = false, bool WITH_J = false, bool CERT = false>
 __global__ __launch_bounds__(128) void fista_mfma2_kernel(FistaArgs a, MfmaTaps tp) {
   extern __shared__ __attribute__((aligned(16))) char mf2_smem[];
+  if (a.range) {                                   // a candidate launch of a device-side plan: workgroups beyond its slots leave
+    if ((int)blockIdx.x * 16 + a.range[0] >= a.range[1]) return;      // (both waves: before any barrier)
+  }
   if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) mfma2_role<NBA, NBB, TAPS_DEV, 0, WITH_J, CERT>(a, tp, mf2_smem);
   else mfma2_role<NBA, NBB, TAPS_DEV, 1, WITH_J, CERT>(a, tp, mf2_smem);
 }
@@ -537,7 +541,7 @@ int launch_mfma2(const FistaArgs& a, const double* taps, int K, bool with_j, hip
   const bool cert = a.stop_mode == PB_STOP_WINDOW;
   if ((a.stop_mode != PB_STOP_NONE && !cert) || !a.n_done) return 1;
   if ((with_j || cert) && a.taps_pp) return 1;
-  const int64_t groups = ((int64_t)(a.P - a.p0) + 15) / 16;
+  const int64_t groups = (launch_count(a) + 15) / 16;
   const dim3 grid((unsigned)groups), block(128);
   const size_t lds = mfma2_lds_bytes(NBB);
   if (a.taps_pp) {                                 // shared HRF and step in device memory (the blind step's z-step)

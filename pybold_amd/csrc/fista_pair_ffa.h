@@ -105,10 +105,11 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
   const int sub = threadIdx.x & 15;
   const int row = gid >> 4;
   const int base = sub * S;
-  const int pA0 = SPLIT ? row + a.p0 : 2 * row + a.p0, pB0 = SPLIT ? pA0 : pA0 + 1;
-  const int n_list = list_length(a);              // (a.P without a partition; else the length of this launch's list)
+  int s0, n_list;                                 // this launch's slots [s0, n_list) of its list (the batch itself without a partition)
+  launch_slots(a, s0, n_list);
+  const int pA0 = SPLIT ? row + s0 : 2 * row + s0, pB0 = SPLIT ? pA0 : pA0 + 1;
   // the four rows of this wave all lie beyond the list: leave (wave-level synchronisation only below)
-  if ((SPLIT ? 4 : 8) * (gid >> 6) + a.p0 >= n_list) return;
+  if ((SPLIT ? 4 : 8) * (gid >> 6) + s0 >= n_list) return;
   bool liveA, liveB;
   // samples of the series held by slot A / slot B, and where slot B starts in the row
   const int nA = SPLIT ? 16 * S : a.N, nB = SPLIT ? a.N - 16 * S : a.N, oB = SPLIT ? 16 * S : 0;
@@ -611,7 +612,7 @@ __global__ __launch_bounds__(256, 2) void fista_pair_ffa_kernel(FistaArgs a, Tap
 template <int S, int KT>
 int launch_pair_ffa_dev(const FistaArgs& a, hipStream_t st) {
   const TapsFFA<KT> none{};
-  const int64_t rows = ((int64_t)(a.P - a.p0) + 1) / 2;
+  const int64_t rows = (launch_count(a) + 1) / 2;
   const dim3 grid((unsigned)((rows * 16 + 255) / 256)), block(256);
   const size_t lds = (size_t)16 * S * 16 * (sizeof(f2) + sizeof(float)) + 16 * PAIR_LJ * sizeof(float);
   hipLaunchKernelGGL((fista_pair_ffa_kernel<S, KT, false, false, false, true>), grid, block, lds, st, a, none);
@@ -623,7 +624,7 @@ template <int S, int KT>
 int launch_pair_ffa_split(const FistaArgs& a, const double* taps, int K, bool with_j, bool cert, hipStream_t st) {
   if (a.N <= 16 * S || a.N > 32 * S || (cert && !a.n_done)) return 1;
   const auto tf = make_taps_ffa<KT>(taps, K);
-  const int64_t rows = (int64_t)(a.P - a.p0);
+  const int64_t rows = launch_count(a);
   const dim3 grid((unsigned)((rows * 16 + 255) / 256)), block(256);
   const size_t lds = (size_t)16 * S * 16 * (sizeof(f2) + sizeof(float)) +
                      (16 * PAIR_LJ + (cert ? 256 * PAIR_LC : 0)) * sizeof(float);
@@ -646,7 +647,7 @@ template <int S, int KT>
 int launch_pair_ffa_cert(const FistaArgs& a, const double* taps, int K, hipStream_t st) {
   if (!a.n_done) return 1;
   const auto tf = make_taps_ffa<KT>(taps, K);
-  const int64_t rows = ((int64_t)(a.P - a.p0) + 1) / 2;
+  const int64_t rows = (launch_count(a) + 1) / 2;
   const dim3 grid((unsigned)((rows * 16 + 255) / 256)), block(256);
   const size_t lds = (size_t)16 * S * 16 * (sizeof(f2) + sizeof(float)) + (16 * PAIR_LJ + 256 * PAIR_LC) * sizeof(float);
   const bool skip0 = KT > 1 && tf.pr[0].x == 0.0f;
@@ -658,7 +659,7 @@ int launch_pair_ffa_cert(const FistaArgs& a, const double* taps, int K, hipStrea
 template <int S, int KT>
 int launch_pair_ffa(const FistaArgs& a, const double* taps, int K, bool with_j, hipStream_t st) {
   const auto tf = make_taps_ffa<KT>(taps, K);
-  const int64_t rows = ((int64_t)(a.P - a.p0) + 1) / 2;
+  const int64_t rows = (launch_count(a) + 1) / 2;
   const dim3 grid((unsigned)((rows * 16 + 255) / 256)), block(256);
   const size_t lds = (size_t)16 * S * 16 * (sizeof(f2) + sizeof(float)) + 16 * PAIR_LJ * sizeof(float);
   const bool skip0 = KT > 1 && tf.pr[0].x == 0.0f;      // leading tap exactly zero

@@ -12,7 +12,7 @@ template <int S, int KT>
 int launch_fast(const FistaArgs& a, const double* taps, int K, bool with_j, int stop,
                 hipStream_t st) {
   const auto tp = make_tap_pairs<KT>(taps, K);
-  const dim3 grid((unsigned)(((int64_t)(a.P - a.p0) * 16 + 255) / 256)), block(256);
+  const dim3 grid((unsigned)((launch_count(a) * 16 + 255) / 256)), block(256);
   if (stop == PB_STOP_NONE) {
     if (with_j) hipLaunchKernelGGL((fista_fast_kernel<S, KT, true, 0>), grid, block, 0, st, a, tp);
     else hipLaunchKernelGGL((fista_fast_kernel<S, KT, false, 0>), grid, block, 0, st, a, tp);
@@ -45,7 +45,7 @@ int launch_fast(const FistaArgs& a, const double* taps, int K, bool with_j, int 
 template <int S, int KT>
 int launch_wide(const FistaArgs& a, const double* taps, int K, bool with_j, int stop, hipStream_t st) {
   const auto tp = make_tap_pairs<KT>(taps, K);
-  const dim3 grid((unsigned)(((int64_t)(a.P - a.p0) * 64 + 255) / 256)), block(256);
+  const dim3 grid((unsigned)((launch_count(a) * 64 + 255) / 256)), block(256);
   if (stop == PB_STOP_NONE) {
     if (with_j) hipLaunchKernelGGL((fista_fast_kernel<S, KT, true, 0, false, 64>), grid, block, 0, st, a, tp);
     else hipLaunchKernelGGL((fista_fast_kernel<S, KT, false, 0, false, 64>), grid, block, 0, st, a, tp);
@@ -78,7 +78,7 @@ int launch_wide(const FistaArgs& a, const double* taps, int K, bool with_j, int 
 template <int S, int KT>
 int launch_fast_pp(const FistaArgs& a, int stop, hipStream_t st) {
   const TapPairs<KT> tp{};
-  const dim3 grid((unsigned)(((int64_t)(a.P - a.p0) * 16 + 255) / 256)), block(256);
+  const dim3 grid((unsigned)((launch_count(a) * 16 + 255) / 256)), block(256);
   if (stop == PB_STOP_NONE)
     hipLaunchKernelGGL((fista_fast_kernel<S, KT, false, 0, true>), grid, block, 0, st, a, tp);
   else
@@ -90,7 +90,7 @@ int launch_fast_pp(const FistaArgs& a, int stop, hipStream_t st) {
 template <int S, int KT>
 int launch_wide_pp(const FistaArgs& a, int stop, hipStream_t st) {
   const TapPairs<KT> tp{};
-  const dim3 grid((unsigned)(((int64_t)(a.P - a.p0) * 64 + 255) / 256)), block(256);
+  const dim3 grid((unsigned)((launch_count(a) * 64 + 255) / 256)), block(256);
   if (stop == PB_STOP_NONE)
     hipLaunchKernelGGL((fista_fast_kernel<S, KT, false, 0, true, 64>), grid, block, 0, st, a, tp);
   else

@@ -10,25 +10,44 @@
 //                           (perm[P-1] = first sparse problem, perm[P-2] = second, ...)
 //   work[P]                 number of dense problems
 //   work[P+1 .. P+1+nblk)   per-block dense counts, then their exclusive prefix (scratch)
+//
+// Round 5: the same three launches serve EVERY call of pb_fista_solve(_ex) that the matrix-pipe form can carry -- one
+// lambda for the batch or one per problem, with or without cost trace and stop rule (`lbda` may be nullptr: `lbda_s`
+// then holds for every problem) -- and, with the predicate "n_done[p] < 0", build the list of the problems a guard or
+// a certificate handed back, which the exact vector forms then re-solve at full occupancy instead of one flagged
+// problem per wave.  `plan_kernel` (one thread) turns the list lengths into launch plans (plan.h).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include "plan.h"
 
 namespace pb {
 
 constexpr int PATH_THREADS = 256, PATH_PER_THREAD = 16, PATH_PER_BLOCK = PATH_THREADS * PATH_PER_THREAD;
 
-__device__ __forceinline__ bool path_is_dense(const double* lbda, const double* lmax, int y_rep, double ratio, int p) {
-  return lbda[p] < ratio * lmax[p / y_rep];        // (lambda_max = 0, an all-zero series: sparse -- its solution is 0)
+// what puts a problem on the FRONT list
+struct ClassPred {
+  const double* lbda;      // per-problem lambdas or nullptr
+  double lbda_s;           // the one lambda of the batch (lbda == nullptr)
+  const double* lmax;      // lambda_max of every series
+  int y_rep;
+  double ratio;
+  const int32_t* n_done;   // != nullptr: the predicate is n_done[p] < 0 instead (handed-back problems)
+};
+
+__device__ __forceinline__ bool path_is_dense(const ClassPred& c, int p) {
+  if (c.n_done) return c.n_done[p] < 0;
+  const double lb = c.lbda ? c.lbda[p] : c.lbda_s;
+  return lb < c.ratio * c.lmax[p / c.y_rep];       // (lambda_max = 0, an all-zero series: sparse -- its solution is 0)
 }
 
 // dense problems of every block of 4 096
-__global__ __launch_bounds__(PATH_THREADS) void path_count_kernel(const double* lbda, const double* lmax, int y_rep,
-                                                                   double ratio, int P, int32_t* work) {
+__global__ __launch_bounds__(PATH_THREADS) void path_count_kernel(ClassPred cp, int P, int32_t* work) {
   __shared__ int part[PATH_THREADS / 64];
   const int p0 = blockIdx.x * PATH_PER_BLOCK + threadIdx.x * PATH_PER_THREAD;
   int c = 0;
-  for (int i = 0; i < PATH_PER_THREAD; ++i) c += (p0 + i < P && path_is_dense(lbda, lmax, y_rep, ratio, p0 + i)) ? 1 : 0;
+  for (int i = 0; i < PATH_PER_THREAD; ++i) c += (p0 + i < P && path_is_dense(cp, p0 + i)) ? 1 : 0;
   for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
   __syncthreads();
@@ -62,14 +81,13 @@ __global__ __launch_bounds__(PATH_THREADS) void path_scan_kernel(int P, int nblk
 }
 
 // the two lists
-__global__ __launch_bounds__(PATH_THREADS) void path_scatter_kernel(const double* lbda, const double* lmax, int y_rep,
-                                                                     double ratio, int P, int32_t* work) {
+__global__ __launch_bounds__(PATH_THREADS) void path_scatter_kernel(ClassPred cp, int P, int32_t* work) {
   __shared__ int buf[PATH_THREADS];
   const int p0 = blockIdx.x * PATH_PER_BLOCK + threadIdx.x * PATH_PER_THREAD;
   unsigned mask = 0;
   int c = 0;
   for (int i = 0; i < PATH_PER_THREAD; ++i)
-    if (p0 + i < P && path_is_dense(lbda, lmax, y_rep, ratio, p0 + i)) { mask |= 1u << i; ++c; }
+    if (p0 + i < P && path_is_dense(cp, p0 + i)) { mask |= 1u << i; ++c; }
   buf[threadIdx.x] = c;
   __syncthreads();
   for (int o = 1; o < PATH_THREADS; o <<= 1) {
@@ -85,6 +103,91 @@ __global__ __launch_bounds__(PATH_THREADS) void path_scatter_kernel(const double
     if (mask & (1u << i)) work[d++] = p;
     else work[P - 1 - (p - d)] = p;                // p - d = sparse problems before p
   }
+}
+
+// ---- launch plans of the two lists, made where their lengths are known ------------------------------------------
+struct PlanSpec {          // how a list is to be laid over the forms (the arguments of plan.h's planners)
+  int kind;                // 0: nothing, 1: plan_pieces_mfma (matrix-pipe form + vector remainder), 2: plan_pieces (vector forms)
+  int has_pair, has_wide, one_launch, one_stream, has_mfma2, beside_chunks;
+  double slots;
+};
+
+__device__ __forceinline__ void plan_list(const PlanSpec& sp, int n, int32_t* ranges) {
+  Piece pc[MAX_PIECES];
+  int npc = 0;
+  if (n > 0 && sp.kind == 1)
+    npc = plan_pieces_mfma(n, sp.has_pair != 0, sp.has_wide != 0, sp.one_launch != 0, sp.one_stream != 0, sp.has_mfma2 != 0,
+                           sp.beside_chunks, sp.slots, pc);
+  else if (n > 0 && sp.kind == 2)
+    npc = plan_pieces(n, sp.has_pair != 0, sp.has_wide != 0, sp.one_launch != 0, sp.one_stream != 0, sp.slots, pc);
+  if (plan_to_candidates(pc, npc, ranges) != 0) {
+    // (unreachable for the plans of plan.h; if it ever happened: everything on the one candidate that always exists)
+    for (int c = 0; c < 2 * CAND_COUNT; ++c) ranges[c] = 0;
+    const int c = sp.kind == 1 ? CAND_MFMA : CAND_FAST0;
+    ranges[2 * c + 1] = n;
+  }
+}
+
+// front list (its length: work[P]) -> ranges_front, back list (P - work[P]) -> ranges_back
+__global__ void plan_kernel(PlanSpec front, PlanSpec back, int P, const int32_t* work, int32_t* ranges_front, int32_t* ranges_back) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int nf = work[P];
+  if (ranges_front) plan_list(front, nf, ranges_front);
+  if (ranges_back) plan_list(back, P - nf, ranges_back);
+}
+
+// ---- lambda_max of every series, for the partition (float32 in, float64 out) ---------------------------------
+// || H^T y ||_inf with H^T y = T_c^T y, c = cumsum(h): (H^T y)[j] = sum_m h[m] s[j + m], s = suffix sums of y
+// (upper-triangular Toeplitz matrices commute).  One series per wave: its lanes hold strips of SL consecutive
+// samples, the suffix sums go through LDS (stride-SL reads: conflict-free for odd SL), the taps come as kernel
+// arguments.  Float32 arithmetic: the result only decides a class (ratio test at 13 %), and pb_lambda_max stays the
+// float64 answer for callers who want the number.
+constexpr int LMAX_KT = 64;
+struct LmaxTaps { float h[LMAX_KT]; };
+
+template <int SL>
+__global__ __launch_bounds__(256) void lmax_wave_kernel(const float* y, int64_t ldy, int V, int N, LmaxTaps tp, int K, double* out) {
+  extern __shared__ float lm_smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int v = blockIdx.x * 4 + wv;
+  if (v >= V) return;                                      // (wave-level synchronisation only below)
+  float* s = lm_smem + wv * (64 * SL + LMAX_KT);
+  const float* yrow = y + (int64_t)v * ldy;
+  float loc[SL];
+  float run = 0.0f;
+#pragma unroll
+  for (int j = SL - 1; j >= 0; --j) {
+    const int t = lane * SL + j;
+    run += t < N ? yrow[t] : 0.0f;
+    loc[j] = run;                                          // suffix sums inside the strip
+  }
+  float above = run;                                       // exclusive suffix over the lanes above
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float t = __shfl_down(above, o, 64);
+    above += (lane + o < 64) ? t : 0.0f;
+  }
+  above -= run;
+#pragma unroll
+  for (int j = 0; j < SL; ++j) s[lane * SL + j] = loc[j] + above;
+  if (lane < LMAX_KT) s[64 * SL + lane] = 0.0f;            // past the end: zeros
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float acc[SL];
+#pragma unroll
+  for (int j = 0; j < SL; ++j) acc[j] = 0.0f;
+  for (int k = 0; k < K; ++k) {                            // one scalar tap load per k, SL independent chains
+    const float hk = tp.h[k];
+#pragma unroll
+    for (int j = 0; j < SL; ++j) acc[j] = fmaf(hk, s[lane * SL + j + k], acc[j]);
+  }
+  float m = 0.0f;
+#pragma unroll
+  for (int j = 0; j < SL; ++j) m = fmaxf(m, lane * SL + j < N ? fabsf(acc[j]) : 0.0f);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if (lane == 0) out[v] = (double)m;
 }
 
 }  // namespace pb

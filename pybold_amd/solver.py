@@ -35,8 +35,10 @@ _FORCE = {None: 0, "generic": PB_FLAG_FORCE_GENERIC, "fast": PB_FLAG_FORCE_FAST,
           "valu": _lib.PB_FLAG_NO_MFMA, "valuseq": _lib.PB_FLAG_NO_MFMA | PB_FLAG_ONE_STREAM,
           "mfma": PB_FLAG_ONE_LAUNCH | _lib.PB_FLAG_FORCE_MFMA,
           # "mfma2": everything on the matrix-pipe form with each series split over two waves, one launch
-          # pb_fista_solve_path, measurement aids: only the dense list's launch / only the sparse list's
-          "path_dense": _lib.PB_FLAG_FORCE_MFMA, "path_sparse": PB_FLAG_FORCE_PAIR,
+          # a partitioned call, measurement aids: only the dense class is solved / only the sparse class
+          "path_dense": _lib.PB_FLAG_ONLY_DENSE, "path_sparse": _lib.PB_FLAG_ONLY_SPARSE,
+          # the host-side plan of round 4 (no partition on the device)
+          "nopart": _lib.PB_FLAG_NO_PARTITION, "nopartseq": _lib.PB_FLAG_NO_PARTITION | PB_FLAG_ONE_STREAM,
           "mfma2": _lib.PB_FLAG_FORCE_MFMA2, "mfma2only": _lib.PB_FLAG_FORCE_MFMA2 | _lib.PB_FLAG_CERT_NO_RESOLVE,
           "mfma2cert": _lib.PB_FLAG_FORCE_MFMA2 | PB_FLAG_FORCE_CERT,
           "mfma2certonly": _lib.PB_FLAG_FORCE_MFMA2 | PB_FLAG_FORCE_CERT | _lib.PB_FLAG_CERT_NO_RESOLVE,
@@ -207,9 +209,10 @@ def fista_solve(Y, hrf, lbda, step, n_iter, W0=None, want_J=False, stop=None,
     step  ``1 / L``
     W0    optional float64 CUDA ``(P, N)`` warm start (not modified)
     stop  None | "loops" (_loops_deconv rule) | "window" (deconv rule)
-    lmax  optional float64 CUDA ``(V,)``: :func:`lambda_max` of every series.  With per-problem ``lbda`` it turns a
-          plain solve into ``pb_fista_solve_path``: the problems with ``lbda < dense_ratio * lmax`` (default 0.13) run on
-          the matrix-pipe form, the sparse rest on the float32 vector form -- a regularisation path, BASELINE config 5
+    lmax  optional float64 CUDA ``(V,)``: :func:`lambda_max` of every series, if the caller has it (a regularisation
+          path, BASELINE config 5, does); otherwise the library computes it when it partitions the call: the problems
+          with ``lbda < dense_ratio * lmax`` (default 0.13) run on the matrix-pipe form, the sparse rest on the float32
+          vector forms (``pb_fista_solve_ex``; any call shape since round 5)
     Returns ``(W float64 (P, N), J float32 (P, n_iter) or None, n_done int32 (P,))``.
     """
     lib = _lib.load()
@@ -261,29 +264,26 @@ def fista_solve(Y, hrf, lbda, step, n_iter, W0=None, want_J=False, stop=None,
                 _stream_ptr(dev))
         _lib.check(rc, "pb_fista_solve_d")
         return W, J, n_done
-    if lmax is not None and lbda_dev is not None and not want_J and _STOP[stop] == PB_STOP_NONE:
+    # Every float32 call goes through pb_fista_solve_ex with a workspace: where the matrix-pipe form can carry the call
+    # (129..310 scans, >= 4 096 problems) the problems are partitioned on the device -- dense class on the matrix
+    # pipe, sparse class (lambda near lambda_max) on the float32 vector forms -- so that nothing is solved twice.
+    if lmax is not None:
         lmax = lmax.to(device=dev, dtype=torch.float64).contiguous().ravel()
         if lmax.numel() != V:
             raise ValueError("lmax must have one entry per series (%d)" % V)
-        work = torch.empty((int(lib.pb_fista_path_work_len(P)),), dtype=torch.int32, device=dev)
-        with torch.cuda.device(dev):
-            rc = lib.pb_fista_solve_path(
-                Y.data_ptr(), _ld(Y), int(y_rep), W.data_ptr(), _ld(W), P, N, taps.ctypes.data, taps_dev.data_ptr(),
-                taps.size, float(step), lbda_dev.data_ptr(), lmax.data_ptr(), float(dense_ratio), betas.data_ptr(),
-                int(n_iter), n_done.data_ptr(), work.data_ptr(), work.numel(), _FORCE[force] | cold, _stream_ptr(dev))
-        _lib.check(rc, "pb_fista_solve_path")
-        return W, J, n_done
+    work = torch.empty((int(lib.pb_fista_work_len(P, int(y_rep))),), dtype=torch.int32, device=dev)
     _warn_if_slow_kernel(lib, N, taps.size, P, want_J, stop, wind, _FORCE[force])
     with torch.cuda.device(dev):
-        rc = lib.pb_fista_solve(
+        rc = lib.pb_fista_solve_ex(
             Y.data_ptr(), _ld(Y), int(y_rep), W.data_ptr(), _ld(W), P, N,
             taps.ctypes.data, taps_dev.data_ptr(), taps.size, float(step), lbda_scalar,
             lbda_dev.data_ptr() if lbda_dev is not None else None,
             betas.data_ptr(), int(n_iter),
             J.data_ptr() if J is not None else None, _ld(J) if J is not None else 0,
             _STOP[stop], float(tol), int(wind), n_done.data_ptr(), _FORCE[force] | cold,
-            _stream_ptr(dev))
-    _lib.check(rc, "pb_fista_solve")
+            _stream_ptr(dev), lmax.data_ptr() if lmax is not None else None, float(dense_ratio),
+            work.data_ptr(), work.numel())
+    _lib.check(rc, "pb_fista_solve_ex")
     return W, J, n_done
 
 
@@ -320,36 +320,28 @@ class FistaPlan:
         self.n_iter = int(n_iter)
         self.betas = _betas_on(self.dev, self.n_iter)
         self.flags = _FORCE[force]
-        # regularisation path (per-problem lambdas + lambda_max of every series): pb_fista_solve_path
-        self.lmax, self.work, self.dense_ratio = None, None, float(dense_ratio)
-        if lmax is not None and self.lbda_dev is not None:
+        # workspace of the device-side partition (pb_fista_solve_ex); lambda_max of every series if the caller has it
+        self.lmax, self.dense_ratio = None, float(dense_ratio)
+        if lmax is not None:
             self.lmax = lmax.to(device=self.dev, dtype=torch.float64).contiguous().ravel()
             if self.lmax.numel() != V:
                 raise ValueError("lmax must have one entry per series (%d)" % V)
-            self.work = torch.empty((int(self.lib.pb_fista_path_work_len(self.P)),), dtype=torch.int32, device=self.dev)
+        self.work = torch.empty((int(self.lib.pb_fista_work_len(self.P, self.y_rep)),), dtype=torch.int32, device=self.dev)
 
     def launch(self, cold=False):
         """Only the solver launch: the iterate continues from its current value, or
         (``cold``) starts from 0 without being read."""
-        if self.lmax is not None:
-            with torch.cuda.device(self.dev):
-                rc = self.lib.pb_fista_solve_path(
-                    self.Y.data_ptr(), _ld(self.Y), self.y_rep, self.W.data_ptr(), _ld(self.W), self.P, self.N,
-                    self.taps.ctypes.data, self.taps_dev.data_ptr(), self.taps.size, self.step, self.lbda_dev.data_ptr(),
-                    self.lmax.data_ptr(), self.dense_ratio, self.betas.data_ptr(), self.n_iter, self.n_done.data_ptr(),
-                    self.work.data_ptr(), self.work.numel(), self.flags | (PB_FLAG_COLD_START if cold else 0),
-                    _stream_ptr(self.dev))
-            _lib.check(rc, "pb_fista_solve_path")
-            return
         # the library finds its per-device side stream and wave count through the CURRENT device
         with torch.cuda.device(self.dev):
-            rc = self.lib.pb_fista_solve(
+            rc = self.lib.pb_fista_solve_ex(
                 self.Y.data_ptr(), _ld(self.Y), self.y_rep, self.W.data_ptr(), _ld(self.W), self.P,
                 self.N, self.taps.ctypes.data, self.taps_dev.data_ptr(), self.taps.size, self.step,
                 self.lbda, self.lbda_dev.data_ptr() if self.lbda_dev is not None else None,
                 self.betas.data_ptr(), self.n_iter, None, 0, PB_STOP_NONE, 0.0, 0,
-                self.n_done.data_ptr(), self.flags | (PB_FLAG_COLD_START if cold else 0), _stream_ptr(self.dev))
-        _lib.check(rc, "pb_fista_solve")
+                self.n_done.data_ptr(), self.flags | (PB_FLAG_COLD_START if cold else 0), _stream_ptr(self.dev),
+                self.lmax.data_ptr() if self.lmax is not None else None, self.dense_ratio,
+                self.work.data_ptr(), self.work.numel())
+        _lib.check(rc, "pb_fista_solve_ex")
 
     def run(self):
         """Cold start (what ``deconv`` does, pybold/bold_signal.py:57): solve from w = 0."""

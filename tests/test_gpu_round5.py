@@ -132,3 +132,114 @@ def test_negative_lambda_is_the_float64_path_only(solver, golden):
         solver.fista_solve(Yd.float(), hrf, -0.7, 1.0 / lip, 60)
     with pytest.raises(ValueError):
         solver.fista_solve(Yd.float(), hrf, np.array([-0.7]), 1.0 / lip, 60)
+
+
+# --------------------------------------------------------------------------------------------
+# Round 5: partition before solving, for every call shape (pb_fista_solve_ex)
+# --------------------------------------------------------------------------------------------
+def _mixed_batch(V, seed):
+    from pybold_amd import data
+    hrf = orc.spm_hrf(1.0, 1.0, 30.0)[0]
+    Y, _, _ = data.gen_rnd_bloc_bold_batch(V, dur=5, tr=1.0, hrf=hrf, nb_events=5, avg_dur=12.0, std_dur=1.0, snr=1.0, seed=seed)
+    lip = 0.9 * orc.spectral_radius_est(orc._MatrixFreeH(hrf), np.random.RandomState(0).randn(Y.shape[1]))
+    return Y, hrf, 1.0 / lip
+
+
+def _oracle_rows(Y, hrf, lam, step, n_it, rows):
+    from oracle import c_oracle
+    lam_rows = lam[rows] if np.ndim(lam) else lam
+    W, _, _ = c_oracle.fista_batch(Y[rows].cpu().numpy().astype(np.float64), hrf, lam_rows, step, n_it, threads=16)
+    return W
+
+
+def test_partition_before_solving_every_call_shape(solver):
+    """20 000 voxels with ONE scalar lambda placed at the batch's median of 0.13 lambda_max,v: half of the problems are
+    dense (matrix pipe), half sparse (vector forms).  The partitioned call -- plain, with the cost trace, with the
+    window rule as certificate, with the _loops_deconv rule, with per-problem lambdas with and without the caller's
+    lambda_max -- returns what the vector dispatch returns (<= 4e-6 per problem: two arithmetics), every n_done set,
+    and a random sample equals the C float64 oracle within eps = 1e-5."""
+    V, n_it = 20000, 300
+    Y, hrf, step = _mixed_batch(V, 11)
+    lmax = solver.lambda_max(Y, hrf)
+    lam_s = float((0.13 * lmax).median())
+    rows = np.random.RandomState(3).choice(V, 256, replace=False)
+    ref = _oracle_rows(Y, hrf, lam_s, step, n_it, rows)
+    ok = np.linalg.norm(ref, axis=1) > 0
+    for kw in (dict(), dict(want_J=True), dict(want_J=True, stop="window", tol=1e-6, wind=6), dict(stop="window", tol=1e-6, wind=6)):
+        W, J, nd = solver.fista_solve(Y, hrf, lam_s, step, n_it, **kw)
+        Wv, Jv, ndv = solver.fista_solve(Y, hrf, lam_s, step, n_it, force="valu", **kw)
+        Wn, Jn, ndn = solver.fista_solve(Y, hrf, lam_s, step, n_it, force="nopart", **kw)
+        assert int(nd.min()) == n_it and int(nd.max()) == n_it, (kw, int(nd.min()), int(nd.max()))
+        scale = Wv.norm(dim=1).clamp_min(1e-300)
+        e_v = float(((W - Wv).norm(dim=1) / scale).max())
+        e_n = float(((Wn - Wv).norm(dim=1) / scale).max())
+        e_o = rel_rows(W[rows].cpu().numpy()[ok], ref[ok]).max()
+        print("partitioned %-60s vs vector dispatch %.2e (round-4 dispatch: %.2e), vs oracle %.2e" % (kw, e_v, e_n, e_o))
+        assert e_v < 4e-6 and e_o < 1e-5, kw
+        if J is not None:
+            assert bool(torch.isfinite(J).all())
+            assert float(((J - Jv).abs() / Jv.abs().clamp_min(1e-30)).max()) < 1e-4
+    # the _loops_deconv rule: stop iterations and iterates of the exact rule
+    Wl, _, ndl = solver.fista_solve(Y, hrf, lam_s, step, n_it, stop="loops", tol=2e-3)
+    Wlv, _, ndlv = solver.fista_solve(Y, hrf, lam_s, step, n_it, stop="loops", tol=2e-3, force="valu")
+    assert int((ndl - ndlv).abs().max()) <= 1 and float((ndl != ndlv).float().mean()) < 0.01      # (criterion on 22-bit operators: ADVICE r4)
+    same = (ndl == ndlv)
+    assert float(((Wl - Wlv).norm(dim=1) / Wlv.norm(dim=1).clamp_min(1e-300))[same].max()) < 1e-5
+    # per-problem lambdas: a path of three values per voxel around the class boundary
+    c = torch.tensor([0.02, 0.13, 0.5], dtype=torch.float64, device=Y.device)
+    lam_p = (lmax[:, None] * c[None, :]).reshape(-1)
+    for lm in (None, lmax):
+        Wp, _, ndp = solver.fista_solve(Y, hrf, lam_p, step, n_it, y_rep=3, lmax=lm)
+        Wpv, _, _ = solver.fista_solve(Y, hrf, lam_p, step, n_it, y_rep=3, force="valu")
+        assert int(ndp.min()) == n_it
+        sc = Wpv.norm(dim=1)
+        nz = sc > 0
+        assert float(((Wp - Wpv).norm(dim=1)[nz] / sc[nz]).max()) < 4e-6
+        assert bool((Wp[~nz] == 0).all())
+
+
+def test_partition_extremes_and_small_lists(solver):
+    """All dense, all sparse, one class of a single problem, a handed-back list (constant series at lambda_max / 10 fail
+    the accuracy guard) -- and the measurement aids PB_FLAG_ONLY_DENSE / _ONLY_SPARSE leave the other class untouched."""
+    V, n_it = 9000, 200
+    Y, hrf, step = _mixed_batch(V, 5)
+    lmax = solver.lambda_max(Y, hrf)
+    ref_rows = np.arange(0, V, 97)
+    for c, what in ((0.01, "all dense"), (0.9, "all sparse")):
+        lam = lmax * c
+        W, _, nd = solver.fista_solve(Y, hrf, lam, step, n_it, lmax=lmax)
+        ref = _oracle_rows(Y, hrf, lam.cpu().numpy(), step, n_it, ref_rows)
+        okr = np.linalg.norm(ref, axis=1) > 0
+        assert int(nd.min()) == n_it and rel_rows(W[ref_rows].cpu().numpy()[okr], ref[okr]).max() < 1e-5, what
+    lam = lmax * 0.9
+    lam[1234] = lmax[1234] * 0.01                       # a dense class of ONE problem
+    W, _, nd = solver.fista_solve(Y, hrf, lam, step, n_it, lmax=lmax)
+    ref = _oracle_rows(Y, hrf, lam.cpu().numpy(), step, n_it, np.array([1233, 1234, 1235]))
+    assert int(nd.min()) == n_it and rel_rows(W[1233:1236].cpu().numpy(), ref).max() < 1e-5
+    # measurement aids
+    lam = torch.where(torch.arange(V, device=Y.device) % 2 == 0, lmax * 0.01, lmax * 0.9)
+    W0 = torch.full((V, Y.shape[1]), 7.0, dtype=torch.float64, device=Y.device)
+    Wd, _, _ = solver.fista_solve(Y, hrf, lam, step, n_it, lmax=lmax, W0=W0, force="path_dense")
+    Ws, _, _ = solver.fista_solve(Y, hrf, lam, step, n_it, lmax=lmax, W0=W0, force="path_sparse")
+    assert bool((Wd[1::2] == 7.0).all()) and bool((Ws[0::2] == 7.0).all())
+    assert not bool((Wd[0::2] == 7.0).all(dim=1).any()) and not bool((Ws[1::2] == 7.0).all(dim=1).any())
+    # handed-back problems: constant series are dense by the ratio test but fail the accuracy guard at the end
+    Yc = Y.clone()
+    Yc[::3] = 5.0
+    lmc = solver.lambda_max(Yc, hrf)
+    lam = lmc * 0.1
+    W, _, nd = solver.fista_solve(Yc, hrf, lam, step, n_it, lmax=lmc)
+    Wv, _, _ = solver.fista_solve(Yc, hrf, lam, step, n_it, force="valu")
+    _, _, ndo = solver.fista_solve(Yc, hrf, lam, step, n_it, force="mfmaonly")
+    assert int(nd.min()) == n_it
+    print("handed back by the matrix-pipe pass: %.1f %% of %d" % (100.0 * float((ndo < 0).float().mean()), V))
+    sc = Wv.norm(dim=1).clamp_min(1e-300)
+    assert float(((W - Wv).norm(dim=1) / sc).max()) < 1e-5
+    flagged = ndo < 0
+    assert bool(flagged.any())
+    # re-solved rows = an exact vector form's, bit for bit (which one -- single row or one problem per wave -- the
+    # device-side plan of the handed-back list decides from its length)
+    W1, _, _ = solver.fista_solve(Yc, hrf, lam, step, n_it, force="fast1")
+    Ww, _, _ = solver.fista_solve(Yc, hrf, lam, step, n_it, force="wide")
+    same = (W[flagged] == W1[flagged]).all(dim=1) | (W[flagged] == Ww[flagged]).all(dim=1)
+    assert bool(same.all())

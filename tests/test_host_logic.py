@@ -208,3 +208,54 @@ def test_large_batch_oracle_ops_match_the_pinned_ones():
     Ws, Wf = slow.z_step(Y, taps, 0.4, 25, W0.clone()), fast.z_step(Y, taps, 0.4, 25, W0.clone())
     np.testing.assert_allclose(Wf.numpy(), Ws.numpy(), rtol=1e-10, atol=1e-14)
     np.testing.assert_allclose(fast.normal_eq(Wf, Y, 27).numpy(), slow.normal_eq(Ws, Y, 27).numpy(), rtol=1e-10)
+
+
+def test_device_side_plans_tile_every_list_length():
+    """Round 5: a call partitioned on the device lays each of its lists (dense class, sparse class, handed-back problems)
+    over a STATIC sequence of candidate launches whose slot ranges a one-thread kernel computes from the list length
+    (csrc/plan.h; the same functions, host build, behind pb_fista_list_plan).  For every list length: the candidates'
+    ranges tile [0, n) exactly once, every range fits the grid the host sizes for that candidate, nothing lands on a
+    candidate the host would not launch (no pair form / no one-problem-per-wave form / one stream), and a list of n problems
+    gets the forms pb_fista_plan_ex gives a call of n problems."""
+    import ctypes
+    from pybold_amd import _lib
+    lib = _lib.load()
+    NC = 10
+    MFMA, PAIR0, FAST0, MFMA2, PAIR1, FAST1, WIDE, SW0, SW1, SF = range(NC)
+    rg, bd = (ctypes.c_int32 * (2 * NC))(), (ctypes.c_int32 * NC)()
+    lengths = sorted(set(list(range(0, 20000, 7)) + list(range(16384 - 40, 16384 + 40)) + list(range(32768 - 40, 32768 + 40)) +
+                         [4608, 4609, 8192, 8193, 9216, 9217, 10240, 10241, 12288, 14336, 98304, 100000, 123457, 1000000]))
+    for kind in (1, 2):
+        for has_pair in (0, 1):
+            for has_wide in (0, 1):
+                for one_stream in (0, 1):
+                    for has_mfma2 in ((0, 1) if kind == 1 else (0,)):
+                        for n in lengths:
+                            rc = lib.pb_fista_list_plan(kind, n, 1000000, has_pair, has_wide, one_stream, has_mfma2, 2, rg, bd)
+                            assert rc == 0, (kind, has_pair, has_wide, one_stream, has_mfma2, n, lib.pb_last_error())
+                            r = [(rg[2 * c], rg[2 * c + 1]) for c in range(NC)]
+                            live = sorted((a, b) for a, b in r if b > a)
+                            assert (live[0][0] if live else 0) == 0 and (live[-1][1] if live else 0) == n
+                            assert all(live[i][1] == live[i + 1][0] for i in range(len(live) - 1)), (n, r)
+                            for c, (a, b) in enumerate(r):
+                                assert b - a <= bd[c], (kind, n, c, r, list(bd))
+                            if kind == 2 or not has_mfma2:
+                                assert r[MFMA2] == (0, 0)
+                            if kind == 2:
+                                assert r[MFMA] == (0, 0)
+                            if not has_pair:
+                                assert r[PAIR0] == (0, 0) and r[PAIR1] == (0, 0)
+                            if not has_wide:
+                                assert r[WIDE] == (0, 0) and r[SW0] == (0, 0) and r[SW1] == (0, 0)
+                            if one_stream:
+                                assert r[SW0] == (0, 0) and r[SW1] == (0, 0) and r[SF] == (0, 0)
+    # the plan of a list = the plan of a call of that many problems (N = 300, K = 30: pair form, one-problem waves, split form)
+    nm, mf, tf = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    for n in (5000, 8192, 10000, 12500, 16384, 25000, 50000, 98304, 100000):
+        lib.pb_fista_plan_ex(300, 30, n, 0, 6, _lib.PB_FLAG_NO_PARTITION, ctypes.byref(nm), ctypes.byref(mf), ctypes.byref(tf))
+        lib.pb_fista_list_plan(1, n, n, 1, 1, 0, 1, 2, rg, bd)
+        whole = rg[2 * MFMA + 1] - rg[2 * MFMA]
+        if mf.value == 4:
+            assert whole == nm.value, (n, whole, nm.value)
+        else:
+            assert nm.value == 0 or whole == 0, (n, whole, nm.value, mf.value)
