@@ -657,12 +657,16 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
           if (fire) {
             lactive = false;
             if (live && !badq) {
+              // (addresses and bounds made HERE, from laundered values: hoisted out of the loop as invariants they
+              // cost ~95 registers through the whole solve -- the NB = 10 variant spilled 156 B per lane, round 4)
               double* wrow = a.w + (int64_t)p * a.ldw;
+              int tbv = tb;
+              asm volatile("" : "+v"(wrow), "+v"(tbv));
 #pragma unroll
               for (int q = 0; q < NB; ++q)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                  const int t = MFMA_SPAN * q + tb + j;
+                  const int t = MFMA_SPAN * q + tbv + j;
                   if (t < a.N && !(j == 7 && g3)) wrow[t] = w[q][j] * (double)inv_sigma;
                 }
             }

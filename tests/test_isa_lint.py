@@ -29,3 +29,17 @@ def test_no_spill_under_a_partial_exec_mask(target):
     assert len(names) == len(scratch) and len(names) >= 4
     plain = [s for n, s in zip(names, scratch) if n.endswith("ILi10ELb0ELb0ELb0ELi2ELb0EEEvNS_9FistaArgsENS_8MfmaTapsE") or "mfma2_kernel" in n]
     assert plain and max(plain) == 0, list(zip(names, scratch))
+
+
+def test_no_matrix_pipe_variant_uses_scratch():
+    """Every instantiation capi.hip can dispatch -- fista_mfma_kernel<5..10> x {plain, cost trace, certificate, taps from
+    device memory, three near tiles, _loops_deconv rule} and fista_mfma2_kernel<a,b> x {plain, cost trace, certificate,
+    taps from device memory}: 112 kernels -- runs without scratch.  (Round 4 shipped `<10, ..., LOOPS>` with 156 B per
+    lane: store addresses of the in-loop write-out hoisted out of the solve loop.)  The reports are written by the compile
+    that makes each object (csrc/Makefile)."""
+    if subprocess.call(["which", "hipcc"], stdout=subprocess.DEVNULL) != 0 and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    subprocess.check_call(["make", "-s", "-j8", "-C", CSRC])
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mfma_register_table.py"), "--check"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    assert int(out.stdout.strip().splitlines()[-1].split()[0]) >= 100, out.stdout
