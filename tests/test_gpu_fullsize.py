@@ -253,7 +253,13 @@ def test_four_million_problems_in_one_call(setup):
     assert rel_rows_t(W[torch.from_numpy(rows).cuda()].cpu(), torch.from_numpy(Wo)) < 1e-5
     # odd symmetry across the two halves of the batch (same lambda index): bitwise
     half = Y.shape[0] * reps
-    assert torch.equal(W[:1000 * reps], -W[half:half + 1000 * reps])
+    # (the default dispatch partitions the call on the device since round 5: a problem and its mirror image sit at
+    # different places of their lists and may run on different kernel forms -- equal within the forms' accuracy; on the
+    # vector dispatch every row runs the same arithmetic wherever it sits: bitwise)
+    a, b = W[:1000 * reps], -W[half:half + 1000 * reps]
+    assert float(((a - b).norm(dim=1) / a.norm(dim=1).clamp_min(1e-300)).max()) < 4e-6
+    Wv, _, _ = solver.fista_solve(Yb, hrf, lam, 1.0 / LIP, n_iter, y_rep=reps, force="valu")
+    assert torch.equal(Wv[:1000 * reps], -Wv[half:half + 1000 * reps])
     del W
     # the guard, through the raw C ABI (no 80 GB iterate needed: it fires before any access)
     from pybold_amd import _lib

@@ -265,8 +265,11 @@ def test_regularisation_path_partition(solver, golden):
     lam = (lmax[:, None] * grid[None, :]).reshape(-1)
     lam[17 * L:18 * L] = 1.0
     P = V * L
-    Wv, _, ndv = solver.fista_solve(Y, hrf, lam, 1.0 / lip, 300, y_rep=L)
+    Wv, _, ndv = solver.fista_solve(Y, hrf, lam, 1.0 / lip, 300, y_rep=L, force="valu")       # (the vector dispatch)
     W, _, nd = solver.fista_solve(Y, hrf, lam, 1.0 / lip, 300, y_rep=L, lmax=lmax)
+    # without the caller's lambda_max the library makes its own (float32 pass) and partitions the same way (round 5)
+    W2, _, _ = solver.fista_solve(Y, hrf, lam, 1.0 / lip, 300, y_rep=L)
+    assert float(((W2 - W).norm(dim=1) / W.norm(dim=1).clamp_min(1e-300)).max()) < 4e-6
     assert int(nd.min()) == 300 and int(nd.max()) == 300 and bool(torch.isfinite(W).all())
     nrm = Wv.norm(dim=1)
     assert bool((W[nrm == 0] == 0).all())                      # lambda_max and the all-zero series: exactly 0
