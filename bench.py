@@ -344,7 +344,7 @@ def run(args):
         # regularisation path partitioned on the device (pb_fista_solve_path): two big launches per step -- the dense
         # class on the matrix-pipe form, the sparse class on the pair form; each is timed on its own (same lists), the
         # longer one is the step's dominant kernel
-        n_dense = int(plan.work[P].item())
+        n_dense = int((lam < 0.13 * lmax5.repeat_interleave(y_rep)).sum().item())     # (the library's own test, path.h)
         _, _, nd0 = solver.fista_solve(Y, hrf, lam, step, n_iter, y_rep=y_rep, lmax=lmax5, force="noresolve")
         n_back = int((nd0 < 0).sum())
         t_cls = {}
