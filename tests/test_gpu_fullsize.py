@@ -219,9 +219,9 @@ def test_config4_shared_hrf_full_size():
     W0, h0, d0 = distributed.bd_shared(Y4, t_r, lbda=1.7, theta_0=2.0, hrf_dur=dur, nb_iter=0, nb_inner=100)
     h20 = orc.spm_hrf(2.0, t_r, dur, False)[0]
     np.testing.assert_allclose(h0, h20, rtol=1e-10, atol=1e-14)
-    idx = np.random.RandomState(4).choice(V4, 64, replace=False)
+    idx = np.random.RandomState(4).choice(V4, 1024, replace=False)
     err = sample_vs_oracle(W0, Y4, idx, h20, 1.7, 1.0 / gram_frobenius(h20, 300), 100)
-    print("config 4: first z-step, max rel err of 64 voxels vs C oracle %.2e" % err)
+    print("config 4: first z-step, max rel err of 1024 voxels vs C oracle %.2e" % err)
     assert err < 1e-5
 
 
@@ -271,3 +271,63 @@ def test_four_million_problems_in_one_call(setup):
                             taps.ctypes.data, None, taps.size, 1.0 / LIP, 1.0, None, betas.data_ptr(), 1,
                             None, 0, 0, 0.0, 0, None, 0, None)
     assert rc != 0 and b"2^25" in lib.pb_last_error()
+
+
+# ---- round 5: the big oracle samples inside the driver-run record -------------------
+def _errs_vs_oracle(solver, W, Y, idx, hrf, lbda, step, n_iter, y_rep=1, threads=16):
+    """max relative L2 over the sampled problems on diff_z, z and x against the C float64 oracle."""
+    sel = torch.from_numpy(idx).cuda()
+    Ys = Y[torch.from_numpy(idx // y_rep).cuda()].cpu().numpy().astype(np.float64)
+    lb = lbda if np.ndim(lbda) == 0 else np.asarray(lbda)[idx]
+    Wo, _, _ = c_oracle.fista_batch(Ys, hrf, lb, step, n_iter, threads=threads)
+    Wg = W[sel].contiguous()
+    Xg, Zg = solver.fista_outputs(Wg, hrf)
+    Zo = np.cumsum(Wo, axis=1)
+    Xo = np.stack([np.convolve(z, hrf)[:len(z)] for z in Zo])
+    nz = np.linalg.norm(Wo, axis=1) > 0
+
+    def worst(a, b):
+        return float((np.linalg.norm(a - b, axis=1)[nz] / np.linalg.norm(b, axis=1)[nz]).max())
+    assert bool((Wg.cpu().numpy()[~nz] == 0).all())                 # exact zeros where the oracle has them
+    return worst(Wg.cpu().numpy(), Wo), worst(Zg.cpu().numpy(), Zo), worst(Xg.cpu().numpy(), Xo)
+
+
+def test_config3_four_thousand_voxels_against_the_oracle(setup):
+    """BASELINE config 3 as the bench runs it (100 000 voxels, lambda = 1, 500 iterations, default dispatch): 4 352
+    random voxels against the C oracle on diff_z, z AND x -- 256 of them from the remainder launch (the voxels behind
+    the whole matrix-pipe rounds), 1 024 from the last round of the main launch, 3 072 from anywhere."""
+    solver, hrf, Y = setup
+    step = 1.0 / LIP
+    W, _, nd = solver.fista_solve(Y, hrf, 1.0, step, 500)
+    assert int(nd.min()) == 500 and int(nd.max()) == 500
+    n_main, main, tail = solver.launch_plan(N, len(hrf), V, force="nopart")
+    assert 0 < n_main < V and "matrix pipe" in main
+    rng = np.random.RandomState(2025)
+    idx = np.unique(np.r_[n_main + rng.choice(V - n_main, 256, replace=False),
+                          n_main - 16384 + rng.choice(16384, 1024, replace=False),
+                          rng.choice(V, 3072, replace=False)])
+    e = _errs_vs_oracle(solver, W, Y, idx, hrf, 1.0, step, 500)
+    print("config 3: %d voxels vs the C oracle: diff_z %.2e  z %.2e  x %.2e" % ((len(idx),) + e))
+    assert max(e) < 1e-5, e
+
+
+def test_configs_2_and_5_a_thousand_problems_against_the_oracle(setup):
+    """Config 2 (10 000 voxels) and config 5 (50 000 voxels x 20 lambdas = logspace(-2, 0, 20) lambda_max,v, partitioned on
+    the device): 1 024 random problems each against the C oracle on diff_z, z, x."""
+    solver, hrf, Y = setup
+    step = 1.0 / LIP
+    Y2 = Y[:10000].contiguous()
+    W2, _, _ = solver.fista_solve(Y2, hrf, 1.0, step, 500)
+    idx = np.random.RandomState(7).choice(10000, 1024, replace=False)
+    e2 = _errs_vs_oracle(solver, W2, Y2, idx, hrf, 1.0, step, 500)
+    print("config 2: 1024 voxels vs the C oracle: diff_z %.2e  z %.2e  x %.2e" % e2)
+    assert max(e2) < 1e-5, e2
+    Y5 = Y[:50000].contiguous()
+    lmax = solver.lambda_max(Y5, hrf)
+    lam = (lmax[:, None] * torch.logspace(-2.0, 0.0, 20, dtype=torch.float64, device="cuda")[None, :]).reshape(-1)
+    W5, _, nd5 = solver.fista_solve(Y5, hrf, lam, step, 500, y_rep=20, lmax=lmax)
+    assert int(nd5.min()) == 500
+    idx5 = np.random.RandomState(8).choice(50000 * 20, 1024, replace=False)
+    e5 = _errs_vs_oracle(solver, W5, Y5, idx5, hrf, lam.cpu().numpy(), step, 500, y_rep=20)
+    print("config 5: 1024 problems vs the C oracle: diff_z %.2e  z %.2e  x %.2e" % e5)
+    assert max(e5) < 1e-5, e5
