@@ -63,7 +63,7 @@ extern "C" {
                                      of the blind loop but the last): their errors, relative 1e-5..1e-4 of a still tiny
                                      iterate, are forgotten by the warm-started solves that follow */
 #define PB_FLAG_FORCE_MFMA2 65536u /* the matrix-pipe form with every series split over two waves (fista_mfma2_kernel:
-                                     161..640 scans, HRFs of up to 33 taps, plain solves), one launch */
+                                     129..640 scans, HRFs of up to 33 taps, plain solves), one launch */
 #define PB_FLAG_NO_MFMA 8192u      /* plain solves: never the matrix-pipe form (fista_mfma_kernel), vector forms only */
 #define PB_FLAG_FORCE_CERT 1024u   /* PB_STOP_WINDOW, wind = 6: certificate path whatever tol * n_iter is */
 #define PB_FLAG_NO_PARTITION 4096u  /* never partition a call on the device (see pb_fista_solve_ex): the host-side plan of round 4 */

@@ -553,7 +553,7 @@ int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mod
   const bool mfma_plain = stop_mode == PB_STOP_NONE && mfma_serves_plain(N, K);
   const bool mfma2_ok = (stop_mode == PB_STOP_NONE || (stop_mode == PB_STOP_WINDOW && wind == 6)) && pick_mfma2(N, K) != nullptr;
   if (mfma2_ok && mfma2_serves_long(N, K) && P >= MFMA2_LONG_MIN_P && (stop_mode == PB_STOP_NONE || pick_wide(N, K)->S <= 20))
-    return mfma2_long_base(P, false) > 0 ? FORM_MFMA2 : FORM_WIDE;
+    return mfma2_long_base(P, false) > 0 ? FORM_MFMA2 : ((pick_fast(N, K) && N <= 320) ? FORM_FAST1 : FORM_WIDE);   // (the solve's own backup form)
   if (const FastEntry* se = pick_split(N, K))
     if (!mfma_plain && P >= SPLIT_MIN_P && pair_carries(se, stop_mode, wind) && (stop_mode == PB_STOP_NONE || pick_wide(N, K)))
       return FORM_PAIR;
@@ -592,8 +592,9 @@ int pb_fista_plan_ex(int N, int K, int P, int stop_mode, int wind, unsigned flag
   if (mfma2_ok && mfma2_serves_long(N, K) && (P >= MFMA2_LONG_MIN_P || (flags & PB_FLAG_FORCE_MFMA2)) &&
       (stop_mode == PB_STOP_NONE || pick_wide(N, K)->S <= 20)) {
     const int base = mfma2_long_base(P, (flags & (PB_FLAG_ONE_LAUNCH | PB_FLAG_FORCE_MFMA2)) != 0);
-    if (base > 0 && base < P) { nm = base; mf = FORM_MFMA2; tf = FORM_WIDE; }
-    else tf = base > 0 ? FORM_MFMA2 : FORM_WIDE;
+    const int backup_form = (pick_fast(N, K) && N <= 320) ? FORM_FAST1 : FORM_WIDE;      // what pb_fista_solve uses behind the split form
+    if (base > 0 && base < P) { nm = base; mf = FORM_MFMA2; tf = backup_form; }
+    else tf = base > 0 ? FORM_MFMA2 : backup_form;
   } else if (mfma2_ok && (flags & PB_FLAG_FORCE_MFMA2) && P >= 1) {
     tf = FORM_MFMA2;
   } else if (se && !mfma_plain && pair_carries(se, stop_mode, wind) && (stop_mode == PB_STOP_NONE || pick_wide(N, K))) {

@@ -179,8 +179,9 @@ __device__ __forceinline__ f4 mma3(const Frag& A, const Frag& B, f4 acc) {
 #ifndef PB_MFMA_KATTR
 #define PB_MFMA_KATTR
 #endif
-// LOOPS: the _loops_deconv stop rule (pybold/bold_signal.py:267-273), EXACT: ||w_{k+1} - u_k|| / (||w_{k+1}|| + 1e-10)
-//   < tol from the fourth iteration on.  With w_{k+1} = u_k - (1 + beta) d, d = clamp(u_k, +-th), the numerator is
+// LOOPS: the _loops_deconv stop rule (pybold/bold_signal.py:267-273), evaluated in full (not certified), in float64,
+//   on the iterate of the 22-bit operators: ||w_{k+1} - u_k|| / (||w_{k+1}|| + 1e-10) < tol from the fourth iteration on
+//   (a criterion within ~1e-6 of tol may cross one iteration apart from the float64 reference).  With w_{k+1} = u_k - (1 + beta) d, d = clamp(u_k, +-th), the numerator is
 //   (1 + beta) ||d||: two float64 multiply-adds per sample next to the update.  A problem that meets the rule is
 //   written out at that moment (after a range / accuracy check of its own) and its lanes keep iterating, results
 //   discarded -- as in fista_fast.h.  Plain variant only (no cost trace, taps as kernel arguments, two near tiles).

@@ -267,6 +267,17 @@ class BdSharedGraph:
         except Exception as e:                   # capture refused: keep the eager loop
             self.graph, self.fallback = None, "capture failed: %s" % (str(e).splitlines()[0] if str(e) else type(e).__name__)
             torch.cuda.synchronize(Y.device)
+        # Every rank must replay the SAME sequence of collectives: if the capture failed on one rank only, the others
+        # would replay captured all-reduces against its eager ones.  The ranks agree here (one MIN all-reduce of a flag,
+        # outside any capture: during a capture collectives are only recorded, so no rank is waiting inside one) and fall
+        # back together.
+        if self.comm.dist is not None and self.comm.world_size > 1:
+            ok = torch.tensor([1.0 if self.graph is not None else 0.0], dtype=torch.float64, device=self.comm.device)
+            self.comm.dist.all_reduce(ok, op=self.comm.dist.ReduceOp.MIN, group=self.comm.group)
+            if float(ok.item()) == 0.0 and self.graph is not None:
+                self.graph, self.out = None, None
+                self.fallback = "capture failed on another rank: eager loop on every rank"
+                self._eager()
 
     def _loop(self):
         return _bd_shared_device_loop(self.Y, self.t_r, self.lbda, self.theta0, self.hrf_dur, self.bounds, self.nb_iter,
@@ -283,8 +294,11 @@ class BdSharedGraph:
             self._eager()
 
     def result(self):
-        """``(W, h, d)`` of the last :meth:`launch`, as :func:`bd_shared` returns them (synchronises)."""
+        """``(W, h, d)`` of the last :meth:`launch`, as :func:`bd_shared` returns them (synchronises).  Under a graph
+        ``W`` is a COPY: the graph's own buffer is overwritten in place by the next :meth:`launch`."""
         W, taps, thetas, costs = self.out
+        if self.graph is not None:
+            W = W.clone()
         d = {"theta": torch.cat(thetas).cpu().numpy(), "J": np.concatenate([[1.0], torch.cat(costs).cpu().numpy()]),
              "evals": [1] * self.nb_iter}
         return W, taps.cpu().numpy(), d
