@@ -31,6 +31,7 @@ dense-Toeplitz NumPy formulation fanned over the host cores, and the matrix-free
 port, both from oracle/, on bounded samples of the same workload).
 """
 import argparse
+import math
 import json
 import os
 import subprocess
@@ -212,6 +213,18 @@ def run(args):
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     red_dev = torch.device("cpu") if args.rehearse_on_one_gpu else dev
+    collective = None
+    if dist is not None:
+        # what the communicator saw: one all-gather of every rank's PCI address (every rank takes part), so that a
+        # multi-GPU line shows RCCL ran over N DIFFERENT devices (a rehearsal on one GPU shows 1)
+        pr = torch.cuda.get_device_properties(dev)
+        addr = (int(getattr(pr, "pci_domain_id", 0)) << 16) | (int(getattr(pr, "pci_bus_id", 0)) << 8) | int(getattr(pr, "pci_device_id", 0))
+        mine = torch.tensor([addr], dtype=torch.int64, device=red_dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        ids = [int(t.item()) for t in every]
+        collective = {"backend": dist.get_backend(), "world_size": world, "distinct_devices": len(set(ids)),
+                      "pci_addresses": ["%04x:%02x:%02x" % (i >> 16, (i >> 8) & 0xff, i & 0xff) for i in ids]}
 
     from pybold_amd import data, solver
     from pybold_amd.hrf_model import spm_hrf
@@ -276,6 +289,8 @@ def run(args):
 
     if cfg == 4:
         out = run_config4(args, world, rank, dev, dist, V, V_total, lo, timed, timed_local, barrier)
+        if collective:
+            out["collective"] = collective
         if rank == 0 and world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline_block(cpu_dense, None, args.iters)
         if dist is not None:
@@ -434,6 +449,8 @@ def run(args):
                                                      (MFMA_F16_PEAK_TFLOPS if matrix_pipe else VALU_FP32_PEAK_TFLOPS)})}),
     }
 
+    if collective:
+        out["collective"] = collective
     if world > 1 and args.scaling == "strong":
         # secondary figure: weak scaling (every rank its own `--voxels` voxels); every rank takes
         # part (the decision depends on `world` and the flags only, never on a rank's own plan)
@@ -463,6 +480,17 @@ def run(args):
         out["sustained"] = {"value": float(P) * n_iter * n_busy / dt, "unit": "voxel-iterations/s",
                             "seconds": dt, "solves": n_busy}
 
+    if rank == 0 and world == 1 and cfg in (2, 3):
+        # wall clock to eps on diff_z, z AND x -- the solve plus pb_fista_outputs (z = cumsum(w), x = h * z)
+        taps_d = torch.from_numpy(np.ascontiguousarray(hrf, dtype=np.float64)).to(dev)
+        Zb, Xb = torch.empty_like(plan.W), torch.empty_like(plan.W)
+
+        def solve_and_outputs():
+            plan.launch(cold=True)
+            solver.fista_outputs_into(plan.W, taps_d, Zb, Xb)
+        _, ms_out = timed_local(solve_and_outputs, max(3, min(args.steps, 10)), 1, 0.05)
+        out["wall_clock_to_eps_ms_incl_outputs"] = ms_out
+        del Zb, Xb
     if rank == 0 and world == 1 and cfg == 3:
         out.update(pcie_inclusive(plan, Y, hrf, args.lbda, step, n_iter, solver, torch, dev, args.extras))
 
@@ -515,16 +543,38 @@ def roofline_block(matrix_pipe, kernel, dom_ms, P_dom, n_iter, N, K, flops_launc
     hbm_alg_gbs = alg_bytes / sec / 1e9
     if matrix_pipe:
         ach, peak = exec_launch / sec / 1e12, MFMA_F16_PEAK_TFLOPS
-        head = {"bound": "mfma", "pipe": "mfma_f16 (v_mfma_f32_16x16x32_f16, dense peak)", "achieved": ach, "peak": peak,
+        head = {"bound": "mfma", "binds": "issue", "headline": "frac_algorithmic",
+                "pipe": "mfma_f16 (v_mfma_f32_16x16x32_f16, dense peak)", "achieved": ach, "peak": peak,
                 "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                 "frac_algorithmic": flops_launch / sec / 1e12 / peak,
                 "executed_flops_per_launch": exec_launch}
-        binding = ("issue of ONE wave per SIMD: 999 vector + 228 matrix instructions per 16 voxel-iterations at N = 300 "
-                   "(profiles/r4_pmc_sq.json: 0.66 of the cycles issuing, 0.14 waiting on matrix results; matrix "
-                   "pipe busy 0.49) at the package power limit -- neither HBM nor the MFMA peak.  Round 4 removed the "
-                   "rank-one far-field products (276 -> 228 matrix instructions): fewer EXECUTED flops in less time, so "
-                   "`frac` fell (0.52 -> 0.48) while the rate rose 7 %; the split form (fista_mfma2_kernel: two waves per "
-                   "16 problems, carry-tile form) adds two workgroup barriers per iteration")
+        if mfma_block and not mfma_block.get("waves_per_16_problems", 1) > 1:
+            # the roof that actually binds: the issue rate of ONE wave per SIMD for this kernel's instruction mix, measured
+            # on its own (tools/microbench/mfma_narrow.hip, profiles/r5_mfma_narrow_and_issue_model.txt: a matrix
+            # instruction followed by v vector instructions of the kernel's kinds takes 13.3 ns at v = 4, + 2.9 ns per
+            # further one, whatever the number of accumulator chains)
+            n_m = mfma_block["mfma_instructions_per_16_problems_and_iteration"]
+            n_v = 996.0 * n_m / 228.0                          # (PMC: 996 vector instructions beside 228 matrix ones at N = 300)
+            ns_model = n_m * (13.3 + 2.9 * (n_v / n_m - 4.0))
+            waves = float(P_dom) / 16.0
+            model_ms = ns_model * 1e-6 * n_iter * max(1.0, math.ceil(waves / 1024.0))
+            head["issue_roof"] = {"matrix_instructions_per_wave_iteration": n_m, "vector_instructions_per_wave_iteration": n_v,
+                                  "model_ns_per_wave_iteration": ns_model, "model_ms_per_launch": model_ms,
+                                  "measured_ms_per_launch": dom_ms, "frac": model_ms / dom_ms,
+                                  "note": "model = the microbenchmark's time for this mix at one wave per SIMD (box and clock of "
+                                          "that run); frac ~ 1 means no issue slot is lost to latency: only fewer instructions, "
+                                          "or a second wave per SIMD (x1.15-1.23, not reachable: 304 registers of state per "
+                                          "wave), would be faster"}
+        binding = ("issue of ONE wave per SIMD: 996 vector + 228 matrix instructions per 16 voxel-iterations at N = 300 "
+                   "(profiles/r4_pmc_sq.json), at the package power limit -- neither HBM nor the MFMA peak.  Round 5 "
+                   "measured the roof itself (profiles/r5_mfma_narrow_and_issue_model.txt, r5_valu_one_wave.txt): a lone "
+                   "wave issues a vector instruction every 5.4-8 cycles (two waves per SIMD: every 4), and the kernel's "
+                   "time equals 228 x the time of one matrix instruction followed by 4.4 vector instructions of its kinds, "
+                   "whether the products form one accumulator chain or four: no latency slack is left (roofline.issue_roof); "
+                   "v_mfma_f32_16x16x16_f16 costs 0.92 of the 16x16x32 form, so skipping the empty quarters of the tiles with "
+                   "narrow products does not pay.  `frac` prices EXECUTED f16 flops (5.9x the algorithmic count: three split "
+                   "products, structural zeros, scans folded into the tiles): a pipe-busy figure; `frac_algorithmic` is the "
+                   "one that tracks progress")
     else:
         ach, peak = flops_launch / sec / 1e12, VALU_FP32_PEAK_TFLOPS
         head = {"bound": "valu_fp32", "pipe": "vector fp32 (v_pk_fma_f32)", "achieved": ach, "peak": peak,

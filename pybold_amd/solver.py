@@ -471,6 +471,17 @@ def fista_outputs(W, hrf):
     return X, Z
 
 
+def fista_outputs_into(W, taps_dev, Z, X):
+    """:func:`fista_outputs` into caller-owned buffers, taps already on the device: one launch, nothing allocated (the
+    form a timed loop wants)."""
+    lib = _lib.load()
+    P, N = W.shape
+    with torch.cuda.device(W.device):
+        rc = lib.pb_fista_outputs(W.data_ptr(), _ld(W), P, N, taps_dev.data_ptr(), taps_dev.numel(), Z.data_ptr(), _ld(Z),
+                                  X.data_ptr(), _ld(X), _stream_ptr(W.device))
+    _lib.check(rc, "pb_fista_outputs")
+
+
 def fista_stats(W, Y, hrf, y_rep=1):
     """Per-problem ``||hrf * cumsum(w) - y||^2`` and ``||w||_1`` (float64 ``(P,)``
     each): the R / G terms of pybold/bold_signal.py:141-157."""
