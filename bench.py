@@ -360,8 +360,9 @@ def run(args):
         # class on the matrix-pipe form, the sparse class on the pair form; each is timed on its own (same lists), the
         # longer one is the step's dominant kernel
         n_dense = int((lam < 0.13 * lmax5.repeat_interleave(y_rep)).sum().item())     # (the library's own test, path.h)
-        _, _, nd0 = solver.fista_solve(Y, hrf, lam, step, n_iter, y_rep=y_rep, lmax=lmax5, force="noresolve")
-        n_back = int((nd0 < 0).sum())
+        # (the dense class alone, without the re-solve: what its guards leave at n_done = -1)
+        _, _, nd0 = solver.fista_solve(Y, hrf, lam, step, n_iter, y_rep=y_rep, lmax=lmax5, force="path_dense")
+        n_back = int((nd0[lam < 0.13 * lmax5.repeat_interleave(y_rep)] < 0).sum())
         t_cls = {}
         for tag, frc in (("dense", "path_dense"), ("sparse", "path_sparse")):
             pl = solver.FistaPlan(Y, hrf, lam, step, n_iter, y_rep=y_rep, force=frc, lmax=lmax5, W=plan.W)
