@@ -882,12 +882,11 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
       int32_t* rg_flag = rg_sparse + 2 * pb::CAND_COUNT;
       {
         pb::ClassPred cp{lbda_dev, lbda, lmax, y_rep, dense_ratio > 0.0 ? dense_ratio : PB_PATH_DENSE_RATIO, nullptr};
-        hipLaunchKernelGGL(pb::path_count_kernel, dim3(nblk), dim3(pb::PATH_THREADS), 0, user, cp, P, work_dev);
-        hipLaunchKernelGGL(pb::path_scan_kernel, dim3(1), dim3(pb::PATH_THREADS), 0, user, P, nblk, work_dev);
-        hipLaunchKernelGGL(pb::path_scatter_kernel, dim3(nblk), dim3(pb::PATH_THREADS), 0, user, cp, P, work_dev);
         const pb::PlanSpec dense{1, (pair_plain || cert) ? 1 : 0, has_wide ? 1 : 0, 0, one_stream ? 1 : 0, has_mfma2 ? 1 : 0, beside_chunks_for(N), slots};
         const pb::PlanSpec sparse{2, (pair_plain || cert) ? 1 : 0, has_wide ? 1 : 0, 0, one_stream ? 1 : 0, 0, 0, slots};
-        hipLaunchKernelGGL(pb::plan_kernel, dim3(1), dim3(1), 0, user, dense, sparse, P, work_dev, rg_dense, rg_sparse);
+        hipLaunchKernelGGL(pb::path_count_kernel, dim3(nblk), dim3(pb::PATH_THREADS), 0, user, cp, P, work_dev);
+        hipLaunchKernelGGL(pb::path_scan_kernel, dim3(1), dim3(pb::PATH_THREADS), 0, user, P, nblk, work_dev, dense, sparse, rg_dense, rg_sparse);
+        hipLaunchKernelGGL(pb::path_scatter_kernel, dim3(nblk), dim3(pb::PATH_THREADS), 0, user, cp, P, work_dev);
         const int rc = check_launch("partition");
         if (rc != PB_OK) return rc;
       }
@@ -951,12 +950,11 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
       // what the guards / certificates handed back (n_done = -1): compacted, then the exact vector forms at full occupancy
       {
         pb::ClassPred cp{nullptr, 0.0, nullptr, 1, 0.0, n_done_dev};
-        hipLaunchKernelGGL(pb::path_count_kernel, dim3(nblk), dim3(pb::PATH_THREADS), 0, user, cp, P, work_dev);
-        hipLaunchKernelGGL(pb::path_scan_kernel, dim3(1), dim3(pb::PATH_THREADS), 0, user, P, nblk, work_dev);
-        hipLaunchKernelGGL(pb::path_scatter_kernel, dim3(nblk), dim3(pb::PATH_THREADS), 0, user, cp, P, work_dev);
         const pb::PlanSpec flagged{2, 0, has_wide ? 1 : 0, 0, 1, 0, 0, slots};
         const pb::PlanSpec none{0, 0, 0, 0, 1, 0, 0, slots};
-        hipLaunchKernelGGL(pb::plan_kernel, dim3(1), dim3(1), 0, user, flagged, none, P, work_dev, rg_flag, (int32_t*)nullptr);
+        hipLaunchKernelGGL(pb::path_count_kernel, dim3(nblk), dim3(pb::PATH_THREADS), 0, user, cp, P, work_dev);
+        hipLaunchKernelGGL(pb::path_scan_kernel, dim3(1), dim3(pb::PATH_THREADS), 0, user, P, nblk, work_dev, flagged, none, rg_flag, (int32_t*)nullptr);
+        hipLaunchKernelGGL(pb::path_scatter_kernel, dim3(nblk), dim3(pb::PATH_THREADS), 0, user, cp, P, work_dev);
         rc = check_launch("partition(handed back)");
         if (rc != PB_OK) return rc;
         ss = nullptr;                                  // (one stream: a few per cent of the batch at most)

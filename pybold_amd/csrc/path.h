@@ -55,7 +55,16 @@ __global__ __launch_bounds__(PATH_THREADS) void path_count_kernel(ClassPred cp, 
 }
 
 // exclusive prefix of the block counts (in place) and the total -- one workgroup, blocks dealt in chunks of 256
-__global__ __launch_bounds__(PATH_THREADS) void path_scan_kernel(int P, int nblk, int32_t* work) {
+struct PlanSpec {          // how a list is to be laid over the forms (the arguments of plan.h's planners)
+  int kind;                // 0: nothing, 1: plan_pieces_mfma (matrix-pipe form + vector remainder), 2: plan_pieces (vector forms)
+  int has_pair, has_wide, one_launch, one_stream, has_mfma2, beside_chunks;
+  double slots;
+};
+__device__ __forceinline__ void plan_list(const PlanSpec& sp, int n, int32_t* ranges);
+
+// ... and, once the total is known, the launch plans of the two lists (thread 0: plan.h's planners on the list lengths)
+__global__ __launch_bounds__(PATH_THREADS) void path_scan_kernel(int P, int nblk, int32_t* work, PlanSpec front, PlanSpec back,
+                                                                  int32_t* ranges_front, int32_t* ranges_back) {
   __shared__ int buf[PATH_THREADS];
   __shared__ int carry;
   if (threadIdx.x == 0) carry = 0;
@@ -77,7 +86,11 @@ __global__ __launch_bounds__(PATH_THREADS) void path_scan_kernel(int P, int nblk
     if (threadIdx.x == PATH_THREADS - 1) carry += buf[PATH_THREADS - 1];
     __syncthreads();
   }
-  if (threadIdx.x == 0) work[P] = carry;
+  if (threadIdx.x == 0) {
+    work[P] = carry;
+    if (ranges_front) plan_list(front, carry, ranges_front);
+    if (ranges_back) plan_list(back, P - carry, ranges_back);
+  }
 }
 
 // the two lists
@@ -105,13 +118,7 @@ __global__ __launch_bounds__(PATH_THREADS) void path_scatter_kernel(ClassPred cp
   }
 }
 
-// ---- launch plans of the two lists, made where their lengths are known ------------------------------------------
-struct PlanSpec {          // how a list is to be laid over the forms (the arguments of plan.h's planners)
-  int kind;                // 0: nothing, 1: plan_pieces_mfma (matrix-pipe form + vector remainder), 2: plan_pieces (vector forms)
-  int has_pair, has_wide, one_launch, one_stream, has_mfma2, beside_chunks;
-  double slots;
-};
-
+// ---- launch plans of the two lists, made where their lengths are known (called by path_scan_kernel) --------------
 __device__ __forceinline__ void plan_list(const PlanSpec& sp, int n, int32_t* ranges) {
   Piece pc[MAX_PIECES];
   int npc = 0;
@@ -128,19 +135,12 @@ __device__ __forceinline__ void plan_list(const PlanSpec& sp, int n, int32_t* ra
   }
 }
 
-// front list (its length: work[P]) -> ranges_front, back list (P - work[P]) -> ranges_back
-__global__ void plan_kernel(PlanSpec front, PlanSpec back, int P, const int32_t* work, int32_t* ranges_front, int32_t* ranges_back) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const int nf = work[P];
-  if (ranges_front) plan_list(front, nf, ranges_front);
-  if (ranges_back) plan_list(back, P - nf, ranges_back);
-}
-
 // ---- lambda_max of every series, for the partition (float32 in, float64 out) ---------------------------------
 // || H^T y ||_inf with H^T y = T_c^T y, c = cumsum(h): (H^T y)[j] = sum_m h[m] s[j + m], s = suffix sums of y
 // (upper-triangular Toeplitz matrices commute).  One series per wave: its lanes hold strips of SL consecutive
-// samples, the suffix sums go through LDS (stride-SL reads: conflict-free for odd SL), the taps come as kernel
-// arguments.  Float32 arithmetic: the result only decides a class (ratio test at 13 %), and pb_lambda_max stays the
+// samples (loaded straight from HBM: staging the series through LDS for coalesced loads measured 18 % slower -- the
+// pass is bound by the latency of its 100 000 short waves, not by bandwidth), the suffix sums go through LDS (stride-SL
+// reads: conflict-free for odd SL), the taps come as kernel arguments.  Float32 arithmetic: the result only decides a class (ratio test at 13 %), and pb_lambda_max stays the
 // float64 answer for callers who want the number.
 constexpr int LMAX_KT = 64;
 struct LmaxTaps { float h[LMAX_KT]; };
