@@ -69,7 +69,27 @@ def _warn_if_slow_kernel(lib, N, K, P, want_J, stop, wind, flags):
     forms; say so once when a batch of some size lands on it by dispatch (not by `force`)."""
     if P < 256 or (flags & (PB_FLAG_FORCE_GENERIC | PB_FLAG_FORCE_FAST)):
         return
-    if lib.pb_fista_which_kernel(int(N), int(K), int(P), int(bool(want_J)), _STOP[stop], int(wind)) != 0:
+    form = lib.pb_fista_which_kernel(int(N), int(K), int(P), int(bool(want_J)), _STOP[stop], int(wind))
+    if form in (1, 2, 3) and P >= 4096 and not (flags & (_lib.PB_FLAG_NO_MFMA | PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_FORCE_WIDE)):
+        # a machine-filling batch on a vector form although a matrix-pipe form exists for neighbouring shapes: say which
+        # limit the call ran into (rates at 300 / 600 scans: matrix pipe 4.8 / 2.0e9 voxel-iterations/s, vector forms
+        # 1.4-3.0e9, one problem per wave 0.5-0.6e9 -- DESIGN 6)
+        why = []
+        if N <= 128:
+            why = []                                  # (short series: the pair form is the fast one there)
+        elif N > 640:
+            why.append("series of %d scans (matrix-pipe forms: 129..640)" % N)
+        elif K > 48 or (K > 33 and N > 310):
+            why.append("HRF of %d taps (matrix-pipe forms: <= 33 taps, <= 48 up to 310 scans)" % K)
+        elif _STOP[stop] == PB_STOP_LOOPS and (want_J or N > 310):
+            why.append("the _loops_deconv rule %s" % ("with a cost trace" if want_J else "beyond 310 scans"))
+        elif _STOP[stop] == PB_STOP_WINDOW:
+            why.append("the window rule with wind=%d / this tolerance (matrix pipe: wind = 6 and tol * n_iter < 0.02)" % wind)
+        if why:
+            warn_once(("vector", N, K, _STOP[stop], wind, bool(want_J)),
+                      "pybold_amd: %d problems (N=%d, K=%d) run on the float32 vector forms (%s), 1.5-4x below the "
+                      "matrix-pipe rate: %s" % (P, N, K, KERNEL_NAMES[form].split(" (")[0], "; ".join(why)))
+    if form != 0:
         return
     why = []
     if _STOP[stop] == PB_STOP_WINDOW and wind not in (4, 6, 8):
