@@ -51,6 +51,9 @@ CONFIG_VOXELS = {2: 10000, 3: 100000, 4: 50000, 5: 50000}
 N_LAMBDA = 20                        # config 5: lambdas per voxel
 
 
+DENSE_RATIO = 0.19        # include/pybold_hip.h: PB_PATH_DENSE_RATIO
+
+
 def executed_flops_per_voxel_iter(n, k):
     """What the pair kernel with 2-parallel fast FIRs executes: three half-length sub-filters
     per FIR instead of four (3/4 of the multiply-adds), same scans and update."""
@@ -359,10 +362,10 @@ def run(args):
         # regularisation path partitioned on the device (pb_fista_solve_path): two big launches per step -- the dense
         # class on the matrix-pipe form, the sparse class on the pair form; each is timed on its own (same lists), the
         # longer one is the step's dominant kernel
-        n_dense = int((lam < 0.13 * lmax5.repeat_interleave(y_rep)).sum().item())     # (the library's own test, path.h)
+        n_dense = int((lam < DENSE_RATIO * lmax5.repeat_interleave(y_rep)).sum().item())     # (the library's own test, path.h)
         # (the dense class alone, without the re-solve: what its guards leave at n_done = -1)
         _, _, nd0 = solver.fista_solve(Y, hrf, lam, step, n_iter, y_rep=y_rep, lmax=lmax5, force="path_dense")
-        n_back = int((nd0[lam < 0.13 * lmax5.repeat_interleave(y_rep)] < 0).sum())
+        n_back = int((nd0[lam < DENSE_RATIO * lmax5.repeat_interleave(y_rep)] < 0).sum())
         t_cls = {}
         for tag, frc in (("dense", "path_dense"), ("sparse", "path_sparse")):
             pl = solver.FistaPlan(Y, hrf, lam, step, n_iter, y_rep=y_rep, force=frc, lmax=lmax5, W=plan.W)
@@ -374,7 +377,7 @@ def run(args):
         P_dom, dom_ms = (n_dense, t_cls["dense"]) if matrix_pipe else (P - n_dense, t_cls["sparse"])
         main_kernel, tail_kernel, n_main = solver.KERNEL_NAMES[4], solver.KERNEL_NAMES[2], n_dense
         kernel_name = main_kernel if matrix_pipe else tail_kernel
-        path_info = {"dense_ratio": 0.13, "dense_problems": n_dense, "sparse_problems": P - n_dense,
+        path_info = {"dense_ratio": DENSE_RATIO, "dense_problems": n_dense, "sparse_problems": P - n_dense,
                      "handed_back_by_the_guards": n_back, "handed_back_fraction_of_dense": n_back / max(n_dense, 1),
                      "dense_launch_ms": t_cls["dense"], "sparse_launch_ms": t_cls["sparse"],
                      "note": "each launch includes the three partition launches (lists built on the device, no host "

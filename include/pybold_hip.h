@@ -212,7 +212,7 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep,
  *
  * work_dev    int32 scratch of at least pb_fista_work_len(P, y_rep) entries, 8-byte aligned (contents meaningless
  *             afterwards); NULL or too small: no partition (the plan of pb_fista_solve with PB_FLAG_NO_PARTITION).
- * lmax_dev    float64 [ceil(P / y_rep)] or NULL.       dense_ratio <= 0: PB_PATH_DENSE_RATIO.
+ * lmax_dev    float64 [ceil(P / y_rep)] or NULL.       dense_ratio <= 0: PB_PATH_DENSE_RATIO(_LONG).
  * pb_fista_solve itself partitions too, on a workspace of the library's own (one per device and stream, grown on
  * demand with hipMalloc -- the one allocation this library makes; never under stream capture, where it runs unpartitioned).
  * Calls of fewer than 4 096 problems, shapes outside form (b), PB_FLAG_FORCE_* / _ONE_LAUNCH / _NO_PARTITION: the
@@ -220,7 +220,8 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep,
  */
 int64_t pb_fista_work_len(int P, int y_rep);
 /* Host-only query: the device-side plan of a LIST of n problems (kind 1: a dense class, matrix-pipe form + vector
- * remainder; kind 2: vector forms only) as the slots [ranges[2c], ranges[2c+1]) of each of the PB_CAND_COUNT candidate
+ * remainder; kind 2: vector forms only; kind 3: a PARTITIONED CALL of n_max problems, n of them dense -- ranges are
+ * positions in the call's list array, dense problems first) as the slots [ranges[2c], ranges[2c+1]) of each of the PB_CAND_COUNT candidate
  * launches (csrc/plan.h: MFMA, PAIR0, FAST0 | fork | MFMA2, PAIR1, FAST1, WIDE | side stream: WIDE0, WIDE1, FAST), and
  * the grid bound of each candidate for lists of at most n_max problems.  The same functions run on the device. */
 #define PB_CAND_COUNT 10
@@ -247,13 +248,17 @@ int pb_fista_solve_ex(const float* y_dev, int64_t ldy, int y_rep,
  * -- the dense class runs on the matrix-pipe form, the sparse class (solutions of a few small entries, where the
  * 22-bit operators of that form would be handed back by its accuracy guard and solved twice) straight on the
  * two-problems-per-row float32 form; whatever a guard still hands back is re-solved exactly as in pb_fista_solve.
- * dense_ratio <= 0 selects PB_PATH_DENSE_RATIO (calibrated on block-signal paths, profiles/r4_path_partition.txt: the
- * guard hands back 0.3 % of the problems at lambda / lambda_max = 0.11, 5 % at 0.14, 24 % at 0.18, 62 % at 0.23).  work_dev: int32 scratch of at least pb_fista_path_work_len(P)
+ * dense_ratio <= 0 selects PB_PATH_DENSE_RATIO (calibrated on block-signal paths: the guard hands back 1.9 % of the
+ * problems at lambda / lambda_max = 0.13, 35 % at 0.20, 90 % at 0.30 for 300 scans, 0.2 % / 14 % / 70 % for 600; a problem
+ * is worth trying on the matrix pipe while its chance of coming back is below 1 - t_matrix / t_vector ~ 0.35).  work_dev: int32 scratch of at least pb_fista_path_work_len(P)
  * entries (index lists and counts; contents meaningless afterwards).  lmax_dev == NULL, work_dev == NULL or a
  * shape outside the matrix-pipe form (129..310 scans, <= 33 taps): the call is pb_fista_solve with lbda_dev.
  * (Round 5: = pb_fista_solve_ex with lbda_dev, no cost trace, no stop rule; kept for callers of round 4.)
  */
-#define PB_PATH_DENSE_RATIO 0.13
+/* (round 5: 0.19 for series of up to 310 scans, 0.22 for 311..640 -- with the handed-back problems compacted the
+ * break-even moved up from round 4's 0.13: profiles/r5_dense_ratio_sweep.txt) */
+#define PB_PATH_DENSE_RATIO 0.19
+#define PB_PATH_DENSE_RATIO_LONG 0.22
 int64_t pb_fista_path_work_len(int P);
 int pb_fista_solve_path(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, int64_t ldw, int P, int N,
                         const double* taps_host, const double* taps_dev, int K, double step,

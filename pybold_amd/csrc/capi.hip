@@ -691,6 +691,102 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
   }
 #endif
 
+
+  // ---- round 5: partition BEFORE solving (dense class -> matrix pipe, sparse class -> float32 vector forms) and a
+  // compacted re-solve of what a guard or certificate hands back; list lengths and launch plans live on the device
+  // (path.h, plan.h).  For every call a matrix-pipe form would carry: one lambda or one per problem, cost trace,
+  // window-rule certificate, _loops_deconv rule; series of 129..310 scans (fista_mfma_kernel) and of 311..640
+  // (fista_mfma2_kernel).  Without it a batch whose lambda lies near lambda_max was solved twice -- matrix pipe, then one
+  // handed-back problem per wave (profiles/r4_path_partition.txt: 2.05 against 3.20e9).
+  //   launch_form(form, args, stream, exact_rule) -> 0 / 1 (rejected);  has_form(form, list) says which candidates exist
+  //   (list 0: the call's one list -- matrix-pipe forms for its dense head, vector forms for the rest --, 1 / 2: the
+  //   measurement aids "matrix-pipe candidates only" / "vector candidates only", 3: handed-back problems);
+  //   bound(cand) = grid bound of a candidate in slots
+  const int V_series = (P + y_rep - 1) / y_rep;
+  const bool part_ws = work_dev && P >= PART_MIN_P && K <= pb::LMAX_KT && N <= 640 && n_done_dev &&
+                       work_len >= work_layout(P, V_series).total &&
+                       !(flags & (PB_FLAG_FORCE_GENERIC | PB_FLAG_FORCE_PAIR | PB_FLAG_FORCE_WIDE | PB_FLAG_NO_PAIR | PB_FLAG_DIRECT_FIR | PB_FLAG_NO_MFMA |
+                                  PB_FLAG_ONE_LAUNCH | PB_FLAG_FORCE_MFMA2 | PB_FLAG_CERT_NO_RESOLVE | PB_FLAG_NO_PARTITION)) &&
+                       !((flags & PB_FLAG_FORCE_MFMA) && !lmax_dev);      // ("everything on the matrix pipe", as before)
+  auto run_partition = [&](const pb::PlanSpec& dense, const pb::PlanSpec& sparse, const pb::PlanSpec& flagged,
+                           auto&& launch_form, auto&& has_form, auto&& bound) -> int {
+    const WorkLayout wl = work_layout(P, V_series);
+    hipStream_t user = (hipStream_t)stream;
+    // lambda_max of every series, unless the caller has it
+    const double* lmax = lmax_dev;
+    if (!lmax) {
+      double* lm = reinterpret_cast<double*>(work_dev + wl.lmax);
+      pb::LmaxTaps lt;
+      for (int k = 0; k < pb::LMAX_KT; ++k) lt.h[k] = k < K ? (float)taps_host[k] : 0.0f;
+      const dim3 grid((unsigned)((V_series + 3) / 4)), block(256);
+      if (N <= 320) hipLaunchKernelGGL((pb::lmax_wave_kernel<5>), grid, block, 4 * (64 * 5 + pb::LMAX_KT) * sizeof(float), user, y_dev, ldy, V_series, N, lt, K, lm);
+      else hipLaunchKernelGGL((pb::lmax_wave_kernel<10>), grid, block, 4 * (64 * 10 + pb::LMAX_KT) * sizeof(float), user, y_dev, ldy, V_series, N, lt, K, lm);
+      lmax = lm;
+    }
+    const int nblk = (P + pb::PATH_PER_BLOCK - 1) / pb::PATH_PER_BLOCK;
+    int32_t* rg_dense = work_dev + wl.ranges;
+    int32_t* rg_sparse = rg_dense + 2 * pb::CAND_COUNT;
+    int32_t* rg_flag = rg_sparse + 2 * pb::CAND_COUNT;
+    {
+      pb::ClassPred cp{lbda_dev, lbda, lmax, y_rep, dense_ratio > 0.0 ? dense_ratio : (N > MFMA1_NMAX ? PB_PATH_DENSE_RATIO_LONG : PB_PATH_DENSE_RATIO), nullptr};
+      hipLaunchKernelGGL(pb::path_count_kernel, dim3(nblk), dim3(pb::PATH_THREADS), 0, user, cp, P, work_dev);
+      pb::PlanSpec front = dense;
+      front.merged = 1;
+      hipLaunchKernelGGL(pb::path_scan_kernel, dim3(1), dim3(pb::PATH_THREADS), 0, user, P, nblk, work_dev, front, sparse, rg_dense, rg_sparse);
+      hipLaunchKernelGGL(pb::path_scatter_kernel, dim3(nblk), dim3(pb::PATH_THREADS), 0, user, cp, P, work_dev);
+      const int rc = check_launch("partition");
+      if (rc != PB_OK) return rc;
+    }
+    SideStream* ss = nullptr;
+    std::unique_lock<std::mutex> lock(g_side_mutex, std::defer_lock);
+    if (!dense.one_stream) {
+      lock.lock();
+      ss = side_stream_locked();
+    }
+    // a whole list: its candidates in their static order, the side-stream ones forked after the whole rounds
+    auto solve_list = [&](const int32_t* ranges, int side, int list, bool exact_rule) -> int {
+      int rc = PB_OK;
+      bool forked = false;
+      for (int c = 0; c < pb::CAND_COUNT && rc == PB_OK; ++c) {
+        const int form = pb::cand_form(c);
+        if (!has_form(form, list) || (pb::cand_side(c) && !ss)) continue;
+        const int bd = bound(c);
+        if (bd <= 0) continue;
+        if (c >= pb::CAND_FIRST_AFTER_FORK && !forked && ss) {
+          if (hipEventRecord(ss->fork, user) != hipSuccess || hipStreamWaitEvent(ss->stream, ss->fork, 0) != hipSuccess)
+            return fail(PB_ERR_HIP, "pb_fista_solve: fork to the side stream failed");
+          forked = true;
+        }
+        pb::FistaArgs b = a;
+        b.perm = work_dev;
+        b.n_dense = work_dev + P;
+        b.perm_side = side;
+        b.range = ranges + 2 * c;
+        b.grid_slots = bd;
+        if (launch_form(form, b, (pb::cand_side(c) && ss) ? ss->stream : user, exact_rule) != 0)
+          return fail(PB_ERR_INVALID, "pb_fista_solve: a kernel form rejected its launch over a device-side list (form %d)", form);
+        rc = check_launch("fista kernel (device-side list)");
+      }
+      if (forked && (hipEventRecord(ss->join, ss->stream) != hipSuccess || hipStreamWaitEvent(user, ss->join, 0) != hipSuccess))
+        return fail(PB_ERR_HIP, "pb_fista_solve: join of the side stream failed");
+      return rc;
+    };
+    // ONE list for the call: positions [0, P) of the list array (dense problems first), one plan (plan.h: plan_partitioned)
+    const bool only_dense = (flags & PB_FLAG_ONLY_DENSE) != 0, only_sparse = (flags & PB_FLAG_ONLY_SPARSE) != 0;   // (measurement aids)
+    int rc = solve_list(rg_dense, 1, only_dense ? 1 : (only_sparse ? 2 : 0), false);
+    if (rc != PB_OK || only_dense || only_sparse) return rc;
+    // what the guards / certificates handed back (n_done = -1): compacted, then the exact vector forms at full occupancy
+    pb::ClassPred cp{nullptr, 0.0, nullptr, 1, 0.0, n_done_dev};
+    const pb::PlanSpec none{0, 0, 0, 0, 1, 0, 0, dense.slots};
+    hipLaunchKernelGGL(pb::path_count_kernel, dim3(nblk), dim3(pb::PATH_THREADS), 0, user, cp, P, work_dev);
+    hipLaunchKernelGGL(pb::path_scan_kernel, dim3(1), dim3(pb::PATH_THREADS), 0, user, P, nblk, work_dev, flagged, none, rg_flag, (int32_t*)nullptr);
+    hipLaunchKernelGGL(pb::path_scatter_kernel, dim3(nblk), dim3(pb::PATH_THREADS), 0, user, cp, P, work_dev);
+    rc = check_launch("partition(handed back)");
+    if (rc != PB_OK) return rc;
+    ss = nullptr;                                  // (one stream: a few per cent of the batch at most)
+    return solve_list(rg_flag, 3, 3, true);
+  };
+
   // series of 16 S < N <= 32 S scans (the reference's 600-scan demo): the pair form with the two
   // halves of ONE series in the slots of a row, in one launch; the window rule as a certificate,
   // re-solved on the one-problem-per-wave form
@@ -708,6 +804,46 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
       ((stop_mode == PB_STOP_NONE || mfma2_cert) && n_done_dev && (!lbda_dev || (flags & (PB_FLAG_FORCE_MFMA | PB_FLAG_FORCE_MFMA2))) &&
        !(flags & (PB_FLAG_FORCE_GENERIC | PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_FORCE_WIDE | PB_FLAG_DIRECT_FIR |
                   PB_FLAG_NO_MFMA))) ? pick_mfma2(N, K) : nullptr;
+  // (round 5) the same call shapes at 311..640 scans, partitioned on the device: dense class on whole passes of the split
+  // form, sparse class on the pair form over two slots (or the backup form), handed-back problems compacted
+  {
+    const mfma2_launch_fn mfma2_l = (mfma2 || !lbda_dev || !(stop_mode == PB_STOP_NONE || mfma2_cert)) ? mfma2 : pick_mfma2(N, K);
+    if (mfma2_l && part_ws && mfma2_serves_long(N, K) && P >= MFMA2_LONG_MIN_P) {
+      const FastEntry* fe1 = pick_fast(N, K);
+      const WideEntry* we1 = pick_wide(N, K);
+      const bool use_wide = we1 && (!fe1 || N > 320);
+      const bool backup_ok = (fe1 || we1) && (stop_mode == PB_STOP_NONE || (use_wide ? we1->S <= 20 : fe1->S <= 20));
+      const FastEntry* se = pick_split(N, K);
+      const bool scert_l = se && stop_mode == PB_STOP_WINDOW && wind == 6 && we1 && we1->S <= 20 && !(flags & PB_FLAG_NO_CERT) &&
+                           ((flags & PB_FLAG_FORCE_CERT) || tol * (double)n_iter < 0.5);
+      const bool split_ok = se != nullptr && (stop_mode == PB_STOP_NONE || scert_l);
+      if (backup_ok) {
+        const double slots = wave_slots();
+        pb::PlanSpec dense{3, 0, 0, 0, 1, 1, 0, slots};
+        pb::PlanSpec sparse{4, split_ok ? 1 : 0, 0, 0, 1, 0, 0, slots};
+        pb::PlanSpec flagged{4, 0, 0, 0, 1, 0, 0, slots};
+        dense.backup_form = sparse.backup_form = flagged.backup_form = use_wide ? FORM_WIDE : FORM_FAST1;
+        sparse.min_pair = SPLIT_MIN_P;
+        const bool wj = J_dev != nullptr;
+        return run_partition(dense, sparse, flagged,
+          [&](int form, const pb::FistaArgs& b, hipStream_t st, bool exact_rule) -> int {
+            if (form == FORM_MFMA2) return mfma2_l(b, taps_host, K, wj, st);
+            if (form == FORM_PAIR) return se->fn_pair_split(b, taps_host, K, wj, scert_l && !exact_rule, st);
+            if (form == FORM_WIDE) return we1->fn(b, taps_host, K, wj, stop_mode, st);
+            return fe1->fn(b, taps_host, K, wj, stop_mode, st);
+          },
+          [&](int form, int list) -> bool {
+            if (form == FORM_MFMA2) return list <= 1;
+            if (list == 1) return false;
+            if (form == FORM_PAIR) return list != 3 && split_ok;
+            if (form == FORM_WIDE) return use_wide;
+            if (form == FORM_FAST1) return !use_wide;
+            return false;
+          },
+          [&](int c) -> int { return (c == pb::CAND_MFMA2 || c == pb::CAND_PAIR0 || c == pb::CAND_FAST0 || c == pb::CAND_WIDE) ? P : 0; });
+      }
+    }
+  }
   if (mfma2 && ((flags & PB_FLAG_FORCE_MFMA2) || (mfma2_serves_long(N, K) && P >= MFMA2_LONG_MIN_P))) {
     const FastEntry* fe1 = pick_fast(N, K);
     const WideEntry* we1 = pick_wide(N, K);
@@ -842,124 +978,39 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
       return check_launch("fista_fast_kernel(re-solve)");
     };
     if (flags & PB_FLAG_NO_PAIR) return run(FORM_FAST1, 0, P);
-    // ---- round 5: partition BEFORE solving (dense class -> matrix pipe, sparse class -> float32 vector forms) and a
-    // compacted re-solve of what a guard or certificate hands back; list lengths and launch plans live on the device
-    // (path.h, plan.h).  For every call the matrix-pipe form would carry: one lambda or one per problem, cost trace,
-    // window-rule certificate, _loops_deconv rule.  Without it a batch whose lambda lies near lambda_max was solved
-    // twice -- matrix pipe, then one handed-back problem per wave (profiles/r4_path_partition.txt: 2.05 against 3.20e9).
-    const bool part_forces = (flags & (PB_FLAG_FORCE_PAIR | PB_FLAG_ONE_LAUNCH | PB_FLAG_FORCE_MFMA2 | PB_FLAG_CERT_NO_RESOLVE |
-                                       PB_FLAG_NO_PARTITION)) != 0 ||
-                             ((flags & PB_FLAG_FORCE_MFMA) && !lmax_dev);       // ("everything on the matrix pipe", as before)
-    const bool part_mfma = mfma != nullptr || (fe && (stop_mode == PB_STOP_NONE || mfma_cert || mfma_loops) && n_done_dev && lbda_dev &&
-                                               !(flags & (PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_DIRECT_FIR | PB_FLAG_NO_MFMA)) &&
+    // (round 5: the call partitioned on the device -- run_partition above)
+    const bool part_mfma = mfma != nullptr || (fe && (stop_mode == PB_STOP_NONE || mfma_cert || mfma_loops) && lbda_dev &&
                                                pick_mfma(N, K, stop_mode != PB_STOP_NONE) != nullptr);
-    if (part_mfma && !part_forces && work_dev && P >= PART_MIN_P && K <= pb::LMAX_KT && N <= 640 &&
-        work_len >= work_layout(P, (P + y_rep - 1) / y_rep).total) {
+    if (part_mfma && part_ws) {
       const mfma_launch_fn mfma_p = mfma ? mfma : pick_mfma(N, K, stop_mode != PB_STOP_NONE);
       const mfma2_launch_fn mfma2_p = (mfma2 || !lbda_dev) ? mfma2 : (((stop_mode == PB_STOP_NONE || mfma2_cert) && K <= MFMA_K2) ? pick_mfma2(N, K) : nullptr);
-      const int V = (P + y_rep - 1) / y_rep;
-      const WorkLayout wl = work_layout(P, V);
-      hipStream_t user = (hipStream_t)stream;
-      const bool one_stream = (flags & PB_FLAG_ONE_STREAM) != 0 || stream_is_capturing(user);
-      // lambda_max of every series, unless the caller has it
-      const double* lmax = lmax_dev;
-      if (!lmax) {
-        double* lm = reinterpret_cast<double*>(work_dev + wl.lmax);
-        pb::LmaxTaps lt;
-        for (int k = 0; k < pb::LMAX_KT; ++k) lt.h[k] = k < K ? (float)taps_host[k] : 0.0f;
-        const dim3 grid((unsigned)((V + 3) / 4)), block(256);
-        if (N <= 320) hipLaunchKernelGGL((pb::lmax_wave_kernel<5>), grid, block, 4 * (64 * 5 + pb::LMAX_KT) * sizeof(float), user, y_dev, ldy, V, N, lt, K, lm);
-        else hipLaunchKernelGGL((pb::lmax_wave_kernel<10>), grid, block, 4 * (64 * 10 + pb::LMAX_KT) * sizeof(float), user, y_dev, ldy, V, N, lt, K, lm);
-        lmax = lm;
-      }
-      const int nblk = (P + pb::PATH_PER_BLOCK - 1) / pb::PATH_PER_BLOCK;
+      const bool one_stream = (flags & PB_FLAG_ONE_STREAM) != 0 || stream_is_capturing((hipStream_t)stream);
       const double slots = wave_slots();
       const bool has_wide = pick_wide_small(N, K) != nullptr;
-      const bool pair_plain = fe->fn_pair != nullptr && stop_mode == PB_STOP_NONE;
+      const bool has_pair = (fe->fn_pair != nullptr && stop_mode == PB_STOP_NONE) || cert;
       const bool has_mfma2 = mfma2_p != nullptr && (stop_mode == PB_STOP_NONE || mfma_cert);
-      int32_t* rg_dense = work_dev + wl.ranges;
-      int32_t* rg_sparse = rg_dense + 2 * pb::CAND_COUNT;
-      int32_t* rg_flag = rg_sparse + 2 * pb::CAND_COUNT;
-      {
-        pb::ClassPred cp{lbda_dev, lbda, lmax, y_rep, dense_ratio > 0.0 ? dense_ratio : PB_PATH_DENSE_RATIO, nullptr};
-        const pb::PlanSpec dense{1, (pair_plain || cert) ? 1 : 0, has_wide ? 1 : 0, 0, one_stream ? 1 : 0, has_mfma2 ? 1 : 0, beside_chunks_for(N), slots};
-        const pb::PlanSpec sparse{2, (pair_plain || cert) ? 1 : 0, has_wide ? 1 : 0, 0, one_stream ? 1 : 0, 0, 0, slots};
-        hipLaunchKernelGGL(pb::path_count_kernel, dim3(nblk), dim3(pb::PATH_THREADS), 0, user, cp, P, work_dev);
-        hipLaunchKernelGGL(pb::path_scan_kernel, dim3(1), dim3(pb::PATH_THREADS), 0, user, P, nblk, work_dev, dense, sparse, rg_dense, rg_sparse);
-        hipLaunchKernelGGL(pb::path_scatter_kernel, dim3(nblk), dim3(pb::PATH_THREADS), 0, user, cp, P, work_dev);
-        const int rc = check_launch("partition");
-        if (rc != PB_OK) return rc;
-      }
-      SideStream* ss = nullptr;
-      std::unique_lock<std::mutex> lock(g_side_mutex, std::defer_lock);
-      if (!one_stream) {
-        lock.lock();
-        ss = side_stream_locked();
-      }
-      // one candidate launch of a list's device-side plan
-      auto cand = [&](int c, const int32_t* ranges, int side, const int32_t* perm, int n_max, int stop_here, bool exact_rule) -> int {
-        const int form = pb::cand_form(c);
-        const int bound = pb::cand_max_slots(c, n_max, slots);
-        if (bound <= 0) return PB_OK;
-        pb::FistaArgs b = a;
-        b.perm = perm;
-        b.n_dense = work_dev + P;
-        b.perm_side = side;
-        b.range = ranges + 2 * c;
-        b.grid_slots = bound;
-        b.stop_mode = stop_here;
-        hipStream_t st = (pb::cand_side(c) && ss) ? ss->stream : user;
-        const bool wj = J_dev != nullptr;
-        int bad = 0;
-        const char* what = "";
-        if (form == FORM_MFMA) { bad = mfma_p(b, taps_host, K, wj, st); what = "fista_mfma_kernel(list)"; }
-        else if (form == FORM_MFMA2) { bad = mfma2_p(b, taps_host, K, wj, st); what = "fista_mfma2_kernel(list)"; }
-        else if (form == FORM_PAIR && cert && !exact_rule) { bad = fe->fn_pair_cert(b, taps_host, K, st); what = "fista_pair_ffa_kernel(cert, list)"; }
-        else if (form == FORM_PAIR) { bad = fe->fn_pair_ffa(b, taps_host, K, wj, st); what = "fista_pair_ffa_kernel(list)"; }
-        else if (form == FORM_WIDE) { bad = pick_wide_small(N, K)->fn(b, taps_host, K, wj, stop_here, st); what = "fista_fast_kernel(wide, list)"; }
-        else { bad = fe->fn(b, taps_host, K, wj, stop_here, st); what = "fista_fast_kernel(list)"; }
-        if (bad) return fail(PB_ERR_INVALID, "pb_fista_solve: %s rejected the launch", what);
-        return check_launch(what);
-      };
-      // a whole list: the candidates in their static order, the side-stream ones forked after the whole rounds
-      auto solve_list = [&](const int32_t* ranges, int side, const int32_t* perm, bool with_mfma, bool with_pair, bool exact_rule) -> int {
-        const int stop_here = stop_mode;
-        int rc = PB_OK;
-        bool forked = false;
-        for (int c = 0; c < pb::CAND_COUNT && rc == PB_OK; ++c) {
-          const int form = pb::cand_form(c);
-          if ((form == FORM_MFMA && !with_mfma) || (form == FORM_MFMA2 && !(with_mfma && has_mfma2)) || (form == FORM_PAIR && !with_pair) ||
-              (form == FORM_WIDE && !has_wide) || (pb::cand_side(c) && !ss))
-            continue;
-          if (c >= pb::CAND_FIRST_AFTER_FORK && !forked && ss) {
-            if (hipEventRecord(ss->fork, user) != hipSuccess || hipStreamWaitEvent(ss->stream, ss->fork, 0) != hipSuccess)
-              return fail(PB_ERR_HIP, "pb_fista_solve: fork to the side stream failed");
-            forked = true;
-          }
-          rc = cand(c, ranges, side, perm, P, stop_here, exact_rule);
-        }
-        if (forked && (hipEventRecord(ss->join, ss->stream) != hipSuccess || hipStreamWaitEvent(user, ss->join, 0) != hipSuccess))
-          return fail(PB_ERR_HIP, "pb_fista_solve: join of the side stream failed");
-        return rc;
-      };
-      const bool only_dense = (flags & PB_FLAG_ONLY_DENSE) != 0, only_sparse = (flags & PB_FLAG_ONLY_SPARSE) != 0;   // (measurement aids)
-      int rc = PB_OK;
-      if (!only_sparse) rc = solve_list(rg_dense, 1, work_dev, true, pair_plain || cert, false);
-      if (rc == PB_OK && !only_dense) rc = solve_list(rg_sparse, 2, work_dev, false, pair_plain || cert, false);
-      if (rc != PB_OK || only_dense || only_sparse) return rc;
-      // what the guards / certificates handed back (n_done = -1): compacted, then the exact vector forms at full occupancy
-      {
-        pb::ClassPred cp{nullptr, 0.0, nullptr, 1, 0.0, n_done_dev};
-        const pb::PlanSpec flagged{2, 0, has_wide ? 1 : 0, 0, 1, 0, 0, slots};
-        const pb::PlanSpec none{0, 0, 0, 0, 1, 0, 0, slots};
-        hipLaunchKernelGGL(pb::path_count_kernel, dim3(nblk), dim3(pb::PATH_THREADS), 0, user, cp, P, work_dev);
-        hipLaunchKernelGGL(pb::path_scan_kernel, dim3(1), dim3(pb::PATH_THREADS), 0, user, P, nblk, work_dev, flagged, none, rg_flag, (int32_t*)nullptr);
-        hipLaunchKernelGGL(pb::path_scatter_kernel, dim3(nblk), dim3(pb::PATH_THREADS), 0, user, cp, P, work_dev);
-        rc = check_launch("partition(handed back)");
-        if (rc != PB_OK) return rc;
-        ss = nullptr;                                  // (one stream: a few per cent of the batch at most)
-        return solve_list(rg_flag, 3, work_dev, false, false, true);
-      }
+      const pb::PlanSpec dense{1, has_pair ? 1 : 0, has_wide ? 1 : 0, 0, one_stream ? 1 : 0, has_mfma2 ? 1 : 0, beside_chunks_for(N), slots};
+      const pb::PlanSpec sparse{2, has_pair ? 1 : 0, has_wide ? 1 : 0, 0, one_stream ? 1 : 0, 0, 0, slots};
+      const pb::PlanSpec flagged{2, 0, has_wide ? 1 : 0, 0, 1, 0, 0, slots};
+      const bool wj = J_dev != nullptr;
+      return run_partition(dense, sparse, flagged,
+        [&](int form, const pb::FistaArgs& b, hipStream_t st, bool exact_rule) -> int {
+          if (form == FORM_MFMA) return mfma_p(b, taps_host, K, wj, st);
+          if (form == FORM_MFMA2) return mfma2_p(b, taps_host, K, wj, st);
+          if (form == FORM_PAIR && cert && !exact_rule) return fe->fn_pair_cert(b, taps_host, K, st);
+          if (form == FORM_PAIR) return fe->fn_pair_ffa(b, taps_host, K, wj, st);
+          if (form == FORM_WIDE) return pick_wide_small(N, K)->fn(b, taps_host, K, wj, stop_mode, st);
+          return fe->fn(b, taps_host, K, wj, stop_mode, st);
+        },
+        [&](int form, int list) -> bool {
+          if (form == FORM_MFMA) return list <= 1;
+          if (form == FORM_MFMA2) return list <= 1 && has_mfma2;
+          if (list == 1) return false;                                // (aid: matrix-pipe candidates only)
+          if (form == FORM_PAIR) return list != 3 && has_pair;
+          if (form == FORM_WIDE) return has_wide;
+          return true;
+        },
+        [&](int c) -> int { return pb::cand_max_slots(c, P, slots); });
     }
     if (flags & PB_FLAG_FORCE_PAIR) {
       if (cert) {
@@ -1092,12 +1143,14 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
 
 int pb_fista_list_plan(int kind, int n, int n_max, int has_pair, int has_wide, int one_stream, int has_mfma2,
                        int beside_chunks, int32_t* ranges, int32_t* bounds) {
-  if (kind < 1 || kind > 2 || n < 0 || n_max < n) return fail(PB_ERR_INVALID, "pb_fista_list_plan: bad argument");
+  if (kind < 1 || kind > 3 || n < 0 || n_max < n) return fail(PB_ERR_INVALID, "pb_fista_list_plan: bad argument");
   Piece pc[pb::MAX_PIECES];
   int npc = 0;
   const double slots = wave_slots();
   if (n > 0 && kind == 1) npc = pb::plan_pieces_mfma(n, has_pair != 0, has_wide != 0, false, one_stream != 0, has_mfma2 != 0, beside_chunks, slots, pc);
-  else if (n > 0) npc = pb::plan_pieces(n, has_pair != 0, has_wide != 0, false, one_stream != 0, slots, pc);
+  else if (n > 0 && kind == 2) npc = pb::plan_pieces(n, has_pair != 0, has_wide != 0, false, one_stream != 0, slots, pc);
+  else if (kind == 3 && n_max > 0)      // a partitioned call of n_max problems, n of them dense
+    npc = pb::plan_partitioned(n, n_max, has_pair != 0, has_wide != 0, one_stream != 0, has_mfma2 != 0, beside_chunks, slots, pc);
   int32_t rg[2 * pb::CAND_COUNT];
   const int rc = pb::plan_to_candidates(pc, npc, rg);
   for (int c = 0; c < pb::CAND_COUNT; ++c) {

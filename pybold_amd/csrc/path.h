@@ -56,11 +56,19 @@ __global__ __launch_bounds__(PATH_THREADS) void path_count_kernel(ClassPred cp, 
 
 // exclusive prefix of the block counts (in place) and the total -- one workgroup, blocks dealt in chunks of 256
 struct PlanSpec {          // how a list is to be laid over the forms (the arguments of plan.h's planners)
-  int kind;                // 0: nothing, 1: plan_pieces_mfma (matrix-pipe form + vector remainder), 2: plan_pieces (vector forms)
+  int kind;                // 0: nothing, 1: plan_pieces_mfma (matrix-pipe form + vector remainder), 2: plan_pieces (vector forms),
+                           // 3: series of 311..640 scans, dense class: whole passes of the split form (and a remainder above
+                           //    5/16 of a pass), the rest on the backup form; 4: the same shapes, sparse class or handed-back
+                           //    problems: the pair form over two slots from `min_pair` problems on, else the backup form
   int has_pair, has_wide, one_launch, one_stream, has_mfma2, beside_chunks;
   double slots;
+  int backup_form = FORM_WIDE;   // kinds 3, 4: FORM_FAST1 (311..320 scans with a single-row entry) or FORM_WIDE
+  int min_pair = 1024;
+  int merged = 0;                // front spec only: 1 = ONE plan for the whole call (plan.h: plan_partitioned / its long-series
+                                 // form): the front list's remainder joins the back list, ranges are positions in the list array
 };
 __device__ __forceinline__ void plan_list(const PlanSpec& sp, int n, int32_t* ranges);
+__device__ __forceinline__ void plan_call(const PlanSpec& front, const PlanSpec& back, int n_d, int P, int32_t* ranges);
 
 // ... and, once the total is known, the launch plans of the two lists (thread 0: plan.h's planners on the list lengths)
 __global__ __launch_bounds__(PATH_THREADS) void path_scan_kernel(int P, int nblk, int32_t* work, PlanSpec front, PlanSpec back,
@@ -88,8 +96,11 @@ __global__ __launch_bounds__(PATH_THREADS) void path_scan_kernel(int P, int nblk
   }
   if (threadIdx.x == 0) {
     work[P] = carry;
-    if (ranges_front) plan_list(front, carry, ranges_front);
-    if (ranges_back) plan_list(back, P - carry, ranges_back);
+    if (ranges_front && front.merged) plan_call(front, back, carry, P, ranges_front);
+    else {
+      if (ranges_front) plan_list(front, carry, ranges_front);
+      if (ranges_back) plan_list(back, P - carry, ranges_back);
+    }
   }
 }
 
@@ -127,11 +138,41 @@ __device__ __forceinline__ void plan_list(const PlanSpec& sp, int n, int32_t* ra
                            sp.beside_chunks, sp.slots, pc);
   else if (n > 0 && sp.kind == 2)
     npc = plan_pieces(n, sp.has_pair != 0, sp.has_wide != 0, sp.one_launch != 0, sp.one_stream != 0, sp.slots, pc);
+  else if (n > 0 && sp.kind == 3) {
+    const int pass = (int)sp.slots * 4;            // 16 problems x (slots / 2 SIMDs / 2 waves): capi.hip, mfma2_long_base
+    int base = (n / pass) * pass;
+    if (sp.one_launch || n - base > pass * 5 / 16) base = n;
+    if (base > 0) pc[npc++] = Piece{FORM_MFMA2, 0, base, false, false};
+    if (base < n) pc[npc++] = Piece{sp.backup_form, base, n, false, false};
+  } else if (n > 0 && sp.kind == 4) {
+    pc[npc++] = Piece{(sp.has_pair && n >= sp.min_pair) ? FORM_PAIR : sp.backup_form, 0, n, false, false};
+  }
   if (plan_to_candidates(pc, npc, ranges) != 0) {
     // (unreachable for the plans of plan.h; if it ever happened: everything on the one candidate that always exists)
     for (int c = 0; c < 2 * CAND_COUNT; ++c) ranges[c] = 0;
-    const int c = sp.kind == 1 ? CAND_MFMA : CAND_FAST0;
+    const int c = sp.kind == 1 ? CAND_MFMA : (sp.kind == 3 ? CAND_MFMA2 : ((sp.kind == 4 && sp.backup_form == FORM_WIDE) ? CAND_WIDE : CAND_FAST0));
     ranges[2 * c + 1] = n;
+  }
+}
+
+// one plan for a partitioned call: dense problems at positions [0, n_d), sparse ones behind (see PlanSpec::merged)
+__device__ __forceinline__ void plan_call(const PlanSpec& front, const PlanSpec& back, int n_d, int P, int32_t* ranges) {
+  Piece pc[MAX_PIECES];
+  int npc = 0;
+  if (front.kind == 1) {
+    npc = plan_partitioned(n_d, P, front.has_pair != 0, front.has_wide != 0, front.one_stream != 0, front.has_mfma2 != 0,
+                           front.beside_chunks, front.slots, pc);
+  } else {                                           // series of 311..640 scans (kinds 3 / 4)
+    const int pass = (int)front.slots * 4;
+    int base = (n_d / pass) * pass;
+    if (n_d - base > pass * 5 / 16) base = n_d;
+    if (base > 0) pc[npc++] = Piece{FORM_MFMA2, 0, base, false, false};
+    if (base < P) pc[npc++] = Piece{(back.has_pair && P - base >= back.min_pair) ? FORM_PAIR : back.backup_form, base, P, false, false};
+  }
+  if (plan_to_candidates(pc, npc, ranges) != 0) {     // (unreachable; if it ever happened: everything on the exact single-row / wide form)
+    for (int c = 0; c < 2 * CAND_COUNT; ++c) ranges[c] = 0;
+    const int c = (front.kind != 1 && back.backup_form == FORM_WIDE) ? CAND_WIDE : CAND_FAST0;
+    ranges[2 * c + 1] = P;
   }
 }
 

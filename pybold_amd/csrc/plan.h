@@ -222,6 +222,34 @@ PB_HD int plan_pieces_mfma(int P, bool has_pair, bool has_wide, bool one_launch,
   return n;
 }
 
+// ---- the plan of a PARTITIONED call (round 5): n_d dense problems at positions [0, n_d) of the list array, the sparse
+// ones behind them.  No sparse problem: the plan of a dense call (plan_pieces_mfma).  Otherwise the matrix-pipe form takes
+// the whole rounds of the dense class (and what is left of it, if that is worth a pass of its own: above half a round on
+// the one-wave form, above MFMA2_MIN_R on the split form), and whatever it does not take joins the sparse class in ONE
+// list for the vector forms, positions [covered, P), planned like a vector call of that many problems.
+PB_HD int plan_partitioned(int n_d, int P, bool has_pair, bool has_wide, bool one_stream, bool has_mfma2, int beside_chunks,
+                           double slots, Piece* out) {
+  if (n_d >= P) return plan_pieces_mfma(P, has_pair, has_wide, false, one_stream, has_mfma2, beside_chunks, slots, out);
+  int n = 0;
+  const int round = (int)slots * 8;
+  const int whole = (n_d / round) * round, R = n_d - whole;
+  int covered = whole;
+  if (R > round / 2) {
+    covered = n_d;
+    out[n++] = Piece{FORM_MFMA, 0, n_d, false, false};
+  } else {
+    if (whole > 0) out[n++] = Piece{FORM_MFMA, 0, whole, false, false};
+    if (has_mfma2 && R > MFMA2_MIN_R) {
+      out[n++] = Piece{FORM_MFMA2, whole, n_d, false, false};
+      covered = n_d;
+    }
+  }
+  Piece sub[4];
+  const int m = plan_pieces(P - covered, has_pair, has_wide, false, one_stream, slots, sub);
+  for (int i = 0; i < m; ++i) out[n++] = Piece{sub[i].form, sub[i].p0 + covered, sub[i].p1 + covered, sub[i].side, sub[i].group};
+  return n;
+}
+
 // ---- device-side plans (round 5) -----------------------------------------------------------------------------
 // A list whose length n is known on the device only (a class of the partition, the problems a guard handed back) is
 // solved by a STATIC sequence of candidate launches, each with a worst-case grid, each reading the slots [s0, s1) it
@@ -272,7 +300,13 @@ PB_HD int plan_to_candidates(const Piece* pc, int npc, int32_t* ranges) {
       case FORM_WIDE:  c = pc[i].side ? (taken(CAND_SIDE_WIDE0) ? CAND_SIDE_WIDE1 : CAND_SIDE_WIDE0) : CAND_WIDE; break;
       default: break;
     }
-    if (c < 0 || taken(c)) { rc = -1; continue; }
+    if (c < 0) { rc = -1; continue; }
+    // a second piece of a form that continues the first one on the same stream and outside a group: one launch
+    if (!pc[i].side && !pc[i].group && (c == CAND_PAIR1 || c == CAND_FAST1)) {
+      const int c0 = c == CAND_PAIR1 ? CAND_PAIR0 : CAND_FAST0;
+      if (taken(c0) && ranges[2 * c0 + 1] == pc[i].p0) { ranges[2 * c0 + 1] = pc[i].p1; continue; }
+    }
+    if (taken(c)) { rc = -1; continue; }
     ranges[2 * c] = pc[i].p0;
     ranges[2 * c + 1] = pc[i].p1;
   }

@@ -216,13 +216,17 @@ def test_partition_extremes_and_small_lists(solver):
     W, _, nd = solver.fista_solve(Y, hrf, lam, step, n_it, lmax=lmax)
     ref = _oracle_rows(Y, hrf, lam.cpu().numpy(), step, n_it, np.array([1233, 1234, 1235]))
     assert int(nd.min()) == n_it and rel_rows(W[1233:1236].cpu().numpy(), ref).max() < 1e-5
-    # measurement aids
-    lam = torch.where(torch.arange(V, device=Y.device) % 2 == 0, lmax * 0.01, lmax * 0.9)
-    W0 = torch.full((V, Y.shape[1]), 7.0, dtype=torch.float64, device=Y.device)
-    Wd, _, _ = solver.fista_solve(Y, hrf, lam, step, n_it, lmax=lmax, W0=W0, force="path_dense")
-    Ws, _, _ = solver.fista_solve(Y, hrf, lam, step, n_it, lmax=lmax, W0=W0, force="path_sparse")
-    assert bool((Wd[1::2] == 7.0).all()) and bool((Ws[0::2] == 7.0).all())
-    assert not bool((Wd[0::2] == 7.0).all(dim=1).any()) and not bool((Ws[1::2] == 7.0).all(dim=1).any())
+    # measurement aids: "matrix-pipe launches only" / "vector launches only" -- together they cover every problem once
+    Vb = 24000
+    Yb, _, _ = _mixed_batch(Vb, 6)
+    lmb = solver.lambda_max(Yb, hrf)
+    lam = torch.where(torch.arange(Vb, device=Yb.device) % 2 == 0, lmb * 0.01, lmb * 0.9)      # 12 000 dense: above half a round
+    W0 = torch.full((Vb, Yb.shape[1]), 1e-3, dtype=torch.float64, device=Yb.device)       # (a warm start inside every form's range)
+    Wd, _, _ = solver.fista_solve(Yb, hrf, lam, step, n_it, lmax=lmb, W0=W0, force="path_dense")
+    Ws, _, _ = solver.fista_solve(Yb, hrf, lam, step, n_it, lmax=lmb, W0=W0, force="path_sparse")
+    touched_d, touched_s = ~(Wd == 1e-3).all(dim=1), ~(Ws == 1e-3).all(dim=1)
+    assert bool((touched_d ^ touched_s).all())                              # every problem by exactly one of the two
+    assert bool(touched_d[0::2].all()) and not bool(touched_d[1::2].any())  # here: the dense class whole on the matrix pipe
     # handed-back problems: constant series are dense by the ratio test but fail the accuracy guard at the end
     Yc = Y.clone()
     Yc[::3] = 5.0
@@ -284,3 +288,39 @@ def test_range_guard_between_its_samples(solver, golden):
                 assert not back.any(), (mult, np.nonzero(back)[0])
             if mult >= 2.6:
                 assert back.any()
+
+
+def test_partition_for_series_of_600_scans(solver):
+    """The reference's demo length (examples/synth_data/deconv.py:46: 600 scans): 12 000 voxels with one scalar lambda at
+    the batch's median of 0.13 lambda_max,v -- dense class on whole passes of the split matrix-pipe form, sparse class on
+    the pair form over two slots, handed-back problems compacted -- plain, with the cost trace, with the window rule;
+    per-problem lambdas; against the vector dispatch (<= 4e-6) and the C oracle (<= 1e-5)."""
+    from pybold_amd import data
+    V, n_it = 12000, 200
+    hrf = orc.spm_hrf(1.0, 1.0, 30.0)[0]
+    Y, _, _ = data.gen_rnd_bloc_bold_batch(V, dur=10, tr=1.0, hrf=hrf, nb_events=9, avg_dur=12.0, std_dur=1.0, snr=1.0, seed=21)
+    assert Y.shape[1] == 600
+    lip = 0.9 * orc.spectral_radius_est(orc._MatrixFreeH(hrf), np.random.RandomState(0).randn(600))
+    step = 1.0 / lip
+    lmax = solver.lambda_max(Y, hrf)
+    lam_s = float((0.13 * lmax).median())
+    rows = np.random.RandomState(5).choice(V, 128, replace=False)
+    ref = _oracle_rows(Y, hrf, lam_s, step, n_it, rows)
+    for kw in (dict(), dict(want_J=True), dict(want_J=True, stop="window", tol=1e-6, wind=6)):
+        W, J, nd = solver.fista_solve(Y, hrf, lam_s, step, n_it, **kw)
+        Wv, Jv, _ = solver.fista_solve(Y, hrf, lam_s, step, n_it, force="valu", **kw)
+        assert int(nd.min()) == n_it and int(nd.max()) == n_it, (kw, int(nd.min()))
+        e_v = float(((W - Wv).norm(dim=1) / Wv.norm(dim=1).clamp_min(1e-300)).max())
+        e_o = rel_rows(W[rows].cpu().numpy(), ref).max()
+        print("600 scans, partitioned %-60s vs vector dispatch %.2e, vs oracle %.2e" % (kw, e_v, e_o))
+        assert e_v < 4e-6 and e_o < 1e-5, kw
+        if J is not None:
+            assert float(((J - Jv).abs() / Jv.abs().clamp_min(1e-30)).max()) < 1e-4
+    c = torch.tensor([0.02, 0.5], dtype=torch.float64, device=Y.device)
+    lam_p = (lmax[:, None] * c[None, :]).reshape(-1)
+    Wp, _, ndp = solver.fista_solve(Y, hrf, lam_p, step, n_it, y_rep=2)
+    Wpv, _, _ = solver.fista_solve(Y, hrf, lam_p, step, n_it, y_rep=2, force="valu")
+    assert int(ndp.min()) == n_it
+    assert float(((Wp - Wpv).norm(dim=1) / Wpv.norm(dim=1).clamp_min(1e-300)).max()) < 4e-6
+    # the dense half did run on the matrix pipe (other bits than the vector forms), the sparse half on the vector forms
+    assert not bool((Wp[0::2] == Wpv[0::2]).all())

@@ -249,6 +249,20 @@ def test_device_side_plans_tile_every_list_length():
                                 assert r[WIDE] == (0, 0) and r[SW0] == (0, 0) and r[SW1] == (0, 0)
                             if one_stream:
                                 assert r[SW0] == (0, 0) and r[SW1] == (0, 0) and r[SF] == (0, 0)
+    # a partitioned call (kind 3): n_max problems, n of them dense -- the candidates tile the positions [0, n_max) of the call's
+    # list array; the matrix-pipe forms stay inside the dense head
+    for P in (4096, 10000, 20000, 100000):
+        for n_d in sorted(set([0, 1, 4608, 4609, 8192, 8193, 9999, 16384, 16385, 30000, 98304, P] + list(range(0, P + 1, 977)))):
+            if n_d > P:
+                continue
+            for one_stream in (0, 1):
+                rc = lib.pb_fista_list_plan(3, n_d, P, 1, 1, one_stream, 1, 2, rg, bd)
+                assert rc == 0, (P, n_d, lib.pb_last_error())
+                r = [(rg[2 * c], rg[2 * c + 1]) for c in range(NC)]
+                live = sorted((a, b) for a, b in r if b > a)
+                assert live[0][0] == 0 and live[-1][1] == P and all(live[i][1] == live[i + 1][0] for i in range(len(live) - 1)), (P, n_d, r)
+                assert all(b - a <= bd[c] for c, (a, b) in enumerate(r)), (P, n_d, r, list(bd))
+                assert r[MFMA][1] <= n_d and r[MFMA2][1] <= n_d, (P, n_d, r)
     # the plan of a list = the plan of a call of that many problems (N = 300, K = 30: pair form, one-problem waves, split form)
     nm, mf, tf = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
     for n in (5000, 8192, 10000, 12500, 16384, 25000, 50000, 98304, 100000):

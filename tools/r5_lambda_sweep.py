@@ -42,17 +42,19 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--voxels", type=int, default=100000)
     ap.add_argument("--iters", type=int, default=500)
+    ap.add_argument("--scans", type=int, default=300)
     ap.add_argument("--shapes", default="plain,default")
+    ap.add_argument("--ratio", type=float, default=0.0, help="dense_ratio of the partition (0: the library's default)")
     args = ap.parse_args()
     V, n_it = args.voxels, args.iters
     hrf = orc.spm_hrf(1.0, 1.0, 30.0)[0]
-    Y, _, _ = data.gen_rnd_bloc_bold_batch(V, dur=5, tr=1.0, hrf=hrf, nb_events=5, avg_dur=12.0, std_dur=1.0, snr=1.0, seed=0)
+    Y, _, _ = data.gen_rnd_bloc_bold_batch(V, dur=args.scans / 60.0, tr=1.0, hrf=hrf, nb_events=5, avg_dur=12.0, std_dur=1.0, snr=1.0, seed=0)
     N = Y.shape[1]
     lip = 0.9 * orc.spectral_radius_est(orc._MatrixFreeH(hrf), np.random.RandomState(0).randn(N))
     step = 1.0 / lip
     lmax = solver.lambda_max(Y, hrf)
-    print("# %d voxels x %d scans, K = %d, %d iterations; lambda_max: median %.3g, 5%% %.3g, 95%% %.3g"
-          % (V, N, len(hrf), n_it, float(lmax.median()), float(lmax.quantile(0.05)), float(lmax.quantile(0.95))))
+    print("# %d voxels x %d scans, K = %d, %d iterations; lambda_max: median %.3g, 5%% %.3g, 95%% %.3g; dense_ratio %s"
+          % (V, N, len(hrf), n_it, float(lmax.median()), float(lmax.quantile(0.05)), float(lmax.quantile(0.95)), args.ratio or "default"))
     worst = 0.0
     shapes = {"plain": ("plain solve", dict()),
               "default": ("cost trace + window rule, tol 1e-6 (the reference-default call)", dict(want_J=True, stop="window", tol=1e-6, wind=6)),
@@ -66,7 +68,7 @@ def main():
         for name, lam in points:
             t = {}
             for force in (None, "nopart", "valu"):
-                t[force] = timed(lambda: solver.fista_solve(Y, hrf, lam, step, n_it, force=force, **kw))
+                t[force] = timed(lambda: solver.fista_solve(Y, hrf, lam, step, n_it, force=force, dense_ratio=args.ratio, **kw))
             hb = ""
             if not kw:
                 _, _, nd = solver.fista_solve(Y, hrf, lam, step, n_it, force="mfmaonly")
