@@ -750,6 +750,8 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
       for (int c = 0; c < pb::CAND_COUNT && rc == PB_OK; ++c) {
         const int form = pb::cand_form(c);
         if (!has_form(form, list) || (pb::cand_side(c) && !ss)) continue;
+        // (a plan on one stream has no groups, and a second piece of a form continues the first: plan_to_candidates merges them)
+        if ((c == pb::CAND_PAIR1 || c == pb::CAND_FAST1) && !ss) continue;
         const int bd = bound(c);
         if (bd <= 0) continue;
         if (c >= pb::CAND_FIRST_AFTER_FORK && !forked && ss) {

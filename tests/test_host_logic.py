@@ -247,8 +247,9 @@ def test_device_side_plans_tile_every_list_length():
                                 assert r[PAIR0] == (0, 0) and r[PAIR1] == (0, 0)
                             if not has_wide:
                                 assert r[WIDE] == (0, 0) and r[SW0] == (0, 0) and r[SW1] == (0, 0)
-                            if one_stream:
+                            if one_stream:     # no side pieces, and no second piece of a form (capi.hip does not launch those then)
                                 assert r[SW0] == (0, 0) and r[SW1] == (0, 0) and r[SF] == (0, 0)
+                                assert r[PAIR1] == (0, 0) and r[FAST1] == (0, 0), (kind, n, r)
     # a partitioned call (kind 3): n_max problems, n of them dense -- the candidates tile the positions [0, n_max) of the call's
     # list array; the matrix-pipe forms stay inside the dense head
     for P in (4096, 10000, 20000, 100000):
@@ -263,6 +264,8 @@ def test_device_side_plans_tile_every_list_length():
                 assert live[0][0] == 0 and live[-1][1] == P and all(live[i][1] == live[i + 1][0] for i in range(len(live) - 1)), (P, n_d, r)
                 assert all(b - a <= bd[c] for c, (a, b) in enumerate(r)), (P, n_d, r, list(bd))
                 assert r[MFMA][1] <= n_d and r[MFMA2][1] <= n_d, (P, n_d, r)
+                if one_stream:
+                    assert r[PAIR1] == (0, 0) and r[FAST1] == (0, 0) and r[SW0] == (0, 0) and r[SF] == (0, 0), (P, n_d, r)
     # the plan of a list = the plan of a call of that many problems (N = 300, K = 30: pair form, one-problem waves, split form)
     nm, mf, tf = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
     for n in (5000, 8192, 10000, 12500, 16384, 25000, 50000, 98304, 100000):
