@@ -393,6 +393,24 @@ int pb_fista_solve_d(const double* y_dev, int64_t ldy, int y_rep, double* w_dev,
                      double step, double lbda, const double* lbda_dev, const double* betas_dev,
                      int n_iter, double* J_dev, int64_t ldj, int stop_mode, double tol, int wind,
                      int32_t* n_done_dev, unsigned flags, void* stream);
+/*
+ * OPT-IN EXTRA, never part of a parity run: the recurrence of pb_fista_solve_d with a BACKTRACKED step.  The reference
+ * has a constant step only (pybold/bold_signal.py:52-53 / :253-254: 1 / (0.9 rho) or 1 / ||A^T A||_F); this is
+ * BASELINE's "Lipschitz-backtracked step": per iteration, with g = H^T (H w - y) at the extrapolated point w,
+ *     repeat   u = w - s g ;  p = soft(u, lbda s) ;
+ *              accept if  F(p) <= F(w) + <p - w, g> + ||p - w||^2 / (2 s)     (F = 0.5 ||H . - y||^2)
+ *              else s <- eta s                       (at most max_halvings_per_iter times per iteration; s never grows)
+ *     w <- p + beta_k (p - u)                        (the reference's momentum, on the accepted gradient point)
+ * so a caller without a Lipschitz constant starts from any step0; with step0 <= 1 / L the test passes at once and the
+ * iterates are those of the constant-step solver.  float64 end to end (y float64), one workgroup per problem, any
+ * 5 N + K <= 20000.  step_out_dev (float64 [P]) / halvings_out_dev (int32 [P]): the final step and the number of
+ * reductions of every problem, or NULL.  Checked against its own NumPy statement (oracle: fista_backtrack_batch).
+ */
+int pb_fista_solve_backtrack_d(const double* y_dev, int64_t ldy, int y_rep, double* w_dev, int64_t ldw, int P, int N,
+                               const double* taps_dev, int K, double step0, double eta, int max_halvings_per_iter,
+                               double lbda, const double* lbda_dev, const double* betas_dev, int n_iter,
+                               int32_t* n_done_dev, double* step_out_dev, int32_t* halvings_out_dev,
+                               unsigned flags, void* stream);
 int pb_fista_stats_d(const double* w_dev, int64_t ldw, const double* y_dev, int64_t ldy,
                      int y_rep, int P, int N, const double* taps_dev, int K,
                      double* r2_dev, double* l1_dev, void* stream);

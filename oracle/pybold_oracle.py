@@ -263,6 +263,41 @@ def fista_batch(Y, hrf, lbda, step, nb_iter, W0=None, dense=False):
     return W
 
 
+def fista_backtrack_batch(Y, hrf, lbda, step0, nb_iter, eta=0.5, max_bt=40, W0=None):
+    """NOT a restatement of the reference (which has a constant step only, pybold/bold_signal.py:52-53): the float64
+    statement of the opt-in backtracking mode (``pb_fista_solve_backtrack_d``, include/pybold_hip.h), its only checker.
+    Returns ``(W, step, halvings, margin)``; ``margin`` = the smallest relative distance of an acceptance test from
+    equality (a decision closer than rounding to equality cannot be compared across arithmetics)."""
+    Y = np.atleast_2d(np.asarray(Y, dtype=np.float64))
+    H = _MatrixFreeH(np.asarray(hrf, dtype=np.float64))
+    V, n = Y.shape
+    lb = np.broadcast_to(np.asarray(lbda, dtype=np.float64), (V,))
+    W = np.zeros((V, n)) if W0 is None else np.array(W0, dtype=np.float64)
+    steps, halv, margin = np.full(V, float(step0)), np.zeros(V, dtype=np.int64), np.full(V, np.inf)
+    betas = momentum_sequence(nb_iter)
+    for v in range(V):
+        w, s = W[v].copy(), float(step0)
+        for k in range(nb_iter):
+            r = H.op(w) - Y[v]
+            f_w = 0.5 * np.dot(r, r)
+            g = H.adj(r)
+            for bt in range(max_bt + 1):
+                u = w - s * g
+                p = soft_threshold(u, lb[v] * s)
+                rp = H.op(p) - Y[v]
+                f_p = 0.5 * np.dot(rp, rp)
+                d = p - w
+                q = f_w + np.dot(d, g) + np.dot(d, d) / (2.0 * s)
+                margin[v] = min(margin[v], abs(f_p - q) / max(abs(q), 1e-300))
+                if f_p <= q or bt >= max_bt:
+                    break
+                s *= eta
+                halv[v] += 1
+            w = p + betas[k] * (p - u)
+        W[v], steps[v] = w, s
+    return W, steps, halv, margin
+
+
 def fista_outputs(W, hrf):
     """``z = cumsum(w)`` and ``x = h * z`` (bold_signal.py:74-75)."""
     Z = np.cumsum(W, axis=-1)

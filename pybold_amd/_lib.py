@@ -70,6 +70,11 @@ SIGNATURES = {
         _c_int, _c_dbl, _c_int, _ptr,    # stop_mode, tol, wind, n_done_dev
         ctypes.c_uint, _ptr,             # flags, stream
         _ptr, _c_dbl, _ptr, _c_i64]),    # lmax_dev, dense_ratio, work_dev, work_len
+    "pb_fista_solve_backtrack_d": (_c_int, [
+        _ptr, _c_i64, _c_int, _ptr, _c_i64, _c_int, _c_int,      # y_dev, ldy, y_rep, w_dev, ldw, P, N
+        _ptr, _c_int, _c_dbl, _c_dbl, _c_int,                    # taps_dev, K, step0, eta, max_halvings_per_iter
+        _c_dbl, _ptr, _ptr, _c_int,                              # lbda, lbda_dev, betas_dev, n_iter
+        _ptr, _ptr, _ptr, ctypes.c_uint, _ptr]),                 # n_done_dev, step_out_dev, halvings_out_dev, flags, stream
     "pb_fista_path_work_len": (_c_i64, [_c_int]),
     "pb_fista_solve_path": (_c_int, [
         _ptr, _c_i64, _c_int,            # y_dev, ldy, y_rep

@@ -1248,6 +1248,31 @@ int pb_fista_solve_d(const double* y_dev, int64_t ldy, int y_rep, double* w_dev,
   return check_launch("fista_generic_kernel(f64)");
 }
 
+int pb_fista_solve_backtrack_d(const double* y_dev, int64_t ldy, int y_rep, double* w_dev, int64_t ldw, int P, int N,
+                               const double* taps_dev, int K, double step0, double eta, int max_halvings_per_iter,
+                               double lbda, const double* lbda_dev, const double* betas_dev, int n_iter,
+                               int32_t* n_done_dev, double* step_out_dev, int32_t* halvings_out_dev, unsigned flags, void* stream) {
+  if (P < 0 || N < 1 || K < 1 || n_iter < 0 || y_rep < 1)
+    return fail(PB_ERR_INVALID, "pb_fista_solve_backtrack_d: bad size (P=%d N=%d K=%d n_iter=%d y_rep=%d)", P, N, K, n_iter, y_rep);
+  if (ldy < N || ldw < N) return fail(PB_ERR_INVALID, "pb_fista_solve_backtrack_d: leading dimension < N");
+  if (!(step0 > 0.0) || !(eta > 0.0 && eta < 1.0) || max_halvings_per_iter < 0)
+    return fail(PB_ERR_INVALID, "pb_fista_solve_backtrack_d: step0 > 0, 0 < eta < 1 and max_halvings_per_iter >= 0 are required");
+  const int64_t nd = 5 * (int64_t)N + K + 2 * pb::GEN_WAVES;
+  if (nd > LDS_DOUBLES_MAX) return fail(PB_ERR_INVALID, "pb_fista_solve_backtrack_d: N=%d K=%d exceeds LDS", N, K);
+  if (P == 0) return PB_OK;
+  if (!y_dev || !w_dev || !taps_dev || (n_iter > 0 && !betas_dev)) return fail(PB_ERR_INVALID, "pb_fista_solve_backtrack_d: NULL pointer");
+  pb::FistaArgs a;
+  a.y = nullptr; a.y64 = y_dev; a.ldy = ldy; a.w = w_dev; a.ldw = ldw; a.lbda_vec = lbda_dev;
+  a.betas = betas_dev; a.J = nullptr; a.J64 = nullptr; a.ldj = 0; a.n_done = n_done_dev;
+  a.step = step0; a.lbda = lbda; a.tol = 0.0;
+  a.y_rep = y_rep; a.P = P; a.N = N; a.n_iter = n_iter; a.stop_mode = PB_STOP_NONE;
+  a.taps_pp = nullptr; a.ldt = 0; a.step_vec = nullptr; a.step_shared = 0; a.K = K; a.p0 = 0;
+  a.cold = (flags & PB_FLAG_COLD_START) ? 1 : 0;
+  hipLaunchKernelGGL(pb::fista_backtrack_kernel, dim3(P), dim3(pb::GEN_THREADS), (size_t)nd * sizeof(double), (hipStream_t)stream,
+                     a, taps_dev, K, eta, max_halvings_per_iter, step_out_dev, halvings_out_dev);
+  return check_launch("fista_backtrack_kernel");
+}
+
 int pb_fista_outputs(const double* w_dev, int64_t ldw, int P, int N, const double* taps_dev, int K,
                      double* z_dev, int64_t ldz, double* x_dev, int64_t ldx, void* stream) {
   if (P < 0 || N < 1 || K < 1 || ldw < N || (z_dev && ldz < N) || (x_dev && ldx < N))

@@ -538,4 +538,89 @@ __global__ __launch_bounds__(GEN_THREADS) void fista_generic_kernel(FistaArgs a_
   if (a_.n_done && threadIdx.x == 0) a_.n_done[p] = min(n_stop, a_.n_iter);
 }
 
+// ---- opt-in extra: the same recurrence with a BACKTRACKED step (north_star's "Lipschitz-backtracked step") ----------
+// The reference has a constant step only (pybold/bold_signal.py:52-53, :253-254), so this mode is never part
+// of a parity run; it is checked against its own float64 NumPy statement (oracle/pybold_oracle.py: fista_backtrack_batch).
+// Beck & Teboulle's rule on the reference's recurrence: per iteration, with g = H^T(H w - y) at the extrapolated point w,
+//   repeat:  u = w - s g;  p = soft(u, lbda s);  accept if  F(p) <= F(w) + <p - w, g> + ||p - w||^2 / (2 s)
+//            (F = 0.5 ||H . - y||^2), else s <- eta s          (at most max_bt times per iteration; s never grows)
+//   w <- p + beta_k (p - u)                                     (the reference's momentum on the gradient point)
+// With s <= 1/L the test passes at once and the iterates are those of the constant-step kernel.
+// One workgroup per problem, float64 end to end.  LDS: w[N] g[N] pt[N] a[N] b[N] k[K] red[8].
+__global__ __launch_bounds__(GEN_THREADS) void fista_backtrack_kernel(FistaArgs a_, const double* taps, int K, double eta,
+                                                                      int max_bt, double* step_out, int32_t* halvings_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int N = a_.N;
+  double* w = reinterpret_cast<double*>(smem);
+  double* g = w + N;
+  double* pt = g + N;
+  double* a = pt + N;
+  double* b = a + N;
+  double* k = b + N;
+  double* red = k + K;
+  const int p = blockIdx.x + a_.p0;
+  const double* yr = a_.y64 + (int64_t)(p / a_.y_rep) * a_.ldy;
+  double* wrow = a_.w + (int64_t)p * a_.ldw;
+  for (int i = threadIdx.x; i < N; i += GEN_THREADS) w[i] = a_.cold ? 0.0 : wrow[i];
+  for (int i = threadIdx.x; i < K; i += GEN_THREADS) k[i] = taps[i];
+  __syncthreads();
+  const double lb = a_.lbda_vec ? a_.lbda_vec[p] : a_.lbda;
+  double s = a_.step;
+  int halvings = 0;
+  for (int it = 0; it < a_.n_iter; ++it) {
+    // F(w) and g = H^T (H w - y)
+    block_cumsum<false>(w, a, N, red);
+    block_conv(a, N, b, N, k, K);
+    double part = 0.0;
+    for (int i = threadIdx.x; i < N; i += GEN_THREADS) {
+      b[i] -= yr[i];
+      part = fma(b[i], b[i], part);
+    }
+    const double f_w = 0.5 * block_sum(part, red);
+    __syncthreads();
+    block_corr(b, N, a, N, k, K);
+    block_cumsum<true>(a, g, N, red);
+    // trials
+    for (int bt = 0;; ++bt) {
+      const double th = lb * s;
+      double dot = 0.0, nd = 0.0;
+      for (int i = threadIdx.x; i < N; i += GEN_THREADS) {
+        const double u = fma(-s, g[i], w[i]);
+        const double pi = u - prox_excess_ref(u, th);
+        pt[i] = pi;
+        const double d = pi - w[i];
+        dot = fma(d, g[i], dot);
+        nd = fma(d, d, nd);
+      }
+      __syncthreads();
+      dot = block_sum(dot, red);
+      nd = block_sum(nd, red);
+      block_cumsum<false>(pt, a, N, red);
+      block_conv(a, N, b, N, k, K);
+      double fp = 0.0;
+      for (int i = threadIdx.x; i < N; i += GEN_THREADS) {
+        const double r = b[i] - yr[i];
+        fp = fma(r, r, fp);
+      }
+      fp = 0.5 * block_sum(fp, red);
+      __syncthreads();
+      if (fp <= f_w + dot + nd / (2.0 * s) || bt >= max_bt) break;      // (uniform: every thread holds the same sums)
+      s *= eta;
+      ++halvings;
+    }
+    const double beta = a_.betas[it];
+    for (int i = threadIdx.x; i < N; i += GEN_THREADS) {
+      const double u = fma(-s, g[i], w[i]);
+      w[i] = fma(beta, pt[i] - u, pt[i]);
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < N; i += GEN_THREADS) wrow[i] = w[i];
+  if (threadIdx.x == 0) {
+    if (a_.n_done) a_.n_done[p] = a_.n_iter;
+    if (step_out) step_out[p] = s;
+    if (halvings_out) halvings_out[p] = halvings;
+  }
+}
+
 }  // namespace pb

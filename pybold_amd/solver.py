@@ -307,6 +307,41 @@ def fista_solve(Y, hrf, lbda, step, n_iter, W0=None, want_J=False, stop=None,
     return W, J, n_done
 
 
+def fista_solve_backtrack(Y, hrf, lbda, step0, n_iter, eta=0.5, max_halvings_per_iter=40, W0=None, y_rep=1):
+    """OPT-IN EXTRA (never part of a parity run; the reference has a constant step only): the recurrence of
+    :func:`fista_solve` with a backtracked step -- ``pb_fista_solve_backtrack_d``.  ``Y`` float64 CUDA ``(V, N)``; ``step0``
+    any positive start step (a caller without ``spectral_radius_est``).  Returns ``(W, step, halvings)``: the iterate, the
+    final step and the number of step reductions of every problem."""
+    lib = _lib.load()
+    Y = _rows(Y, torch.float64, "Y")
+    dev = Y.device
+    V, N = Y.shape
+    P = V * int(y_rep)
+    taps_dev = torch.from_numpy(_as_taps(hrf)).to(dev)
+    cold = 0
+    if W0 is None:
+        W = torch.empty((P, N), dtype=torch.float64, device=dev)
+        cold = PB_FLAG_COLD_START
+    else:
+        W = _rows(W0, torch.float64, "W0").clone()
+    lbda_dev, lbda_scalar = None, 0.0
+    if np.ndim(lbda) == 0 and not torch.is_tensor(lbda):
+        lbda_scalar = float(lbda)
+    else:
+        lbda_dev = torch.as_tensor(lbda, dtype=torch.float64).to(dev).contiguous().ravel()
+    betas = _betas_on(dev, n_iter)
+    step = torch.empty((P,), dtype=torch.float64, device=dev)
+    halv = torch.empty((P,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.pb_fista_solve_backtrack_d(
+            Y.data_ptr(), _ld(Y), int(y_rep), W.data_ptr(), _ld(W), P, N, taps_dev.data_ptr(), taps_dev.numel(),
+            float(step0), float(eta), int(max_halvings_per_iter), lbda_scalar,
+            lbda_dev.data_ptr() if lbda_dev is not None else None, betas.data_ptr(), int(n_iter), None,
+            step.data_ptr(), halv.data_ptr(), cold, _stream_ptr(dev))
+    _lib.check(rc, "pb_fista_solve_backtrack_d")
+    return W, step, halv
+
+
 class FistaPlan:
     """Pre-allocated, launch-only form of :func:`fista_solve` for hot loops and
     graph capture: ``run()`` makes ONE ``pb_fista_solve`` call on the current stream of the

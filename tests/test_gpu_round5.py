@@ -324,3 +324,28 @@ def test_partition_for_series_of_600_scans(solver):
     assert float(((Wp - Wpv).norm(dim=1) / Wpv.norm(dim=1).clamp_min(1e-300)).max()) < 4e-6
     # the dense half did run on the matrix pipe (other bits than the vector forms), the sparse half on the vector forms
     assert not bool((Wp[0::2] == Wpv[0::2]).all())
+
+
+def test_backtracked_step_opt_in_mode(solver, golden):
+    """SURVEY row g2 (BASELINE's "Lipschitz-backtracked step"; the reference itself has a constant step only): the opt-in
+    `pb_fista_solve_backtrack_d` against its own float64 NumPy statement -- the number of step reductions, the final step
+    and the iterate of every problem whose acceptance tests all sit away from equality; with a start step <= 1 / L it is
+    the constant-step solver bit for bit in its decisions (no reduction) and within 1e-12 in its iterates."""
+    g = golden("grid")
+    hrf, lip = g["hrf"], float(g["lip_s0"])
+    rho = lip / 0.9
+    Y = np.stack([g["y_s%d" % s] * a for s in range(4) for a in (1.0, 0.2, -3.0)])
+    Yd = torch.from_numpy(Y).cuda()
+    for step0, lb in ((1.0 / rho, 1.0), (16.0 / rho, 1.0), (300.0 / rho, 0.1), (5.0 / rho, np.linspace(0.05, 5.0, len(Y)))):
+        W, step, halv = solver.fista_solve_backtrack(Yd, hrf, lb, step0, 80)
+        Wo, so, ho, margin = orc.fista_backtrack_batch(Y, hrf, lb, step0, 80)
+        robust = margin > 1e-9
+        assert robust.sum() >= len(Y) - 2, margin
+        assert (halv.cpu().numpy()[robust] == ho[robust]).all() and (step.cpu().numpy()[robust] == so[robust]).all()
+        assert rel_rows(W.cpu().numpy()[robust], Wo[robust]).max() < 1e-10
+        if step0 <= 1.0 / rho:
+            assert int(halv.max()) == 0
+            Wc, _, _ = solver.fista_solve(Yd, hrf, lb, step0, 80)               # the constant-step float64 solver
+            assert rel_rows(W.cpu().numpy(), Wc.cpu().numpy()).max() < 1e-12
+        else:
+            assert int(halv.min()) >= 2 and float(step.max()) <= 2.0 / rho * 1.0001

@@ -276,3 +276,23 @@ def test_device_side_plans_tile_every_list_length():
             assert whole == nm.value, (n, whole, nm.value)
         else:
             assert nm.value == 0 or whole == 0, (n, whole, nm.value, mf.value)
+
+
+def test_backtracking_statement_reduces_to_the_constant_step_recurrence(golden):
+    """The opt-in backtracking mode's NumPy statement (its only checker; the reference has no backtracking): with a
+    start step <= 1 / L every acceptance test passes at once and the iterates are those of the reference's recurrence; from
+    a start step 16x too large it halves the step until the quadratic upper bound holds and the cost still decreases."""
+    g = golden("case1")
+    y, hrf, lip = g["y"], g["hrf"], float(g["lipschitz"])
+    rho = lip / 0.9
+    ref = orc.fista_batch(y[None, :], hrf, 1.0, 1.0 / rho, 60)
+    W, step, halv, margin = orc.fista_backtrack_batch(y[None, :], hrf, 1.0, 1.0 / rho, 60)
+    assert halv[0] == 0 and step[0] == 1.0 / rho
+    np.testing.assert_allclose(W, ref, rtol=0, atol=1e-15)
+    W2, step2, halv2, _ = orc.fista_backtrack_batch(y[None, :], hrf, 1.0, 16.0 / rho, 60)
+    assert 3 <= halv2[0] <= 6 and step2[0] == 16.0 / rho * 0.5 ** halv2[0] and step2[0] <= 2.0 / rho
+
+    def cost(w):
+        r = orc.causal_conv(hrf, np.cumsum(w)) - y
+        return 0.5 * r.dot(r) + np.abs(w).sum()
+    assert cost(W2[0]) < cost(np.zeros_like(y)) and np.isfinite(W2).all()
