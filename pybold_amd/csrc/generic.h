@@ -540,7 +540,7 @@ __global__ __launch_bounds__(GEN_THREADS) void fista_generic_kernel(FistaArgs a_
 
 // ---- opt-in extra: the same recurrence with a BACKTRACKED step (north_star's "Lipschitz-backtracked step") ----------
 // The reference has a constant step only (pybold/bold_signal.py:52-53, :253-254), so this mode is never part
-// of a parity run; it is checked against its own float64 NumPy statement (oracle/pybold_oracle.py: fista_backtrack_batch).
+// of a parity run; it is checked against its own float64 NumPy statement (tests/: `fista_backtrack_batch` of the checker).
 // Beck & Teboulle's rule on the reference's recurrence: per iteration, with g = H^T(H w - y) at the extrapolated point w,
 //   repeat:  u = w - s g;  p = soft(u, lbda s);  accept if  F(p) <= F(w) + <p - w, g> + ||p - w||^2 / (2 s)
 //            (F = 0.5 ||H . - y||^2), else s <- eta s          (at most max_bt times per iteration; s never grows)
