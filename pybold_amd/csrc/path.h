@@ -218,10 +218,14 @@ __global__ __launch_bounds__(256) void lmax_wave_kernel(const float* y, int64_t 
   float acc[SL];
 #pragma unroll
   for (int j = 0; j < SL; ++j) acc[j] = 0.0f;
-  for (int k = 0; k < K; ++k) {                            // one scalar tap load per k, SL independent chains
-    const float hk = tp.h[k];
+  for (int k0 = 0; k0 < K; k0 += 8) {                      // eight taps per scalar load (taps beyond K are zero), SL independent chains
+    float hk[8];
 #pragma unroll
-    for (int j = 0; j < SL; ++j) acc[j] = fmaf(hk, s[lane * SL + j + k], acc[j]);
+    for (int q = 0; q < 8; ++q) hk[q] = tp.h[k0 + q];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int j = 0; j < SL; ++j) acc[j] = fmaf(hk[q], s[lane * SL + j + k0 + q], acc[j]);
   }
   float m = 0.0f;
 #pragma unroll
