@@ -349,3 +349,23 @@ def test_backtracked_step_opt_in_mode(solver, golden):
             assert rel_rows(W.cpu().numpy(), Wc.cpu().numpy()).max() < 1e-12
         else:
             assert int(halv.min()) >= 2 and float(step.max()) <= 2.0 / rho * 1.0001
+
+
+def test_plain_pb_fista_solve_partitions_on_the_librarys_own_workspace(solver):
+    """`pb_fista_solve` (the round-1 signature, no workspace argument: what a C caller and the torch.ops shim use) partitions
+    too, on a workspace the library owns: same bits as `pb_fista_solve_ex` with the caller's workspace, on a mixed batch,
+    twice in a row and on a second stream (one workspace per device and stream)."""
+    from pybold_amd import _lib, torch_ops
+    V, n_it = 20000, 100
+    Y, hrf, step = _mixed_batch(V, 31)
+    lmax = solver.lambda_max(Y, hrf)
+    lam_s = float((0.19 * lmax).median())
+    W_ex, _, nd_ex = solver.fista_solve(Y, hrf, lam_s, step, n_it)
+    W_np, _, _ = solver.fista_solve(Y, hrf, lam_s, step, n_it, force="nopart")
+    assert not torch.equal(W_ex, W_np)                      # (the partition did move the sparse half to other kernels)
+    for stream in (torch.cuda.current_stream(), torch.cuda.Stream()):
+        with torch.cuda.stream(stream):
+            for _ in range(2):
+                W, J, nd = torch_ops.fista_solve(Y, hrf, lam_s, step, n_it)     # -> pb_fista_solve
+                stream.synchronize()
+                assert torch.equal(W, W_ex) and int(nd.min()) == n_it
