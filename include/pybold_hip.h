@@ -69,6 +69,7 @@ extern "C" {
 #define PB_FLAG_NO_PARTITION 4096u  /* never partition a call on the device (see pb_fista_solve_ex): the host-side plan of round 4 */
 #define PB_FLAG_ONLY_DENSE 131072u  /* measurement aids for a partitioned call: only the dense class / only the sparse */
 #define PB_FLAG_ONLY_SPARSE 262144u /*   class is solved; the other class's rows of w and n_done are left untouched */
+#define PB_FLAG_NO_ILL_GUARD 524288u /* partitioned calls: do not single out ill-conditioned series (see pb_fista_solve_ex) */
 #define PB_FLAG_ONE_LAUNCH 32u    /* never split a plain solve into a full-rounds launch and a
                                      remainder launch (see pb_fista_solve) */
 

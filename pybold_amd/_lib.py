@@ -30,6 +30,7 @@ PB_FLAG_NO_RHO_GUARD = 32768
 PB_FLAG_FORCE_MFMA2 = 65536
 PB_FLAG_ONLY_DENSE = 131072
 PB_FLAG_ONLY_SPARSE = 262144
+PB_FLAG_NO_ILL_GUARD = 524288
 PB_PATH_DENSE_RATIO = 0.19          # include/pybold_hip.h (series of up to 310 scans; 0.22 beyond)
 PB_STOP_NONE = 0
 PB_STOP_LOOPS = 1

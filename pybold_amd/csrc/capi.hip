@@ -349,11 +349,14 @@ struct WorkLayout { int64_t ranges, lmax, total; };
 WorkLayout work_layout(int P, int V) {
   const int64_t nblk = ((int64_t)P + pb::PATH_PER_BLOCK - 1) / pb::PATH_PER_BLOCK;
   WorkLayout w;
-  w.ranges = ((int64_t)P + 1 + nblk + 8 + 1) & ~(int64_t)1;
-  w.lmax = w.ranges + 3 * 2 * pb::CAND_COUNT + 2;           // (even: 8-byte aligned when the buffer is)
+  w.ranges = ((int64_t)P + 2 + 2 * nblk + 8 + 1) & ~(int64_t)1;   // (list, n_front, front / ill counts per block, n_ill: path.h)
+  w.lmax = w.ranges + 3 * 2 * pb::CAND_COUNT + 4;           // (3 x candidate ranges + the ill range; even: 8-byte aligned when the buffer is)
   w.total = w.lmax + 2 * (int64_t)V + 8;
   return w;
 }
+// series whose coherence lambda_max / (max|y| sum|c|) lies below this are solved in float64 (path.h: path_class;
+// profiles/r5_conditioning_probe.txt: every family at or above 8.9e-3 holds 1.7e-6, families at 4.3e-3 reach 1.5e-5)
+constexpr double PART_ILL_GAMMA = 7.0e-3;
 // below this many problems a call is latency-bound and keeps the host-side plan (a partition costs ~8 small launches)
 constexpr int PART_MIN_P = 4096;
 
@@ -712,27 +715,33 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
                            auto&& launch_form, auto&& has_form, auto&& bound) -> int {
     const WorkLayout wl = work_layout(P, V_series);
     hipStream_t user = (hipStream_t)stream;
-    // lambda_max of every series, unless the caller has it
-    const double* lmax = lmax_dev;
-    if (!lmax) {
-      double* lm = reinterpret_cast<double*>(work_dev + wl.lmax);
+    // lambda_max of every series (the caller's lmax_dev is not needed any more: the pass also sees max|y| and marks the
+    // ill-conditioned series, which the caller's numbers do not tell) -- float32, ~55 us per 100 k series
+    double* lm = reinterpret_cast<double*>(work_dev + wl.lmax);
+    {
       pb::LmaxTaps lt;
+      double run = 0.0, csum = 0.0;                   // sum|c| over the N lags of the operator's step response c = cumsum(h)
       for (int k = 0; k < pb::LMAX_KT; ++k) lt.h[k] = k < K ? (float)taps_host[k] : 0.0f;
+      for (int t = 0; t < N; ++t) { if (t < K) run += taps_host[t]; csum += std::fabs(run); }
+      // (the float64 LDS kernel takes the marked series: it needs the taps in device memory and the row in LDS)
+      const int64_t nd_g = 3 * (int64_t)N + K + 2 * pb::GEN_WAVES + (stop_mode == PB_STOP_WINDOW ? (int64_t)wind * N : 0);
+      const float ill_bound = (taps_dev && nd_g <= LDS_DOUBLES_MAX && !(flags & PB_FLAG_NO_ILL_GUARD)) ? (float)(PART_ILL_GAMMA * csum) : 0.0f;
       const dim3 grid((unsigned)((V_series + 3) / 4)), block(256);
-      if (N <= 320) hipLaunchKernelGGL((pb::lmax_wave_kernel<5>), grid, block, 4 * (64 * 5 + pb::LMAX_KT) * sizeof(float), user, y_dev, ldy, V_series, N, lt, K, lm);
-      else hipLaunchKernelGGL((pb::lmax_wave_kernel<10>), grid, block, 4 * (64 * 10 + pb::LMAX_KT) * sizeof(float), user, y_dev, ldy, V_series, N, lt, K, lm);
-      lmax = lm;
+      if (N <= 320) hipLaunchKernelGGL((pb::lmax_wave_kernel<5>), grid, block, 4 * (64 * 5 + pb::LMAX_KT) * sizeof(float), user, y_dev, ldy, V_series, N, lt, K, lm, ill_bound);
+      else hipLaunchKernelGGL((pb::lmax_wave_kernel<10>), grid, block, 4 * (64 * 10 + pb::LMAX_KT) * sizeof(float), user, y_dev, ldy, V_series, N, lt, K, lm, ill_bound);
     }
+    const double* lmax = lm;
     const int nblk = (P + pb::PATH_PER_BLOCK - 1) / pb::PATH_PER_BLOCK;
     int32_t* rg_dense = work_dev + wl.ranges;
     int32_t* rg_sparse = rg_dense + 2 * pb::CAND_COUNT;
     int32_t* rg_flag = rg_sparse + 2 * pb::CAND_COUNT;
+    int32_t* rg_ill = rg_flag + 2 * pb::CAND_COUNT;
     {
       pb::ClassPred cp{lbda_dev, lbda, lmax, y_rep, dense_ratio > 0.0 ? dense_ratio : (N > MFMA1_NMAX ? PB_PATH_DENSE_RATIO_LONG : PB_PATH_DENSE_RATIO), nullptr};
       hipLaunchKernelGGL(pb::path_count_kernel, dim3(nblk), dim3(pb::PATH_THREADS), 0, user, cp, P, work_dev);
       pb::PlanSpec front = dense;
       front.merged = 1;
-      hipLaunchKernelGGL(pb::path_scan_kernel, dim3(1), dim3(pb::PATH_THREADS), 0, user, P, nblk, work_dev, front, sparse, rg_dense, rg_sparse);
+      hipLaunchKernelGGL(pb::path_scan_kernel, dim3(1), dim3(pb::PATH_THREADS), 0, user, P, nblk, work_dev, front, sparse, rg_dense, rg_sparse, rg_ill);
       hipLaunchKernelGGL(pb::path_scatter_kernel, dim3(nblk), dim3(pb::PATH_THREADS), 0, user, cp, P, work_dev);
       const int rc = check_launch("partition");
       if (rc != PB_OK) return rc;
@@ -777,11 +786,27 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
     const bool only_dense = (flags & PB_FLAG_ONLY_DENSE) != 0, only_sparse = (flags & PB_FLAG_ONLY_SPARSE) != 0;   // (measurement aids)
     int rc = solve_list(rg_dense, 1, only_dense ? 1 : (only_sparse ? 2 : 0), false);
     if (rc != PB_OK || only_dense || only_sparse) return rc;
+    // the ill-conditioned series (marked by the lambda_max pass, the tail of the list array): float64 LDS kernel, any stop
+    // rule; its workgroups stride over the list, which is empty for ordinary data
+    if (taps_dev) {
+      pb::FistaArgs b = a;
+      b.perm = work_dev;
+      b.perm_side = 1;
+      b.range = rg_ill;
+      const int64_t nd_g = 3 * (int64_t)N + K + 2 * pb::GEN_WAVES + (stop_mode == PB_STOP_WINDOW ? (int64_t)wind * N : 0);
+      if (nd_g <= LDS_DOUBLES_MAX) {
+        const int wgs = P < 2048 ? P : 2048;
+        if (J_dev) hipLaunchKernelGGL((pb::fista_generic_kernel<true>), dim3(wgs), dim3(pb::GEN_THREADS), (size_t)nd_g * sizeof(double), user, b, taps_dev, K, wind);
+        else hipLaunchKernelGGL((pb::fista_generic_kernel<false>), dim3(wgs), dim3(pb::GEN_THREADS), (size_t)nd_g * sizeof(double), user, b, taps_dev, K, wind);
+        rc = check_launch("fista_generic_kernel(ill-conditioned series)");
+        if (rc != PB_OK) return rc;
+      }
+    }
     // what the guards / certificates handed back (n_done = -1): compacted, then the exact vector forms at full occupancy
     pb::ClassPred cp{nullptr, 0.0, nullptr, 1, 0.0, n_done_dev};
     const pb::PlanSpec none{0, 0, 0, 0, 1, 0, 0, dense.slots};
     hipLaunchKernelGGL(pb::path_count_kernel, dim3(nblk), dim3(pb::PATH_THREADS), 0, user, cp, P, work_dev);
-    hipLaunchKernelGGL(pb::path_scan_kernel, dim3(1), dim3(pb::PATH_THREADS), 0, user, P, nblk, work_dev, flagged, none, rg_flag, (int32_t*)nullptr);
+    hipLaunchKernelGGL(pb::path_scan_kernel, dim3(1), dim3(pb::PATH_THREADS), 0, user, P, nblk, work_dev, flagged, none, rg_flag, (int32_t*)nullptr, (int32_t*)nullptr);
     hipLaunchKernelGGL(pb::path_scatter_kernel, dim3(nblk), dim3(pb::PATH_THREADS), 0, user, cp, P, work_dev);
     rc = check_launch("partition(handed back)");
     if (rc != PB_OK) return rc;

@@ -66,10 +66,10 @@ struct FistaArgs {
   int rho_guard = 1;      // matrix-pipe form: hand sparse solutions (th / max|w| > MFMA_RHO_MAX) back to the vector forms
   int only_flagged = 0;   // 1: solve only the problems with n_done[p] < 0 (left by the certificate
                           //    form of the pair kernel, fista_pair_ffa.h), skip the others
-  // Partition of a regularisation path (pb_fista_solve_path, path.h): perm[0 .. *n_dense) lists the problems of the
-  // dense class in ascending order, perm[P-1], perm[P-2], ... those of the sparse class.  perm_side = 1: this launch
-  // solves the dense list (slot s -> problem perm[s]), 2: the sparse list (slot s -> perm[P-1-s]); the count is read on
-  // the device, so the grid covers P slots and the waves beyond the list leave at once.  0: slot = problem.
+  // Lists built on the device (path.h): perm[0 .. *n_dense) the front class in ascending order, the middle class behind
+  // it, ill-conditioned problems descending from perm[P-1].  perm_side = 1 (and 3): slot s -> problem perm[s]; 2: the
+  // middle class on its own (slot s -> perm[*n_dense + s]); counts and ranges are read on the device, so a grid covers a
+  // host bound and the waves beyond the list leave at once.  0: slot = problem.
   const int32_t* perm = nullptr;
   const int32_t* n_dense = nullptr;
   int perm_side = 0;
@@ -104,7 +104,7 @@ __device__ __forceinline__ void launch_slots(const FistaArgs& a, int& s0, int& s
 __device__ __forceinline__ int slot_to_problem(const FistaArgs& a, int slot, int n_list, bool& live) {
   live = slot < n_list;
   if (a.perm_side == 0) return live ? slot : a.P - 1;
-  return live ? a.perm[a.perm_side == 2 ? a.P - 1 - slot : slot] : 0;        // (sides 1 and 3: ascending from the front)
+  return live ? a.perm[a.perm_side == 2 ? *a.n_dense + slot : slot] : 0;     // (sides 1 and 3: positions of the list array)
 }
 
 // Tap pairs as kernel arguments (read with scalar loads, kept in SGPRs).

@@ -451,7 +451,12 @@ __global__ __launch_bounds__(GEN_THREADS) void fista_generic_kernel(FistaArgs a_
   double* k = b + N;
   double* red = k + K;
   double* hist = red + 2 * GEN_WAVES;
-  const int p = blockIdx.x + a_.p0;
+  // a launch over a device-side list (round 5: the ill-conditioned problems of a partitioned call): the workgroups stride
+  // over the slots [range[0], range[1]) of the list array, which may hold none or many
+  int slot = a_.range ? a_.range[0] + (int)blockIdx.x : 0;
+  const int slot_end = a_.range ? a_.range[1] : 1;
+  for (; slot < slot_end; slot += (a_.range ? (int)gridDim.x : 1)) {
+  const int p = a_.range ? a_.perm[slot] : (int)blockIdx.x + a_.p0;
   const TY* yr = [&] {
     if constexpr (F64IO) return a_.y64 + (int64_t)(p / a_.y_rep) * a_.ldy;
     else return a_.y + (int64_t)(p / a_.y_rep) * a_.ldy;
@@ -459,6 +464,7 @@ __global__ __launch_bounds__(GEN_THREADS) void fista_generic_kernel(FistaArgs a_
   double* wrow = a_.w + (int64_t)p * a_.ldw;
   const double* tp = a_.taps_pp ? a_.taps_pp + (int64_t)p * a_.ldt : taps;
   const double stp = a_.step_vec ? a_.step_vec[a_.step_shared ? 0 : p] : a_.step;
+  __syncthreads();                                  // (the previous problem of this workgroup is out of LDS)
   for (int i = threadIdx.x; i < N; i += GEN_THREADS) w[i] = a_.cold ? 0.0 : wrow[i];
   for (int i = threadIdx.x; i < K; i += GEN_THREADS) k[i] = tp[i];
   __syncthreads();
@@ -536,6 +542,7 @@ __global__ __launch_bounds__(GEN_THREADS) void fista_generic_kernel(FistaArgs a_
   }
   for (int i = threadIdx.x; i < N; i += GEN_THREADS) wrow[i] = w[i];
   if (a_.n_done && threadIdx.x == 0) a_.n_done[p] = min(n_stop, a_.n_iter);
+  }
 }
 
 // ---- opt-in extra: the same recurrence with a BACKTRACKED step (north_star's "Lipschitz-backtracked step") ----------

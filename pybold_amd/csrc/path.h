@@ -36,22 +36,41 @@ struct ClassPred {
   const int32_t* n_done;   // != nullptr: the predicate is n_done[p] < 0 instead (handed-back problems)
 };
 
-__device__ __forceinline__ bool path_is_dense(const ClassPred& c, int p) {
-  if (c.n_done) return c.n_done[p] < 0;
+// class of a problem: 0 = front list (dense; or handed back, with the n_done predicate), 1 = the list behind it (sparse),
+// 2 = ILL-CONDITIONED (round 5): a series the operator barely sees -- lambda_max << max|y| sum|c| (alternating signs, fast
+// sinusoids, high-pass noise) -- loses digits in ANY arithmetic narrower than float64 (matrix pipe up to 5e-5, float32
+// vector forms up to 3e-5 on diff_z / z / x: profiles/r5_conditioning_probe.txt); the lambda_max pass marks such series
+// with a NEGATIVE lambda_max and they are solved by the float64 LDS kernel.
+__device__ __forceinline__ int path_class(const ClassPred& c, int p) {
+  if (c.n_done) return c.n_done[p] < 0 ? 0 : 1;
+  const double lm = c.lmax[p / c.y_rep];
+  if (lm < 0.0) return 2;
   const double lb = c.lbda ? c.lbda[p] : c.lbda_s;
-  return lb < c.ratio * c.lmax[p / c.y_rep];       // (lambda_max = 0, an all-zero series: sparse -- its solution is 0)
+  return lb < c.ratio * lm ? 0 : 1;                 // (lambda_max = 0, an all-zero series: sparse -- its solution is 0)
 }
 
-// dense problems of every block of 4 096
+// layout of the counters behind the list array (int32 units from work + P): [0] n_front, [1, 1+nblk) front counts per block,
+// [1+nblk, 1+2 nblk) ill counts per block, [1+2 nblk] n_ill
+__host__ __device__ inline int path_nill_offset(int nblk) { return 1 + 2 * nblk; }
+
+// front and ill problems of every block of 4 096
 __global__ __launch_bounds__(PATH_THREADS) void path_count_kernel(ClassPred cp, int P, int32_t* work) {
-  __shared__ int part[PATH_THREADS / 64];
+  __shared__ int part[2][PATH_THREADS / 64];
   const int p0 = blockIdx.x * PATH_PER_BLOCK + threadIdx.x * PATH_PER_THREAD;
-  int c = 0;
-  for (int i = 0; i < PATH_PER_THREAD; ++i) c += (p0 + i < P && path_is_dense(cp, p0 + i)) ? 1 : 0;
-  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+  int c = 0, ci = 0;
+  for (int i = 0; i < PATH_PER_THREAD; ++i) {
+    if (p0 + i >= P) break;
+    const int k = path_class(cp, p0 + i);
+    c += k == 0;
+    ci += k == 2;
+  }
+  for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o, 64); ci += __shfl_xor(ci, o, 64); }
+  if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = c; part[1][threadIdx.x >> 6] = ci; }
   __syncthreads();
-  if (threadIdx.x == 0) work[P + 1 + blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+  if (threadIdx.x == 0) {
+    work[P + 1 + blockIdx.x] = part[0][0] + part[0][1] + part[0][2] + part[0][3];
+    work[P + 1 + gridDim.x + blockIdx.x] = part[1][0] + part[1][1] + part[1][2] + part[1][3];
+  }
 }
 
 // exclusive prefix of the block counts (in place) and the total -- one workgroup, blocks dealt in chunks of 256
@@ -72,60 +91,79 @@ __device__ __forceinline__ void plan_call(const PlanSpec& front, const PlanSpec&
 
 // ... and, once the total is known, the launch plans of the two lists (thread 0: plan.h's planners on the list lengths)
 __global__ __launch_bounds__(PATH_THREADS) void path_scan_kernel(int P, int nblk, int32_t* work, PlanSpec front, PlanSpec back,
-                                                                  int32_t* ranges_front, int32_t* ranges_back) {
+                                                                  int32_t* ranges_front, int32_t* ranges_back, int32_t* range_ill) {
   __shared__ int buf[PATH_THREADS];
   __shared__ int carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  int32_t* cnt = work + P + 1;
-  for (int b0 = 0; b0 < nblk; b0 += PATH_THREADS) {
-    const int b = b0 + (int)threadIdx.x;
-    const int v = b < nblk ? cnt[b] : 0;
-    buf[threadIdx.x] = v;
+  int total[2] = {0, 0};
+  for (int which = 0; which < 2; ++which) {         // 0: front counts, 1: ill counts
+    if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    for (int o = 1; o < PATH_THREADS; o <<= 1) {    // inclusive Hillis-Steele scan of 256 counts
-      const int add = threadIdx.x >= (unsigned)o ? buf[threadIdx.x - o] : 0;
+    int32_t* cnt = work + P + 1 + which * nblk;
+    for (int b0 = 0; b0 < nblk; b0 += PATH_THREADS) {
+      const int b = b0 + (int)threadIdx.x;
+      const int v = b < nblk ? cnt[b] : 0;
+      buf[threadIdx.x] = v;
       __syncthreads();
-      buf[threadIdx.x] += add;
+      for (int o = 1; o < PATH_THREADS; o <<= 1) {    // inclusive Hillis-Steele scan of 256 counts
+        const int add = threadIdx.x >= (unsigned)o ? buf[threadIdx.x - o] : 0;
+        __syncthreads();
+        buf[threadIdx.x] += add;
+        __syncthreads();
+      }
+      if (b < nblk) cnt[b] = carry + buf[threadIdx.x] - v;
+      __syncthreads();
+      if (threadIdx.x == PATH_THREADS - 1) carry += buf[PATH_THREADS - 1];
       __syncthreads();
     }
-    if (b < nblk) cnt[b] = carry + buf[threadIdx.x] - v;
-    __syncthreads();
-    if (threadIdx.x == PATH_THREADS - 1) carry += buf[PATH_THREADS - 1];
+    total[which] = carry;
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    work[P] = carry;
-    if (ranges_front && front.merged) plan_call(front, back, carry, P, ranges_front);
+    const int n_front = total[0], n_ill = total[1], P_eff = P - n_ill;
+    work[P] = n_front;
+    work[P + path_nill_offset(nblk)] = n_ill;
+    if (range_ill) { range_ill[0] = P_eff; range_ill[1] = P; }       // the ill-conditioned problems: the tail of the list array
+    if (ranges_front && front.merged) plan_call(front, back, n_front, P_eff, ranges_front);
     else {
-      if (ranges_front) plan_list(front, carry, ranges_front);
-      if (ranges_back) plan_list(back, P - carry, ranges_back);
+      if (ranges_front) plan_list(front, n_front, ranges_front);
+      if (ranges_back) plan_list(back, P_eff - n_front, ranges_back);
     }
   }
 }
 
-// the two lists
+// the lists: front problems ascending from position 0, the others ascending behind them (from n_front), ill-conditioned
+// ones descending from the end -- every list is read as list[slot]
 __global__ __launch_bounds__(PATH_THREADS) void path_scatter_kernel(ClassPred cp, int P, int32_t* work) {
-  __shared__ int buf[PATH_THREADS];
+  __shared__ int buf[2][PATH_THREADS];
   const int p0 = blockIdx.x * PATH_PER_BLOCK + threadIdx.x * PATH_PER_THREAD;
-  unsigned mask = 0;
-  int c = 0;
-  for (int i = 0; i < PATH_PER_THREAD; ++i)
-    if (p0 + i < P && path_is_dense(cp, p0 + i)) { mask |= 1u << i; ++c; }
-  buf[threadIdx.x] = c;
+  unsigned mask = 0, maski = 0;
+  int c = 0, ci = 0;
+  for (int i = 0; i < PATH_PER_THREAD; ++i) {
+    if (p0 + i >= P) break;
+    const int k = path_class(cp, p0 + i);
+    if (k == 0) { mask |= 1u << i; ++c; }
+    if (k == 2) { maski |= 1u << i; ++ci; }
+  }
+  buf[0][threadIdx.x] = c;
+  buf[1][threadIdx.x] = ci;
   __syncthreads();
   for (int o = 1; o < PATH_THREADS; o <<= 1) {
-    const int add = threadIdx.x >= (unsigned)o ? buf[threadIdx.x - o] : 0;
+    const int add = threadIdx.x >= (unsigned)o ? buf[0][threadIdx.x - o] : 0;
+    const int addi = threadIdx.x >= (unsigned)o ? buf[1][threadIdx.x - o] : 0;
     __syncthreads();
-    buf[threadIdx.x] += add;
+    buf[0][threadIdx.x] += add;
+    buf[1][threadIdx.x] += addi;
     __syncthreads();
   }
-  int d = work[P + 1 + blockIdx.x] + buf[threadIdx.x] - c;       // dense problems before this thread's first one
+  const int n_front = work[P];
+  int d = work[P + 1 + blockIdx.x] + buf[0][threadIdx.x] - c;                  // front problems before this thread's first one
+  int e = work[P + 1 + gridDim.x + blockIdx.x] + buf[1][threadIdx.x] - ci;     // ill-conditioned problems before it
   for (int i = 0; i < PATH_PER_THREAD; ++i) {
     const int p = p0 + i;
     if (p >= P) break;
     if (mask & (1u << i)) work[d++] = p;
-    else work[P - 1 - (p - d)] = p;                // p - d = sparse problems before p
+    else if (maski & (1u << i)) work[P - 1 - (e++)] = p;
+    else work[n_front + (p - d - e)] = p;          // p - d - e = problems of the middle class before p
   }
 }
 
@@ -182,12 +220,13 @@ __device__ __forceinline__ void plan_call(const PlanSpec& front, const PlanSpec&
 // samples (loaded straight from HBM: staging the series through LDS for coalesced loads measured 18 % slower -- the
 // pass is bound by the latency of its 100 000 short waves, not by bandwidth), the suffix sums go through LDS (stride-SL
 // reads: conflict-free for odd SL), the taps come as kernel arguments.  Float32 arithmetic: the result only decides a class (ratio test at 13 %), and pb_lambda_max stays the
-// float64 answer for callers who want the number.
+// float64 answer for callers who want the number.  The pass also sees max|y| and marks ILL-CONDITIONED series (path_class).
 constexpr int LMAX_KT = 64;
 struct LmaxTaps { float h[LMAX_KT]; };
 
 template <int SL>
-__global__ __launch_bounds__(256) void lmax_wave_kernel(const float* y, int64_t ldy, int V, int N, LmaxTaps tp, int K, double* out) {
+__global__ __launch_bounds__(256) void lmax_wave_kernel(const float* y, int64_t ldy, int V, int N, LmaxTaps tp, int K, double* out,
+                                                        float ill_bound) {
   extern __shared__ float lm_smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int v = blockIdx.x * 4 + wv;
@@ -195,11 +234,13 @@ __global__ __launch_bounds__(256) void lmax_wave_kernel(const float* y, int64_t 
   float* s = lm_smem + wv * (64 * SL + LMAX_KT);
   const float* yrow = y + (int64_t)v * ldy;
   float loc[SL];
-  float run = 0.0f;
+  float run = 0.0f, ymax = 0.0f;
 #pragma unroll
   for (int j = SL - 1; j >= 0; --j) {
     const int t = lane * SL + j;
-    run += t < N ? yrow[t] : 0.0f;
+    const float yv = t < N ? yrow[t] : 0.0f;
+    ymax = fmaxf(ymax, fabsf(yv));
+    run += yv;
     loc[j] = run;                                          // suffix sums inside the strip
   }
   float above = run;                                       // exclusive suffix over the lanes above
@@ -231,8 +272,9 @@ __global__ __launch_bounds__(256) void lmax_wave_kernel(const float* y, int64_t 
 #pragma unroll
   for (int j = 0; j < SL; ++j) m = fmaxf(m, lane * SL + j < N ? fabsf(acc[j]) : 0.0f);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if (lane == 0) out[v] = (double)m;
+  for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o, 64)); ymax = fmaxf(ymax, __shfl_xor(ymax, o, 64)); }
+  // coherence gamma = lambda_max / (max|y| sum|c|) below the bound (ill_bound = gamma_0 sum|c|): marked by the sign
+  if (lane == 0) out[v] = (m > 0.0f && m < ill_bound * ymax) ? -(double)m : (double)m;
 }
 
 }  // namespace pb

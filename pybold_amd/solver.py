@@ -38,6 +38,7 @@ _FORCE = {None: 0, "generic": PB_FLAG_FORCE_GENERIC, "fast": PB_FLAG_FORCE_FAST,
           # a partitioned call, measurement aids: only the dense class is solved / only the sparse class
           "path_dense": _lib.PB_FLAG_ONLY_DENSE, "path_sparse": _lib.PB_FLAG_ONLY_SPARSE,
           # the host-side plan of round 4 (no partition on the device)
+          "noill": _lib.PB_FLAG_NO_ILL_GUARD,     # partitioned, but ill-conditioned series stay with their class (measurement aid)
           "nopart": _lib.PB_FLAG_NO_PARTITION, "nopartseq": _lib.PB_FLAG_NO_PARTITION | PB_FLAG_ONE_STREAM,
           "mfma2": _lib.PB_FLAG_FORCE_MFMA2, "mfma2only": _lib.PB_FLAG_FORCE_MFMA2 | _lib.PB_FLAG_CERT_NO_RESOLVE,
           "mfma2cert": _lib.PB_FLAG_FORCE_MFMA2 | PB_FLAG_FORCE_CERT,

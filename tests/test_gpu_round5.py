@@ -369,3 +369,48 @@ def test_plain_pb_fista_solve_partitions_on_the_librarys_own_workspace(solver):
                 W, J, nd = torch_ops.fista_solve(Y, hrf, lam_s, step, n_it)     # -> pb_fista_solve
                 stream.synchronize()
                 assert torch.equal(W, W_ex) and int(nd.min()) == n_it
+
+
+def test_ill_conditioned_series_are_solved_in_float64(solver, golden):
+    """Series the operator H = K_h . cumsum barely sees -- alternating signs, sinusoids of period 3 / 4, high-pass noise,
+    such a series plus 1e-3 .. 1e-2 of an ordinary one: coherence lambda_max / (max|y| sum|c|) of 1e-3 .. 4e-3 against
+    3e-2 .. 1 for ordinary data -- lose digits in every arithmetic narrower than float64: up to 5e-5 on the matrix pipe
+    and 3e-5 on the float32 vector forms (tools/r5_conditioning_probe.py, profiles/r5_conditioning_probe.txt: eps is
+    1e-5).  A partitioned call marks them in its lambda_max pass and solves them on the float64 LDS kernel: through the
+    DEFAULT dispatch every family is within eps on diff_z, z AND x, at lambda = 0, 0.05 lambda_max and 1, with the cost
+    trace and the window rule too; ordinary series next to them keep their kernels (timing: a handful of rows)."""
+    g = golden("case1")
+    hrf, lip = g["hrf"], float(g["lipschitz"])
+    N, step = 300, 1.0 / lip
+    t = np.arange(N)
+    rng = np.random.RandomState(1)
+    alt = np.where(t % 2 == 0, 1.0, -1.0)
+    hp = rng.randn(N)
+    fams = [g["y"], rng.randn(N), alt, np.sin(2 * np.pi * t / 3), np.sin(2 * np.pi * t / 4), np.sin(2 * np.pi * t / 6),
+            np.sin(2 * np.pi * t / 10), np.diff(np.r_[0.0, hp]), np.diff(np.r_[0.0, 0.0, hp], n=2), alt + 1e-3 * g["y"],
+            alt + 1e-2 * g["y"], alt + 0.1 * g["y"], alt * (1 + np.sin(2 * np.pi * t / 100)), np.ones(N), 37.0 * alt, 1e-3 * alt]
+    Y = np.stack(fams)
+    reps = 4096 // len(fams) + 1
+    Yd = torch.from_numpy(np.tile(Y, (reps, 1)).astype(np.float32)).cuda()          # 4 112 problems: a partitioned call
+    Yo = Yd[:len(fams)].cpu().numpy().astype(np.float64)
+    lmax = solver.lambda_max(Yd, hrf)
+    worst_default, worst_unguarded = 0.0, 0.0
+    for lam in (0.0, 0.05 * lmax, 1.0):
+        lam_o = lam[:len(fams)].cpu().numpy() if torch.is_tensor(lam) else lam
+        ref = orc.fista_batch(Yo, hrf, lam_o, step, 500)
+        xr, zr = orc.fista_outputs(ref, hrf)
+        for kw in (dict(), dict(want_J=True, stop="window", tol=1e-7, wind=6)):
+            for force in (None, "noill"):
+                W, J, nd = solver.fista_solve(Yd, hrf, lam, step, 500, force=force, **kw)
+                assert int(nd.min()) == 500
+                X, Z = solver.fista_outputs(W[:len(fams)].contiguous(), hrf)
+                e = max(rel_rows(W[:len(fams)].cpu().numpy(), ref).max(), rel_rows(Z.cpu().numpy(), zr).max(),
+                        rel_rows(X.cpu().numpy(), xr).max())
+                if force is None:
+                    assert e < 1e-5, (kw, e)
+                    worst_default = max(worst_default, e)
+                    assert torch.equal(W[:len(fams)], W[len(fams):2 * len(fams)])       # (the same series anywhere in the batch)
+                else:
+                    worst_unguarded = max(worst_unguarded, e)
+    print("ill-conditioned families through the default dispatch: worst %.1e (guard off: %.1e)" % (worst_default, worst_unguarded))
+    assert worst_unguarded > 1e-5                       # (the guard is what holds eps here)
