@@ -71,7 +71,7 @@ def _warn_if_slow_kernel(lib, N, K, P, want_J, stop, wind, flags):
     if P < 256 or (flags & (PB_FLAG_FORCE_GENERIC | PB_FLAG_FORCE_FAST)):
         return
     form = lib.pb_fista_which_kernel(int(N), int(K), int(P), int(bool(want_J)), _STOP[stop], int(wind))
-    if form in (1, 2, 3) and P >= 4096 and not (flags & (_lib.PB_FLAG_NO_MFMA | PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_FORCE_WIDE)):
+    if form in (1, 2, 3) and P >= 16384 and not (flags & (_lib.PB_FLAG_NO_MFMA | PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_FORCE_WIDE)):
         # a machine-filling batch on a vector form although a matrix-pipe form exists for neighbouring shapes: say which
         # limit the call ran into (rates at 300 / 600 scans: matrix pipe 4.8 / 2.0e9 voxel-iterations/s, vector forms
         # 1.4-3.0e9, one problem per wave 0.5-0.6e9 -- DESIGN 6)
