@@ -354,9 +354,9 @@ WorkLayout work_layout(int P, int V) {
   w.total = w.lmax + 2 * (int64_t)V + 8;
   return w;
 }
-// series whose coherence lambda_max / (max|y| sum|c|) lies below this are solved in float64 (path.h: path_class;
-// profiles/r5_conditioning_probe.txt: every family at or above 8.9e-3 holds 1.7e-6, families at 4.3e-3 reach 1.5e-5)
-constexpr double PART_ILL_GAMMA = 7.0e-3;
+// coherence bounds of the conditioning guard (path.h: path_class; calibrated on 5 120 series per length,
+// profiles/r5_gamma_calibration_*.txt: above them the matrix-pipe form holds 3.3e-6 and the float32 vector forms 3e-6)
+constexpr double PART_GAMMA_F64 = 1.0e-2, PART_GAMMA_MATRIX_PIPE = 7.0e-2;
 // below this many problems a call is latency-bound and keeps the host-side plan (a partition costs ~8 small launches)
 constexpr int PART_MIN_P = 4096;
 
@@ -725,10 +725,13 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
       for (int t = 0; t < N; ++t) { if (t < K) run += taps_host[t]; csum += std::fabs(run); }
       // (the float64 LDS kernel takes the marked series: it needs the taps in device memory and the row in LDS)
       const int64_t nd_g = 3 * (int64_t)N + K + 2 * pb::GEN_WAVES + (stop_mode == PB_STOP_WINDOW ? (int64_t)wind * N : 0);
-      const float ill_bound = (taps_dev && nd_g <= LDS_DOUBLES_MAX && !(flags & PB_FLAG_NO_ILL_GUARD)) ? (float)(PART_ILL_GAMMA * csum) : 0.0f;
+      const bool guard = !(flags & PB_FLAG_NO_ILL_GUARD);
+      const double unit = csum / std::sqrt((double)N);
+      const float f64_bound = (guard && taps_dev && nd_g <= LDS_DOUBLES_MAX) ? (float)(PART_GAMMA_F64 * unit) : 0.0f;
+      const float vec_bound = guard ? (float)(PART_GAMMA_MATRIX_PIPE * unit) : 0.0f;
       const dim3 grid((unsigned)((V_series + 3) / 4)), block(256);
-      if (N <= 320) hipLaunchKernelGGL((pb::lmax_wave_kernel<5>), grid, block, 4 * (64 * 5 + pb::LMAX_KT) * sizeof(float), user, y_dev, ldy, V_series, N, lt, K, lm, ill_bound);
-      else hipLaunchKernelGGL((pb::lmax_wave_kernel<10>), grid, block, 4 * (64 * 10 + pb::LMAX_KT) * sizeof(float), user, y_dev, ldy, V_series, N, lt, K, lm, ill_bound);
+      if (N <= 320) hipLaunchKernelGGL((pb::lmax_wave_kernel<5>), grid, block, 4 * (64 * 5 + pb::LMAX_KT) * sizeof(float), user, y_dev, ldy, V_series, N, lt, K, lm, f64_bound, vec_bound);
+      else hipLaunchKernelGGL((pb::lmax_wave_kernel<10>), grid, block, 4 * (64 * 10 + pb::LMAX_KT) * sizeof(float), user, y_dev, ldy, V_series, N, lt, K, lm, f64_bound, vec_bound);
     }
     const double* lmax = lm;
     const int nblk = (P + pb::PATH_PER_BLOCK - 1) / pb::PATH_PER_BLOCK;

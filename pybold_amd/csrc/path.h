@@ -37,10 +37,14 @@ struct ClassPred {
 };
 
 // class of a problem: 0 = front list (dense; or handed back, with the n_done predicate), 1 = the list behind it (sparse),
-// 2 = ILL-CONDITIONED (round 5): a series the operator barely sees -- lambda_max << max|y| sum|c| (alternating signs, fast
-// sinusoids, high-pass noise) -- loses digits in ANY arithmetic narrower than float64 (matrix pipe up to 5e-5, float32
-// vector forms up to 3e-5 on diff_z / z / x: profiles/r5_conditioning_probe.txt); the lambda_max pass marks such series
-// with a NEGATIVE lambda_max and they are solved by the float64 LDS kernel.
+// 2 = ILL-CONDITIONED (round 5).  A series most of whose energy the operator H = K_h . cumsum does not see (alternating
+// signs, fast sinusoids, high-pass noise, an ordinary signal under a strong fast carrier) loses digits in every
+// arithmetic narrower than float64: with the coherence gamma_2 = lambda_max / (||y||_2 sum|c| / sqrt(N)), c = cumsum(h)
+// (ordinary block signals at SNR 1 dB: 0.25 .. 0.5, white noise: 0.02 .. 0.2), the matrix-pipe form reaches 1e-5 on
+// diff_z / z / x below gamma_2 ~ 3e-2 and 4e-4 below 3e-3, the float32 vector forms 7e-6 below 5e-3 and 5e-3 below 1e-3
+// (tools/r5_gamma_calibration.py, profiles/r5_gamma_calibration_*.txt).  The lambda_max pass therefore marks series with
+// gamma_2 < 1e-2 by a NEGATIVE lambda_max (class 2: float64 LDS kernel) and stores 0 for gamma_2 < 7e-2 (class 1
+// whatever lambda: float32 vector forms, never the matrix pipe).
 __device__ __forceinline__ int path_class(const ClassPred& c, int p) {
   if (c.n_done) return c.n_done[p] < 0 ? 0 : 1;
   const double lm = c.lmax[p / c.y_rep];
@@ -226,7 +230,7 @@ struct LmaxTaps { float h[LMAX_KT]; };
 
 template <int SL>
 __global__ __launch_bounds__(256) void lmax_wave_kernel(const float* y, int64_t ldy, int V, int N, LmaxTaps tp, int K, double* out,
-                                                        float ill_bound) {
+                                                        float f64_bound, float vec_bound) {
   extern __shared__ float lm_smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int v = blockIdx.x * 4 + wv;
@@ -234,12 +238,12 @@ __global__ __launch_bounds__(256) void lmax_wave_kernel(const float* y, int64_t 
   float* s = lm_smem + wv * (64 * SL + LMAX_KT);
   const float* yrow = y + (int64_t)v * ldy;
   float loc[SL];
-  float run = 0.0f, ymax = 0.0f;
+  float run = 0.0f, ysq = 0.0f;
 #pragma unroll
   for (int j = SL - 1; j >= 0; --j) {
     const int t = lane * SL + j;
     const float yv = t < N ? yrow[t] : 0.0f;
-    ymax = fmaxf(ymax, fabsf(yv));
+    ysq = fmaf(yv, yv, ysq);
     run += yv;
     loc[j] = run;                                          // suffix sums inside the strip
   }
@@ -272,9 +276,12 @@ __global__ __launch_bounds__(256) void lmax_wave_kernel(const float* y, int64_t 
 #pragma unroll
   for (int j = 0; j < SL; ++j) m = fmaxf(m, lane * SL + j < N ? fabsf(acc[j]) : 0.0f);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o, 64)); ymax = fmaxf(ymax, __shfl_xor(ymax, o, 64)); }
-  // coherence gamma = lambda_max / (max|y| sum|c|) below the bound (ill_bound = gamma_0 sum|c|): marked by the sign
-  if (lane == 0) out[v] = (m > 0.0f && m < ill_bound * ymax) ? -(double)m : (double)m;
+  for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o, 64)); ysq += __shfl_xor(ysq, o, 64); }
+  // coherence gamma_2 = lambda_max / (||y||_2 sum|c| / sqrt(N)) (the bounds carry gamma sum|c| / sqrt(N)):
+  //   below the float64 bound: marked by the SIGN (path_class: class 2);  below the matrix-pipe bound: stored as 0, so
+  //   that `lbda < ratio * lambda_max` is false and the series takes the float32 vector forms whatever its lambda
+  const float yn = __builtin_sqrtf(ysq);
+  if (lane == 0) out[v] = (m > 0.0f && m < f64_bound * yn) ? -(double)m : ((m < vec_bound * yn) ? 0.0 : (double)m);
 }
 
 }  // namespace pb
