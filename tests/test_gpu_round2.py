@@ -556,8 +556,9 @@ def test_host_pipeline_matches_resident_solve():
         got = out.cuda().double() if out_dtype is not None else out
         err = float((got - ref).abs().max()) / scale
         assert err < (1e-6 if out_dtype != torch.float32 else 2e-6), (out_dtype, chunk, err)
-        if chunk == 16384 and out_dtype != torch.float32:
-            assert torch.equal(got[:32768], ref[:32768])    # same kernel form for those rows
+        # (until round 4 the first 32 768 rows ran the same kernel form either way and compared bitwise; a partitioned call
+        # -- white noise at lambda ~ 0.7: mixed classes, half of the series kept off the matrix pipe by the conditioning
+        # guard -- places a row by its position in the call's lists: chunked and whole calls agree to the forms' accuracy)
     # enqueue-only form is ordered before later work on the current stream
     assert solver.round_size(N, len(hrf)) == 16384
     pipe = solver.HostPipeline(V, N, hrf, lam, step, n_iter, out_dtype=None)

@@ -195,8 +195,12 @@ def test_split_matrix_pipe_form_matches_oracle(solver, n, k):
     if n > 320:
         assert "split over two" in solver.which_kernel(n, k, 6000)
         Yb = torch.from_numpy(np.tile(Yv, (150, 1)).astype(np.float32)).cuda()             # 6 000 series
-        Wl, _, ndl = solver.fista_solve(Yb, hrf, 0.3, 1.0 / lip, 200)
+        # (white noise: since round 5 the conditioning guard keeps about half of such series off the matrix pipe -- "noill"
+        # = the partitioned dispatch without that guard, to see the split form's own bits; the guarded default against the oracle)
+        Wl, _, ndl = solver.fista_solve(Yb, hrf, 0.3, 1.0 / lip, 200, force="noill")
         assert int(ndl.min()) == 200 and torch.equal(Wl[:40], Wc) and torch.equal(Wl[-40:], Wc)
+        Wg, _, ndg = solver.fista_solve(Yb, hrf, 0.3, 1.0 / lip, 200)
+        assert int(ndg.min()) == 200 and rel_rows(Wg[:40].cpu().numpy(), Woc).max() < 3e-6 and torch.equal(Wg[:40], Wg[-40:])
 
 
 def test_split_matrix_pipe_form_guards_and_shared_hrf(solver, golden):
@@ -394,5 +398,7 @@ def test_split_form_cost_trace_and_window_rule(solver, n, k):
     if n > 320:                                     # the library's own dispatch for the reference-default call on long series
         assert "split over two" in solver.which_kernel(n, k, 6000, want_J=True, stop="window")
         Yb = torch.from_numpy(np.tile(Yv, (250, 1)).astype(np.float32)).cuda()
-        Wl, Jl, ndl = solver.fista_solve(Yb, hrf, 0.7, 1.0 / lip, 200, want_J=True, stop="window", tol=1e-6, wind=6)
-        assert int(ndl.min()) == 200 and torch.equal(Wl[:24], W) and torch.equal(Wl[-24:], W)
+        Wl, Jl, ndl = solver.fista_solve(Yb, hrf, 0.7, 1.0 / lip, 200, want_J=True, stop="window", tol=1e-6, wind=6, force="noill")
+        assert int(ndl.min()) == 200 and torch.equal(Wl[:24], W) and torch.equal(Wl[-24:], W)      # (see above: white noise)
+        Wg, Jg, ndg = solver.fista_solve(Yb, hrf, 0.7, 1.0 / lip, 200, want_J=True, stop="window", tol=1e-6, wind=6)
+        assert int(ndg.min()) == 200 and rel_rows(Wg[:24].cpu().numpy(), Wo).max() < 3e-6
