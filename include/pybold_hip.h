@@ -211,9 +211,18 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep,
  * or certificate still hands back (n_done = -1) is compacted the same way and re-solved by the exact vector forms at
  * full occupancy.  Results, n_done and J are those of pb_fista_solve; the call allocates nothing.
  *
+ * CONDITIONING GUARD.  The same pass sees ||y_v||_2, and the call classes every series on its coherence
+ *     gamma_2 = lmax_v / (||y_v||_2 sum|c| / sqrt(N)),   c = cumsum(taps)        (block signals at SNR 1 dB: 0.16 .. 0.5)
+ * -- a series most of whose energy the operator does not see (alternating signs, fast sinusoids, a signal under a strong fast
+ * carrier) loses digits in every arithmetic narrower than float64: gamma_2 < 1e-2 -> the float64 LDS kernel (needs taps_dev),
+ * gamma_2 < 7e-2 -> the float32 vector forms whatever lambda, never (b).  5 120 such series per length through this entry point:
+ * worst 2.9e-6 / 3.7e-6 on diff_z, z, x; without the guard 4e-4 on (b) and 5e-3 on (a) (profiles/r5_gamma_calibration_*.txt).
+ * PB_FLAG_NO_ILL_GUARD switches it off.  Calls that are not partitioned are not guarded.
+ *
  * work_dev    int32 scratch of at least pb_fista_work_len(P, y_rep) entries, 8-byte aligned (contents meaningless
  *             afterwards); NULL or too small: no partition (the plan of pb_fista_solve with PB_FLAG_NO_PARTITION).
- * lmax_dev    float64 [ceil(P / y_rep)] or NULL.       dense_ratio <= 0: PB_PATH_DENSE_RATIO(_LONG).
+ * lmax_dev    ignored since the conditioning guard (the call makes its own lambda_max, which also carries the guard's marks);
+ *             kept in the signature.       dense_ratio <= 0: PB_PATH_DENSE_RATIO(_LONG).
  * pb_fista_solve itself partitions too, on a workspace of the library's own (one per device and stream, grown on
  * demand with hipMalloc -- the one allocation this library makes; never under stream capture, where it runs unpartitioned).
  * Calls of fewer than 4 096 problems, shapes outside form (b), PB_FLAG_FORCE_* / _ONE_LAUNCH / _NO_PARTITION: the
