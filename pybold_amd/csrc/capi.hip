@@ -711,6 +711,11 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
                        !(flags & (PB_FLAG_FORCE_GENERIC | PB_FLAG_FORCE_PAIR | PB_FLAG_FORCE_WIDE | PB_FLAG_NO_PAIR | PB_FLAG_DIRECT_FIR | PB_FLAG_NO_MFMA |
                                   PB_FLAG_ONE_LAUNCH | PB_FLAG_FORCE_MFMA2 | PB_FLAG_CERT_NO_RESOLVE | PB_FLAG_NO_PARTITION)) &&
                        !((flags & PB_FLAG_FORCE_MFMA) && !lmax_dev);      // ("everything on the matrix pipe", as before)
+  // (the ill-conditioned class: register-resident float64 kernel where the shape has an entry; its window rule is wind = 6)
+  auto ill_exact = [&]() -> const ExactEntry* {
+    const ExactEntry* e = pick_exact(N, K);
+    return (e && stop_mode == PB_STOP_WINDOW && wind != 6) ? nullptr : e;
+  };
   auto run_partition = [&](const pb::PlanSpec& dense, const pb::PlanSpec& sparse, const pb::PlanSpec& flagged,
                            auto&& launch_form, auto&& has_form, auto&& bound) -> int {
     const WorkLayout wl = work_layout(P, V_series);
@@ -723,11 +728,11 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
       double run = 0.0, csum = 0.0;                   // sum|c| over the N lags of the operator's step response c = cumsum(h)
       for (int k = 0; k < pb::LMAX_KT; ++k) lt.h[k] = k < K ? (float)taps_host[k] : 0.0f;
       for (int t = 0; t < N; ++t) { if (t < K) run += taps_host[t]; csum += std::fabs(run); }
-      // (the float64 LDS kernel takes the marked series: it needs the taps in device memory and the row in LDS)
+      // (the marked series: float64 register-resident kernel, or the LDS one, which needs the taps in device memory and the row in LDS)
       const int64_t nd_g = 3 * (int64_t)N + K + 2 * pb::GEN_WAVES + (stop_mode == PB_STOP_WINDOW ? (int64_t)wind * N : 0);
       const bool guard = !(flags & PB_FLAG_NO_ILL_GUARD);
       const double unit = csum / std::sqrt((double)N);
-      const float f64_bound = (guard && taps_dev && nd_g <= LDS_DOUBLES_MAX) ? (float)(PART_GAMMA_F64 * unit) : 0.0f;
+      const float f64_bound = (guard && (ill_exact() || (taps_dev && nd_g <= LDS_DOUBLES_MAX))) ? (float)(PART_GAMMA_F64 * unit) : 0.0f;
       const float vec_bound = guard ? (float)(PART_GAMMA_MATRIX_PIPE * unit) : 0.0f;
       const dim3 grid((unsigned)((V_series + 3) / 4)), block(256);
       if (N <= 320) hipLaunchKernelGGL((pb::lmax_wave_kernel<5>), grid, block, 4 * (64 * 5 + pb::LMAX_KT) * sizeof(float), user, y_dev, ldy, V_series, N, lt, K, lm, f64_bound, vec_bound);
@@ -791,13 +796,21 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
     if (rc != PB_OK || only_dense || only_sparse) return rc;
     // the ill-conditioned series (marked by the lambda_max pass, the tail of the list array): float64 LDS kernel, any stop
     // rule; its workgroups stride over the list, which is empty for ordinary data
-    if (taps_dev) {
+    {
       pb::FistaArgs b = a;
       b.perm = work_dev;
       b.perm_side = 1;
       b.range = rg_ill;
       const int64_t nd_g = 3 * (int64_t)N + K + 2 * pb::GEN_WAVES + (stop_mode == PB_STOP_WINDOW ? (int64_t)wind * N : 0);
-      if (nd_g <= LDS_DOUBLES_MAX) {
+      // (the register-resident float64 kernel where the shape has an entry: 1.0e9 voxel-iterations/s against 0.17e9)
+      const ExactEntry* ee = ill_exact();
+      if (ee) {
+        b.grid_slots = P;
+        if (ee->fn(b, taps_host, K, J_dev != nullptr, stop_mode, user) != 0)
+          return fail(PB_ERR_INVALID, "pb_fista_solve: float64 kernel rejected the launch (ill-conditioned series)");
+        rc = check_launch("fista_exact_kernel(ill-conditioned series)");
+        if (rc != PB_OK) return rc;
+      } else if (taps_dev && nd_g <= LDS_DOUBLES_MAX) {
         const int wgs = P < 2048 ? P : 2048;
         if (J_dev) hipLaunchKernelGGL((pb::fista_generic_kernel<true>), dim3(wgs), dim3(pb::GEN_THREADS), (size_t)nd_g * sizeof(double), user, b, taps_dev, K, wind);
         else hipLaunchKernelGGL((pb::fista_generic_kernel<false>), dim3(wgs), dim3(pb::GEN_THREADS), (size_t)nd_g * sizeof(double), user, b, taps_dev, K, wind);

@@ -91,19 +91,25 @@ __global__ __launch_bounds__(256) void fista_exact_kernel(FistaArgs a, TapsD<KT>
   static_assert(D <= 63, "halo spans more than the wave");
 
   const int lane = threadIdx.x & 63;
-  const int prob = (int)((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) + a.p0;
-  const bool live = prob < a.P;
-  const int p = live ? prob : a.P - 1;
+  // slots of this launch's list (fista_fast.h: launch_slots; the batch itself without a device-side list).  Round 5: the
+  // ill-conditioned series of a partitioned float32 call run here (y float32 in HBM, a.y64 == nullptr; cost trace to a.J)
+  int s0, s1;
+  launch_slots(a, s0, s1);
+  const int slot = (int)((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) + s0;
+  if (slot >= s1 && a.range) return;               // (one problem per wave: uniform; an empty candidate launch leaves here)
+  bool live;
+  const int p = slot_to_problem(a, slot, s1, live);
   const int base = lane * S;
 
   double y[S], w[S], mk[S];
   {
-    const double* yrow = a.y64 + (int64_t)(p / a.y_rep) * a.ldy;
+    const double* yrow = a.y64 ? a.y64 + (int64_t)(p / a.y_rep) * a.ldy : nullptr;
+    const float* yrow32 = a.y64 ? nullptr : a.y + (int64_t)(p / a.y_rep) * a.ldy;
     const double* wrow = a.w + (int64_t)p * a.ldw;
 #pragma unroll
     for (int j = 0; j < S; ++j) {
       const bool ok = base + j < a.N;
-      y[j] = ok ? yrow[base + j] : 0.0;
+      y[j] = ok ? (yrow ? yrow[base + j] : (double)yrow32[base + j]) : 0.0;
       w[j] = (ok && !a.cold) ? wrow[base + j] : 0.0;
       mk[j] = ok ? 1.0 : 0.0;
     }
@@ -120,7 +126,8 @@ __global__ __launch_bounds__(256) void fista_exact_kernel(FistaArgs a, TapsD<KT>
   }
   bool active = live;
   int done = 0;
-  double* Jrow = WITH_J ? a.J64 + (int64_t)p * a.ldj : nullptr;
+  double* Jrow = (WITH_J && a.J64) ? a.J64 + (int64_t)p * a.ldj : nullptr;
+  float* Jrow32 = (WITH_J && !a.J64 && a.J) ? a.J + (int64_t)p * a.ldj : nullptr;
 
   int n_stop = a.n_iter;
   for (int it = 0;; ++it) {
@@ -176,7 +183,10 @@ __global__ __launch_bounds__(256) void fista_exact_kernel(FistaArgs a, TapsD<KT>
           l1 += fabs(w[j]);
         }
         const double cost = seg_allsum_f64<64>(fma(0.5, sq, lb * l1));
-        if (live && lane == 0 && (STOP == 0 || it <= done)) Jrow[it - 1] = cost;
+        if (live && lane == 0 && (STOP == 0 || it <= done)) {
+          if (Jrow) Jrow[it - 1] = cost;
+          else if (Jrow32) Jrow32[it - 1] = (float)cost;
+        }
       }
       if (it >= n_stop) break;
     }
@@ -282,7 +292,7 @@ __global__ __launch_bounds__(256) void fista_exact_kernel(FistaArgs a, TapsD<KT>
 template <int S, int KT>
 int launch_exact(const FistaArgs& a, const double* taps, int K, bool with_j, int stop, hipStream_t st) {
   const auto td = make_taps_d<KT>(taps, K);
-  const dim3 grid((unsigned)(((int64_t)(a.P - a.p0) + 3) / 4)), block(256);
+  const dim3 grid((unsigned)((launch_count(a) + 3) / 4)), block(256);
   if (stop == PB_STOP_NONE) {
     if (with_j) hipLaunchKernelGGL((fista_exact_kernel<S, KT, true, 0>), grid, block, 0, st, a, td);
     else hipLaunchKernelGGL((fista_exact_kernel<S, KT, false, 0>), grid, block, 0, st, a, td);

@@ -376,7 +376,8 @@ def test_ill_conditioned_series_are_solved_in_float64(solver, golden):
     such a series plus 1e-3 .. 1e-2 of an ordinary one: coherence lambda_max / (max|y| sum|c|) of 1e-3 .. 4e-3 against
     3e-2 .. 1 for ordinary data -- lose digits in every arithmetic narrower than float64: up to 5e-5 on the matrix pipe
     and 3e-5 on the float32 vector forms (tools/r5_conditioning_probe.py, profiles/r5_conditioning_probe.txt: eps is
-    1e-5).  A partitioned call marks them in its lambda_max pass and solves them on the float64 LDS kernel: through the
+    1e-5).  A partitioned call marks them in its lambda_max pass and solves them in float64 (the register-resident
+    kernel of fista_exact.h on their list; the LDS kernel for a window other than 6): through the
     DEFAULT dispatch every family is within eps on diff_z, z AND x, at lambda = 0, 0.05 lambda_max and 1, with the cost
     trace and the window rule too; ordinary series next to them keep their kernels (timing: a handful of rows)."""
     g = golden("case1")
@@ -399,7 +400,7 @@ def test_ill_conditioned_series_are_solved_in_float64(solver, golden):
         lam_o = lam[:len(fams)].cpu().numpy() if torch.is_tensor(lam) else lam
         ref = orc.fista_batch(Yo, hrf, lam_o, step, 500)
         xr, zr = orc.fista_outputs(ref, hrf)
-        for kw in (dict(), dict(want_J=True, stop="window", tol=1e-7, wind=6)):
+        for kw in (dict(), dict(want_J=True, stop="window", tol=1e-7, wind=6), dict(want_J=True, stop="window", tol=1e-7, wind=4)):
             for force in (None, "noill"):
                 W, J, nd = solver.fista_solve(Yd, hrf, lam, step, 500, force=force, **kw)
                 assert int(nd.min()) == 500
