@@ -19,6 +19,7 @@
 #include "blind.h"
 #include "fista_mfma.h"
 #include "fista_mfma2.h"
+#include "fista_mfma4.h"
 #include "path.h"
 
 namespace {
@@ -87,6 +88,9 @@ namespace pb {
 PB_MFMA2(2, 3) PB_MFMA2(3, 3) PB_MFMA2(3, 4) PB_MFMA2(4, 4) PB_MFMA2(4, 5) PB_MFMA2(5, 5) PB_MFMA2(5, 6) PB_MFMA2(6, 6)
 PB_MFMA2(6, 7) PB_MFMA2(7, 7) PB_MFMA2(7, 8) PB_MFMA2(8, 8) PB_MFMA2(8, 9) PB_MFMA2(9, 9) PB_MFMA2(9, 10) PB_MFMA2(10, 10)
 #undef PB_MFMA2
+#define PB_MFMA4(A) extern template int launch_mfma4<A>(const FistaArgs&, const double*, int, bool, hipStream_t);
+PB_MFMA4(6) PB_MFMA4(7) PB_MFMA4(8) PB_MFMA4(9) PB_MFMA4(10)
+#undef PB_MFMA4
 }
 namespace {
 // the matrix-pipe form with one series split over the two waves of a workgroup (fista_mfma2.h): nb = ceil(N / 32)
@@ -104,6 +108,14 @@ mfma2_launch_fn pick_mfma2(int N, int K) {
   const int nb = (N + 31) / 32;
   if (K < 1 || K > 33 || nb < 5 || nb > 20) return nullptr;
   return tab[nb - 5];
+}
+// the same with one series split over the FOUR waves of a workgroup (fista_mfma4.h): 641 .. 1 280 scans, A = ceil(N / 128)
+// blocks per wave (6 .. 10); K <= 33; the call shapes of the two-wave form
+mfma2_launch_fn pick_mfma4(int N, int K) {
+  static const mfma2_launch_fn tab[] = {&pb::launch_mfma4<6>, &pb::launch_mfma4<7>, &pb::launch_mfma4<8>, &pb::launch_mfma4<9>,
+                                        &pb::launch_mfma4<10>};
+  if (K < 1 || K > 33 || N <= 640 || N > 1280) return nullptr;
+  return tab[(N + 127) / 128 - 6];
 }
 typedef int (*mfma_launch_fn)(const pb::FistaArgs&, const double*, int, bool, hipStream_t);
 // the matrix-pipe form (fista_mfma.h): NB = ceil(N / 31) blocks of 31 samples + one sum slot, 129 <= N <= 310; K <= 33
@@ -338,6 +350,16 @@ int mfma2_long_base(int P, bool one_launch) {
   const int base = (P / pass) * pass;
   return (one_launch || P - base > pass * 5 / 16) ? P : base;
 }
+// Series of 641 .. 1 280 scans on the four-wave form: a pass is 16 problems per compute unit (4 096 on 256 of them) whatever
+// the batch; whole passes, a remainder above MFMA4_MIN_R of a pass too, a smaller one -- and batches below it -- on the
+// one-problem-per-wave form
+constexpr int MFMA4_MIN_R_NUM = 5, MFMA4_MIN_R_DEN = 8;    // (N = 1 200: 2 048 problems 1.89 ms against 2.31, 3 072 2.59 against 2.30 -- profiles/r5_long_series_1200_scans.txt)
+bool mfma4_serves(int N, int K) { return pick_mfma4(N, K) != nullptr && pick_wide(N, K) != nullptr; }
+int mfma4_base(int P, bool one_launch) {
+  const int pass = (int)wave_slots() * 2;            // 16 problems x (slots / 2 per SIMD / 4 SIMDs per workgroup)
+  const int base = (P / pass) * pass;
+  return (one_launch || (int64_t)(P - base) * MFMA4_MIN_R_DEN > (int64_t)pass * MFMA4_MIN_R_NUM) ? P : base;
+}
 int plan_pieces_mfma(int P, bool has_pair, bool has_wide, bool one_launch, bool one_stream, bool has_mfma2, int beside_chunks, Piece* out) {
   return pb::plan_pieces_mfma(P, has_pair, has_wide, one_launch, one_stream, has_mfma2, beside_chunks, wave_slots(), out);
 }
@@ -555,6 +577,9 @@ int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mod
   if (N < 1 || K < 1 || P < 1) return 0;
   const bool mfma_plain = stop_mode == PB_STOP_NONE && mfma_serves_plain(N, K);
   const bool mfma2_ok = (stop_mode == PB_STOP_NONE || (stop_mode == PB_STOP_WINDOW && wind == 6)) && pick_mfma2(N, K) != nullptr;
+  if ((stop_mode == PB_STOP_NONE || (stop_mode == PB_STOP_WINDOW && wind == 6)) && mfma4_serves(N, K) &&
+      (stop_mode == PB_STOP_NONE || pick_wide(N, K)->S <= 20))
+    return mfma4_base(P, false) > 0 ? pb::FORM_MFMA4 : FORM_WIDE;
   if (mfma2_ok && mfma2_serves_long(N, K) && P >= MFMA2_LONG_MIN_P && (stop_mode == PB_STOP_NONE || pick_wide(N, K)->S <= 20))
     return mfma2_long_base(P, false) > 0 ? FORM_MFMA2 : ((pick_fast(N, K) && N <= 320) ? FORM_FAST1 : FORM_WIDE);   // (the solve's own backup form)
   if (const FastEntry* se = pick_split(N, K))
@@ -592,7 +617,12 @@ int pb_fista_plan_ex(int N, int K, int P, int stop_mode, int wind, unsigned flag
   const bool mfma_plain = N >= 1 && K >= 1 && stop_mode == PB_STOP_NONE && !no_mfma && mfma_serves_plain(N, K);
   const bool mfma2_ok = N >= 1 && K >= 1 && (stop_mode == PB_STOP_NONE || (stop_mode == PB_STOP_WINDOW && wind == 6)) && !no_mfma &&
                         pick_mfma2(N, K) != nullptr;
-  if (mfma2_ok && mfma2_serves_long(N, K) && (P >= MFMA2_LONG_MIN_P || (flags & PB_FLAG_FORCE_MFMA2)) &&
+  if (N >= 1 && K >= 1 && P >= 1 && (stop_mode == PB_STOP_NONE || (stop_mode == PB_STOP_WINDOW && wind == 6)) && !no_mfma &&
+      mfma4_serves(N, K) && (stop_mode == PB_STOP_NONE || pick_wide(N, K)->S <= 20)) {
+    const int base = mfma4_base(P, (flags & (PB_FLAG_ONE_LAUNCH | PB_FLAG_FORCE_MFMA2)) != 0);
+    if (base > 0 && base < P) { nm = base; mf = pb::FORM_MFMA4; tf = FORM_WIDE; }
+    else tf = base > 0 ? pb::FORM_MFMA4 : FORM_WIDE;
+  } else if (mfma2_ok && mfma2_serves_long(N, K) && (P >= MFMA2_LONG_MIN_P || (flags & PB_FLAG_FORCE_MFMA2)) &&
       (stop_mode == PB_STOP_NONE || pick_wide(N, K)->S <= 20)) {
     const int base = mfma2_long_base(P, (flags & (PB_FLAG_ONE_LAUNCH | PB_FLAG_FORCE_MFMA2)) != 0);
     const int backup_form = (pick_fast(N, K) && N <= 320) ? FORM_FAST1 : FORM_WIDE;      // what pb_fista_solve uses behind the split form
@@ -885,6 +915,41 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
           },
           [&](int c) -> int { return (c == pb::CAND_MFMA2 || c == pb::CAND_PAIR0 || c == pb::CAND_FAST0 || c == pb::CAND_WIDE) ? P : 0; });
       }
+    }
+  }
+  // 641 .. 1 280 scans: the same call shapes on the form split over four waves (fista_mfma4.h)
+  const mfma2_launch_fn mfma4 =
+      ((stop_mode == PB_STOP_NONE || mfma2_cert) && n_done_dev && (!lbda_dev || (flags & (PB_FLAG_FORCE_MFMA | PB_FLAG_FORCE_MFMA2))) &&
+       !(flags & (PB_FLAG_FORCE_GENERIC | PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_FORCE_WIDE | PB_FLAG_DIRECT_FIR |
+                  PB_FLAG_NO_MFMA)) && mfma4_serves(N, K)) ? pick_mfma4(N, K) : nullptr;
+  if (mfma4) {
+    const WideEntry* we1 = pick_wide(N, K);
+    if (stop_mode == PB_STOP_NONE || we1->S <= 20) {       // (the window rule's re-solve needs the rule's increment ring)
+      auto backup = [&](const pb::FistaArgs& b) -> int { return we1->fn(b, taps_host, K, J_dev != nullptr, stop_mode, (hipStream_t)stream); };
+      const int base = (flags & PB_FLAG_FORCE_MFMA2) ? P : mfma4_base(P, (flags & PB_FLAG_ONE_LAUNCH) != 0);
+      pb::FistaArgs b = a;
+      if (base > 0) {
+        b.P = base;
+        if (mfma4(b, taps_host, K, J_dev != nullptr, (hipStream_t)stream) != 0)
+          return fail(PB_ERR_INVALID, "pb_fista_solve: four-wave matrix-pipe kernel rejected the launch");
+        const int rc = check_launch("fista_mfma4_kernel");
+        if (rc != PB_OK) return rc;
+      }
+      if (base < P) {
+        b = a;
+        b.p0 = base;
+        if (backup(b) != 0) return fail(PB_ERR_INVALID, "pb_fista_solve: no vector form for the remainder");
+        const int rc = check_launch("fista_fast_kernel(wide, remainder)");
+        if (rc != PB_OK) return rc;
+      }
+      if (base > 0 && !(flags & PB_FLAG_CERT_NO_RESOLVE)) {
+        b = a;
+        b.P = base;
+        b.only_flagged = 1;
+        if (backup(b) != 0) return fail(PB_ERR_INVALID, "pb_fista_solve: no vector form for the re-solve");
+        return check_launch("fista_fast_kernel(wide, re-solve)");
+      }
+      return PB_OK;
     }
   }
   if (mfma2 && ((flags & PB_FLAG_FORCE_MFMA2) || (mfma2_serves_long(N, K) && P >= MFMA2_LONG_MIN_P))) {

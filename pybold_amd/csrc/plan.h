@@ -16,7 +16,7 @@ namespace pb {
 
 #define PB_HD __host__ __device__ inline
 
-enum Form { FORM_GENERIC = 0, FORM_FAST1 = 1, FORM_PAIR = 2, FORM_WIDE = 3, FORM_MFMA = 4, FORM_MFMA2 = 5 };
+enum Form { FORM_GENERIC = 0, FORM_FAST1 = 1, FORM_PAIR = 2, FORM_WIDE = 3, FORM_MFMA = 4, FORM_MFMA2 = 5, FORM_MFMA4 = 6 };
 
 // ---- dispatch of a plain solve (no stop rule) over the register-resident vector forms --------
 // All forms keep two waves per SIMD and are VALU-issue bound, so a launch costs "rounds":

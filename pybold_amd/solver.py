@@ -196,7 +196,9 @@ KERNEL_NAMES = {0: "fista_generic_kernel (LDS)", 1: "fista_fast_kernel (register
                 3: "fista_fast_kernel (register-resident, one problem per wave)",
                 4: "fista_mfma_kernel (register-resident, 16 problems per wave, both operators on the matrix pipe)",
                 5: "fista_mfma2_kernel (register-resident, 16 problems per two waves -- every series split over two "
-                   "SIMDs --, both operators on the matrix pipe)"}
+                   "SIMDs --, both operators on the matrix pipe)",
+                6: "fista_mfma4_kernel (register-resident, 16 problems per workgroup of four waves -- every series split over "
+                   "the four SIMDs of a compute unit --, both operators on the matrix pipe)"}
 
 
 def which_kernel(n_scans, n_taps, n_problems, want_J=False, stop=None, wind=6):

@@ -415,3 +415,47 @@ def test_ill_conditioned_series_are_solved_in_float64(solver, golden):
                     worst_unguarded = max(worst_unguarded, e)
     print("ill-conditioned families through the default dispatch: worst %.1e (guard off: %.1e)" % (worst_default, worst_unguarded))
     assert worst_unguarded > 1e-5                       # (the guard is what holds eps here)
+
+
+# --------------------------------------------------------------------------------------------
+# Round 5: series of 641 .. 1 280 scans on the matrix pipe (fista_mfma4.h: one series over the four waves of a workgroup)
+@pytest.mark.parametrize("n,k", [(641, 30), (700, 27), (768, 33), (769, 16), (900, 30), (1000, 2), (1024, 30), (1025, 30),
+                                 (1200, 28), (1216, 33), (1217, 30), (1279, 30), (1280, 32)])
+def test_four_wave_matrix_pipe_form_matches_oracle(solver, n, k):
+    """`fista_mfma4_kernel`: 16 problems per workgroup of four waves, wave j owning blocks j A .. j A + A - 1 of 32 samples
+    (A = ceil(N / 128): 6 .. 10; the last wave holds the end of the series and the padding behind it) -- HCP-length
+    runs (examples/icassp_2019/validation.py:41-48).  Warm and cold start against the C float64 oracle, nothing handed
+    back on ordinary data, any batch position the same bits; the cost trace; the window rule as a certificate."""
+    from oracle import c_oracle
+    rng = np.random.RandomState(n + k)
+    hrf = orc.spm_hrf(1.0, 1.0, float(k), False)[0][:k] if k >= 20 else (np.hanning(k + 2)[1:-1] * 0.3 if k > 2 else np.array([0.0, 0.7])[:k])
+    assert len(hrf) == k
+    lip = orc.gram_lipschitz(hrf, n)
+    Yv = rng.randn(40, n)
+    W0 = 0.01 * rng.randn(40, n)
+    Yh = Yv.astype(np.float32).astype(np.float64)
+    Yd, W0d = torch.from_numpy(Yv.astype(np.float32)).cuda(), torch.from_numpy(W0).cuda()
+    Wo, _, _ = c_oracle.fista_batch(Yh, hrf, 0.3, 1.0 / lip, 200, W0=W0, threads=4)
+    W, _, nd = solver.fista_solve(Yd, hrf, 0.3, 1.0 / lip, 200, W0=W0d, force="mfma2only")
+    assert int(nd.min()) == 200 and int(nd.max()) == 200            # nothing handed back
+    assert rel_rows(W.cpu().numpy(), Wo).max() < 3e-6
+    Wc, Jc, ndc = solver.fista_solve(Yd, hrf, 0.3, 1.0 / lip, 200, force="mfma2only", want_J=True)     # cold start, cost trace
+    Woc, Joc, _ = c_oracle.fista_batch(Yh, hrf, 0.3, 1.0 / lip, 200, threads=4, want_J=True)
+    assert int(ndc.min()) == 200 and rel_rows(Wc.cpu().numpy(), Woc).max() < 3e-6
+    assert np.abs(Jc.cpu().numpy() / Joc - 1.0).max() < 2e-5            # (float32 cost trace, as on the other matrix-pipe forms)
+    Wp, _, _ = solver.fista_solve(Yd, hrf, 0.3, 1.0 / lip, 200, force="mfma2only")
+    assert torch.equal(Wp, Wc)                                       # (the rotated loop of the cost trace: the same iterate)
+    # another batch position, another workgroup: the same bits
+    perm = torch.from_numpy(np.r_[np.arange(23, 40), np.arange(23)]).cuda()
+    W2, _, _ = solver.fista_solve(Yd[perm].contiguous(), hrf, 0.3, 1.0 / lip, 200, W0=W0d[perm].contiguous(), force="mfma2only")
+    assert torch.equal(W2, W[perm])
+    # the window rule (far from firing) as a certificate: cleared everywhere; a tolerance it fires at: handed back, re-solved
+    if n <= 1216:
+        Wk, Jk, ndk = solver.fista_solve(Yd, hrf, 0.3, 1.0 / lip, 200, force="mfma2certonly", want_J=True, stop="window", tol=1e-9, wind=6)
+        assert int(ndk.min()) == 200 and torch.equal(Wk, Wc)
+        # (the exact rule on the one-problem-per-wave form: tests/test_gpu_parity.py pins that one to the reference's stops)
+        Wf, Jf, ndf = solver.fista_solve(Yd, hrf, 0.3, 1.0 / lip, 200, force="mfma2cert", want_J=True, stop="window", tol=2e-2, wind=6)
+        Wv, Jv, ndv = solver.fista_solve(Yd, hrf, 0.3, 1.0 / lip, 200, force="valu", want_J=True, stop="window", tol=2e-2, wind=6)
+        assert torch.equal(ndf, ndv) and int(ndv.min()) < 200 and torch.equal(Wf, Wv)
+    # the library's own dispatch: whole passes of 4 096 problems and remainders above 5/8 of one on this form
+    assert "four waves" in solver.which_kernel(n, k, 4096)
