@@ -353,7 +353,7 @@ int mfma2_long_base(int P, bool one_launch) {
 // Series of 641 .. 1 280 scans on the four-wave form: a pass is 16 problems per compute unit (4 096 on 256 of them) whatever
 // the batch; whole passes, a remainder above MFMA4_MIN_R of a pass too, a smaller one -- and batches below it -- on the
 // one-problem-per-wave form
-constexpr int MFMA4_MIN_R_NUM = 5, MFMA4_MIN_R_DEN = 8;    // (N = 1 200: 2 048 problems 1.89 ms against 2.31, 3 072 2.59 against 2.30 -- profiles/r5_long_series_1200_scans.txt)
+constexpr int MFMA4_MIN_R_NUM = 10, MFMA4_MIN_R_DEN = 16;   // (N = 1 200: 2 048 problems 1.89 ms against 2.31, 3 072 2.59 against 2.30 -- profiles/r5_long_series_1200_scans.txt)
 bool mfma4_serves(int N, int K) { return pick_mfma4(N, K) != nullptr && pick_wide(N, K) != nullptr; }
 int mfma4_base(int P, bool one_launch) {
   const int pass = (int)wave_slots() * 2;            // 16 problems x (slots / 2 per SIMD / 4 SIMDs per workgroup)
@@ -736,7 +736,7 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
   //   measurement aids "matrix-pipe candidates only" / "vector candidates only", 3: handed-back problems);
   //   bound(cand) = grid bound of a candidate in slots
   const int V_series = (P + y_rep - 1) / y_rep;
-  const bool part_ws = work_dev && P >= PART_MIN_P && K <= pb::LMAX_KT && N <= 640 && n_done_dev &&
+  const bool part_ws = work_dev && P >= PART_MIN_P && K <= pb::LMAX_KT && N <= 1280 && n_done_dev &&
                        work_len >= work_layout(P, V_series).total &&
                        !(flags & (PB_FLAG_FORCE_GENERIC | PB_FLAG_FORCE_PAIR | PB_FLAG_FORCE_WIDE | PB_FLAG_NO_PAIR | PB_FLAG_DIRECT_FIR | PB_FLAG_NO_MFMA |
                                   PB_FLAG_ONE_LAUNCH | PB_FLAG_FORCE_MFMA2 | PB_FLAG_CERT_NO_RESOLVE | PB_FLAG_NO_PARTITION)) &&
@@ -766,7 +766,8 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
       const float vec_bound = guard ? (float)(PART_GAMMA_MATRIX_PIPE * unit) : 0.0f;
       const dim3 grid((unsigned)((V_series + 3) / 4)), block(256);
       if (N <= 320) hipLaunchKernelGGL((pb::lmax_wave_kernel<5>), grid, block, 4 * (64 * 5 + pb::LMAX_KT) * sizeof(float), user, y_dev, ldy, V_series, N, lt, K, lm, f64_bound, vec_bound);
-      else hipLaunchKernelGGL((pb::lmax_wave_kernel<10>), grid, block, 4 * (64 * 10 + pb::LMAX_KT) * sizeof(float), user, y_dev, ldy, V_series, N, lt, K, lm, f64_bound, vec_bound);
+      else if (N <= 640) hipLaunchKernelGGL((pb::lmax_wave_kernel<10>), grid, block, 4 * (64 * 10 + pb::LMAX_KT) * sizeof(float), user, y_dev, ldy, V_series, N, lt, K, lm, f64_bound, vec_bound);
+      else hipLaunchKernelGGL((pb::lmax_wave_kernel<21>), grid, block, 4 * (64 * 21 + pb::LMAX_KT) * sizeof(float), user, y_dev, ldy, V_series, N, lt, K, lm, f64_bound, vec_bound);   // (odd strips: conflict-free)
     }
     const double* lmax = lm;
     const int nblk = (P + pb::PATH_PER_BLOCK - 1) / pb::PATH_PER_BLOCK;
@@ -880,8 +881,12 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
   // (round 5) the same call shapes at 311..640 scans, partitioned on the device: dense class on whole passes of the split
   // form, sparse class on the pair form over two slots (or the backup form), handed-back problems compacted
   {
-    const mfma2_launch_fn mfma2_l = (mfma2 || !lbda_dev || !(stop_mode == PB_STOP_NONE || mfma2_cert)) ? mfma2 : pick_mfma2(N, K);
-    if (mfma2_l && part_ws && mfma2_serves_long(N, K) && P >= MFMA2_LONG_MIN_P) {
+    const bool four = N > 640;                       // 641 .. 1 280 scans: the form split over four waves (fista_mfma4.h)
+    const bool shape_ok = (stop_mode == PB_STOP_NONE || mfma2_cert) && n_done_dev &&
+                          !(flags & (PB_FLAG_FORCE_GENERIC | PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_FORCE_WIDE | PB_FLAG_DIRECT_FIR | PB_FLAG_NO_MFMA));
+    const mfma2_launch_fn mfma2_l = four ? ((shape_ok && mfma4_serves(N, K)) ? pick_mfma4(N, K) : nullptr)
+                                         : ((mfma2 || !lbda_dev || !(stop_mode == PB_STOP_NONE || mfma2_cert)) ? mfma2 : pick_mfma2(N, K));
+    if (mfma2_l && part_ws && (four || (mfma2_serves_long(N, K) && P >= MFMA2_LONG_MIN_P))) {
       const FastEntry* fe1 = pick_fast(N, K);
       const WideEntry* we1 = pick_wide(N, K);
       const bool use_wide = we1 && (!fe1 || N > 320);
@@ -893,6 +898,7 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
       if (backup_ok) {
         const double slots = wave_slots();
         pb::PlanSpec dense{3, 0, 0, 0, 1, 1, 0, slots};
+        if (four) { dense.pass_mult = 2; dense.rem_num16 = MFMA4_MIN_R_NUM; }
         pb::PlanSpec sparse{4, split_ok ? 1 : 0, 0, 0, 1, 0, 0, slots};
         pb::PlanSpec flagged{4, 0, 0, 0, 1, 0, 0, slots};
         dense.backup_form = sparse.backup_form = flagged.backup_form = use_wide ? FORM_WIDE : FORM_FAST1;
@@ -1296,7 +1302,7 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, in
   // without the partition.  pb_fista_solve_ex takes the caller's workspace instead and allocates nothing.)
   int32_t* work = nullptr;
   int64_t len = 0;
-  if (P >= PART_MIN_P && N <= 640 && n_done_dev && !(flags & PB_FLAG_NO_PARTITION) && !stream_is_capturing((hipStream_t)stream))
+  if (P >= PART_MIN_P && N <= 1280 && n_done_dev && !(flags & PB_FLAG_NO_PARTITION) && !stream_is_capturing((hipStream_t)stream))
     work = own_workspace(stream, work_layout(P, (P + (y_rep > 0 ? y_rep : 1) - 1) / (y_rep > 0 ? y_rep : 1)).total, &len);
   return solve_impl(y_dev, ldy, y_rep, w_dev, ldw, P, N, taps_host, taps_dev, K, step, lbda, lbda_dev, betas_dev, n_iter,
                     J_dev, ldj, stop_mode, tol, wind, n_done_dev, flags, stream, nullptr, 0.0, work, len);

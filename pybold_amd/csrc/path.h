@@ -87,6 +87,8 @@ struct PlanSpec {          // how a list is to be laid over the forms (the argum
   double slots;
   int backup_form = FORM_WIDE;   // kinds 3, 4: FORM_FAST1 (311..320 scans with a single-row entry) or FORM_WIDE
   int min_pair = 1024;
+  int pass_mult = 4;             // kind 3: a pass of the split form = pass_mult * slots problems (two waves: 4; four waves,
+  int rem_num16 = 5;             // fista_mfma4.h: 2); a remainder above rem_num16 / 16 of a pass runs on it too
   int merged = 0;                // front spec only: 1 = ONE plan for the whole call (plan.h: plan_partitioned / its long-series
                                  // form): the front list's remainder joins the back list, ranges are positions in the list array
 };
@@ -181,9 +183,9 @@ __device__ __forceinline__ void plan_list(const PlanSpec& sp, int n, int32_t* ra
   else if (n > 0 && sp.kind == 2)
     npc = plan_pieces(n, sp.has_pair != 0, sp.has_wide != 0, sp.one_launch != 0, sp.one_stream != 0, sp.slots, pc);
   else if (n > 0 && sp.kind == 3) {
-    const int pass = (int)sp.slots * 4;            // 16 problems x (slots / 2 SIMDs / 2 waves): capi.hip, mfma2_long_base
+    const int pass = (int)sp.slots * sp.pass_mult; // 16 problems x (slots / 2 SIMDs / 2 waves): capi.hip, mfma2_long_base / mfma4_base
     int base = (n / pass) * pass;
-    if (sp.one_launch || n - base > pass * 5 / 16) base = n;
+    if (sp.one_launch || n - base > pass * sp.rem_num16 / 16) base = n;
     if (base > 0) pc[npc++] = Piece{FORM_MFMA2, 0, base, false, false};
     if (base < n) pc[npc++] = Piece{sp.backup_form, base, n, false, false};
   } else if (n > 0 && sp.kind == 4) {
@@ -204,10 +206,10 @@ __device__ __forceinline__ void plan_call(const PlanSpec& front, const PlanSpec&
   if (front.kind == 1) {
     npc = plan_partitioned(n_d, P, front.has_pair != 0, front.has_wide != 0, front.one_stream != 0, front.has_mfma2 != 0,
                            front.beside_chunks, front.slots, pc);
-  } else {                                           // series of 311..640 scans (kinds 3 / 4)
-    const int pass = (int)front.slots * 4;
+  } else {                                           // series of 311..1 280 scans (kinds 3 / 4)
+    const int pass = (int)front.slots * front.pass_mult;
     int base = (n_d / pass) * pass;
-    if (n_d - base > pass * 5 / 16) base = n_d;
+    if (n_d - base > pass * front.rem_num16 / 16) base = n_d;
     if (base > 0) pc[npc++] = Piece{FORM_MFMA2, 0, base, false, false};
     if (base < P) pc[npc++] = Piece{(back.has_pair && P - base >= back.min_pair) ? FORM_PAIR : back.backup_form, base, P, false, false};
   }

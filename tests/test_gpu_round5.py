@@ -459,3 +459,45 @@ def test_four_wave_matrix_pipe_form_matches_oracle(solver, n, k):
         assert torch.equal(ndf, ndv) and int(ndv.min()) < 200 and torch.equal(Wf, Wv)
     # the library's own dispatch: whole passes of 4 096 problems and remainders above 5/8 of one on this form
     assert "four waves" in solver.which_kernel(n, k, 4096)
+
+
+def test_partition_and_guard_for_series_of_1200_scans(solver):
+    """641 .. 1 280 scans through the DEFAULT dispatch (a partitioned call: lambda_max pass with 21-sample strips, dense
+    class on whole passes of the four-wave form, sparse class and remainders on the one-problem-per-wave form, ill-conditioned
+    series in float64): a mixed batch -- per-problem lambda on both sides of the class boundary, an alternating series, an
+    all-zero one -- against the C oracle; with the cost trace and the window rule too."""
+    from oracle import c_oracle
+    from pybold_amd import data
+    n, P = 1200, 4500
+    hrf = orc.spm_hrf(1.0, 1.0, 28.0, False)[0][:28]
+    lip = orc.gram_lipschitz(hrf, n)
+    Y, _, _ = data.gen_rnd_bloc_bold_batch(P, dur=n / 60.0, tr=1.0, hrf=hrf, nb_events=5, avg_dur=12.0, std_dur=1.0, snr=1.0, seed=11)
+    Y = Y[:, :n].contiguous()
+    Y[17] = torch.from_numpy(np.where(np.arange(n) % 2 == 0, 1.0, -1.0)).float().cuda()
+    Y[33] = 0.0
+    lmax = solver.lambda_max(Y, hrf)
+    rng = np.random.RandomState(0)
+    frac = np.where(rng.rand(P) < 0.7, 0.02, 0.5)
+    frac[:64] = np.where(np.arange(64) % 2 == 0, 0.02, 0.5)
+    lam = torch.from_numpy(frac).cuda() * lmax
+    lam[17], lam[33] = 0.1, 1.0
+    idx = np.r_[np.arange(64), rng.choice(np.arange(64, P), 64, replace=False)]
+    Yo = Y[idx].cpu().numpy().astype(np.float64)
+    Wo, Jo, _ = c_oracle.fista_batch(Yo, hrf, lam[idx].cpu().numpy(), 1.0 / lip, 150, threads=8, want_J=True)
+    nz = np.linalg.norm(Wo, axis=1) > 0
+    for kw in (dict(), dict(want_J=True), dict(want_J=True, stop="window", tol=1e-8, wind=6)):
+        W, J, nd = solver.fista_solve(Y, hrf, lam, 1.0 / lip, 150, **kw)
+        # (the all-zero series meets the window rule at once: 0 / (0 + 1e-10) < tol at the first test, bold_signal.py:86-95)
+        expect = torch.full_like(nd, 150)
+        if "stop" in kw:
+            expect[33] = 8
+        bad = torch.nonzero(nd != expect).flatten()
+        assert len(bad) == 0, (kw, bad[:16].tolist(), nd[bad[:16]].tolist(), (lam / lmax)[bad[:16]].tolist())
+        Wn = W[idx].cpu().numpy()
+        assert rel_rows(Wn[nz], Wo[nz]).max() < 1e-5 and np.abs(Wn[~nz]).max() == 0.0, kw
+        if J is not None:
+            assert np.abs(J[idx].cpu().numpy()[nz] / Jo[nz] - 1.0).max() < 5e-5
+    # one scalar lambda: everything dense but the two odd rows
+    W, _, nd = solver.fista_solve(Y, hrf, 0.05, 1.0 / lip, 150)
+    Wo1, _, _ = c_oracle.fista_batch(Yo, hrf, 0.05, 1.0 / lip, 150, threads=8)
+    assert int(nd.min()) == 150 and rel_rows(W[idx].cpu().numpy()[nz], Wo1[nz]).max() < 1e-5

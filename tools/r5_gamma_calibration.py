@@ -38,7 +38,8 @@ def rel(a, b):
 
 fam = np.concatenate([np.full(1024, 0), np.full(512, 1), np.full(512, 2)] + [np.full(512, 3 + i) for i in range(6)])
 fam_names = ["white noise", "diff noise", "diff^2 noise"] + ["carrier period %d + fraction" % p for p in (2, 3, 4, 5, 6, 8)]
-err = {"mfmaonly": np.zeros(len(Y)), "fast1": np.zeros(len(Y)), None: np.zeros(len(Y))}      # (None: the DEFAULT dispatch, guard on)
+MP, VEC = ("mfma2only", "valu") if N > 640 else ("mfmaonly", "fast1")      # (641+ scans: the four-wave form, the one-problem-per-wave form)
+err = {MP: np.zeros(len(Y)), VEC: np.zeros(len(Y)), None: np.zeros(len(Y))}      # (None: the DEFAULT dispatch, guard on)
 err_l = {k: np.zeros((3, len(Y))) for k in err}
 li = -1
 for lam in (0.0, 0.05 * lmax, 1.0):
@@ -62,7 +63,7 @@ edges = [0, 1e-3, 2e-3, 3e-3, 4e-3, 5e-3, 6e-3, 7e-3, 8e-3, 1e-2, 1.5e-2, 2e-2, 
 for lo, hi in zip(edges[:-1], edges[1:]):
     m = (gamma >= lo) & (gamma < hi)
     if m.any():
-        print("[%.0e, %.0e) %16d %12.1e %12.1e %12.1e" % (lo, hi, m.sum(), err["mfmaonly"][m].max(), err["fast1"][m].max(), err[None][m].max()))
+        print("[%.0e, %.0e) %16d %12.1e %12.1e %12.1e" % (lo, hi, m.sum(), err[MP][m].max(), err[VEC][m].max(), err[None][m].max()))
 wn = gamma[:1024]
 print("white noise: gamma min %.2e, 1 %% %.2e, 5 %% %.2e, median %.2e" % (wn.min(), np.quantile(wn, 0.01), np.quantile(wn, 0.05), np.median(wn)))
 
@@ -71,7 +72,7 @@ print("# the same per bin of gamma_2 = lambda_max / (||y||_2 sum|c| / sqrt(N))  
 for lo, hi in zip(edges[:-1], edges[1:]):
     m = (gamma2 >= lo) & (gamma2 < hi)
     if m.any():
-        print("[%.0e, %.0e) %16d %12.1e %12.1e %12.1e   %s" % (lo, hi, m.sum(), err["mfmaonly"][m].max(), err["fast1"][m].max(), err[None][m].max(),
+        print("[%.0e, %.0e) %16d %12.1e %12.1e %12.1e   %s" % (lo, hi, m.sum(), err[MP][m].max(), err[VEC][m].max(), err[None][m].max(),
               " ".join("%s:%d" % (fam_names[f].split()[0][:4] + fam_names[f].split()[-3][-1:] if f >= 3 else fam_names[f][:5], (m & (fam == f)).sum()) for f in range(len(fam_names)) if (m & (fam == f)).any())))
 print("white noise: gamma_2 min %.2e, 1 %% %.2e, median %.2e; block signals at SNR 1 dB: gamma_2 min %.2e median %.2e"
       % (gamma2[:1024].min(), np.quantile(gamma2[:1024], 0.01), np.median(gamma2[:1024]),
@@ -80,14 +81,14 @@ print("white noise: gamma_2 min %.2e, 1 %% %.2e, median %.2e; block signals at S
 print("# DEFAULT dispatch (partitioned call, conditioning guard on): worst error over ALL %d series: %.1e" % (len(Y), err[None].max()))
 print("worst kept problems of the matrix-pipe form with gamma >= 1e-2:")
 m = gamma >= 1e-2
-order = np.argsort(-err["mfmaonly"] * m)[:12]
+order = np.argsort(-err[MP] * m)[:12]
 for i in order:
     print("  %-28s gamma %.2e  errors at lambda 0 / 0.05 lmax / 1: %.1e %.1e %.1e   (vector form %.1e %.1e %.1e)  ||w||/||y|| ~ lmax %.2e"
-          % (fam_names[fam[i]], gamma[i], err_l["mfmaonly"][0][i], err_l["mfmaonly"][1][i], err_l["mfmaonly"][2][i],
-             err_l["fast1"][0][i], err_l["fast1"][1][i], err_l["fast1"][2][i], float(lmax[i])))
+          % (fam_names[fam[i]], gamma[i], err_l[MP][0][i], err_l[MP][1][i], err_l[MP][2][i],
+             err_l[VEC][0][i], err_l[VEC][1][i], err_l[VEC][2][i], float(lmax[i])))
 print("per family, gamma >= 1e-2: worst matrix-pipe error")
 for f, nm in enumerate(fam_names):
     mm = m & (fam == f)
     if mm.any():
-        print("  %-28s %5d series  %.1e  (lambda 0: %.1e, 0.05 lmax: %.1e, 1: %.1e)" % (nm, mm.sum(), err["mfmaonly"][mm].max(),
-              err_l["mfmaonly"][0][mm].max(), err_l["mfmaonly"][1][mm].max(), err_l["mfmaonly"][2][mm].max()))
+        print("  %-28s %5d series  %.1e  (lambda 0: %.1e, 0.05 lmax: %.1e, 1: %.1e)" % (nm, mm.sum(), err[MP][mm].max(),
+              err_l[MP][0][mm].max(), err_l[MP][1][mm].max(), err_l[MP][2][mm].max()))
