@@ -573,14 +573,13 @@ static bool pair_carries(const FastEntry* fe, int stop_mode, int wind) {
 }
 
 int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mode, int wind) {
-  (void)with_cost_trace;
   if (N < 1 || K < 1 || P < 1) return 0;
   const bool mfma_plain = stop_mode == PB_STOP_NONE && mfma_serves_plain(N, K);
+  const bool split_shape = stop_mode == PB_STOP_NONE || (stop_mode == PB_STOP_WINDOW && wind == 6) || (stop_mode == PB_STOP_LOOPS && !with_cost_trace);
   const bool mfma2_ok = (stop_mode == PB_STOP_NONE || (stop_mode == PB_STOP_WINDOW && wind == 6)) && pick_mfma2(N, K) != nullptr;
-  if ((stop_mode == PB_STOP_NONE || (stop_mode == PB_STOP_WINDOW && wind == 6)) && mfma4_serves(N, K) &&
-      (stop_mode == PB_STOP_NONE || pick_wide(N, K)->S <= 20))
+  if (split_shape && mfma4_serves(N, K) && (stop_mode != PB_STOP_WINDOW || pick_wide(N, K)->S <= 20))
     return mfma4_base(P, false) > 0 ? pb::FORM_MFMA4 : FORM_WIDE;
-  if (mfma2_ok && mfma2_serves_long(N, K) && P >= MFMA2_LONG_MIN_P && (stop_mode == PB_STOP_NONE || pick_wide(N, K)->S <= 20))
+  if (split_shape && pick_mfma2(N, K) && mfma2_serves_long(N, K) && P >= MFMA2_LONG_MIN_P && (stop_mode != PB_STOP_WINDOW || pick_wide(N, K)->S <= 20))
     return mfma2_long_base(P, false) > 0 ? FORM_MFMA2 : ((pick_fast(N, K) && N <= 320) ? FORM_FAST1 : FORM_WIDE);   // (the solve's own backup form)
   if (const FastEntry* se = pick_split(N, K))
     if (!mfma_plain && P >= SPLIT_MIN_P && pair_carries(se, stop_mode, wind) && (stop_mode == PB_STOP_NONE || pick_wide(N, K)))
@@ -617,13 +616,14 @@ int pb_fista_plan_ex(int N, int K, int P, int stop_mode, int wind, unsigned flag
   const bool mfma_plain = N >= 1 && K >= 1 && stop_mode == PB_STOP_NONE && !no_mfma && mfma_serves_plain(N, K);
   const bool mfma2_ok = N >= 1 && K >= 1 && (stop_mode == PB_STOP_NONE || (stop_mode == PB_STOP_WINDOW && wind == 6)) && !no_mfma &&
                         pick_mfma2(N, K) != nullptr;
-  if (N >= 1 && K >= 1 && P >= 1 && (stop_mode == PB_STOP_NONE || (stop_mode == PB_STOP_WINDOW && wind == 6)) && !no_mfma &&
-      mfma4_serves(N, K) && (stop_mode == PB_STOP_NONE || pick_wide(N, K)->S <= 20)) {
+  const bool split_shape = stop_mode == PB_STOP_NONE || (stop_mode == PB_STOP_WINDOW && wind == 6) || stop_mode == PB_STOP_LOOPS;
+  if (N >= 1 && K >= 1 && P >= 1 && split_shape && !no_mfma &&
+      mfma4_serves(N, K) && (stop_mode != PB_STOP_WINDOW || pick_wide(N, K)->S <= 20)) {
     const int base = mfma4_base(P, (flags & (PB_FLAG_ONE_LAUNCH | PB_FLAG_FORCE_MFMA2)) != 0);
     if (base > 0 && base < P) { nm = base; mf = pb::FORM_MFMA4; tf = FORM_WIDE; }
     else tf = base > 0 ? pb::FORM_MFMA4 : FORM_WIDE;
-  } else if (mfma2_ok && mfma2_serves_long(N, K) && (P >= MFMA2_LONG_MIN_P || (flags & PB_FLAG_FORCE_MFMA2)) &&
-      (stop_mode == PB_STOP_NONE || pick_wide(N, K)->S <= 20)) {
+  } else if (N >= 1 && K >= 1 && split_shape && !no_mfma && pick_mfma2(N, K) && mfma2_serves_long(N, K) && (P >= MFMA2_LONG_MIN_P || (flags & PB_FLAG_FORCE_MFMA2)) &&
+      (stop_mode != PB_STOP_WINDOW || pick_wide(N, K)->S <= 20)) {
     const int base = mfma2_long_base(P, (flags & (PB_FLAG_ONE_LAUNCH | PB_FLAG_FORCE_MFMA2)) != 0);
     const int backup_form = (pick_fast(N, K) && N <= 320) ? FORM_FAST1 : FORM_WIDE;      // what pb_fista_solve uses behind the split form
     if (base > 0 && base < P) { nm = base; mf = FORM_MFMA2; tf = backup_form; }
@@ -874,23 +874,25 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
   // (the window rule rides it as the no-fire certificate of the one-wave form: wind = 6, far from firing)
   const bool mfma2_cert = stop_mode == PB_STOP_WINDOW && wind == 6 && n_done_dev && !(flags & PB_FLAG_NO_CERT) &&
                           ((flags & PB_FLAG_FORCE_CERT) || tol * (double)n_iter < 0.02);
+  // (the _loops_deconv rule in full inside the kernel, as on the one-wave form: no cost trace)
+  const bool split_loops = stop_mode == PB_STOP_LOOPS && !J_dev;
   const mfma2_launch_fn mfma2 =
-      ((stop_mode == PB_STOP_NONE || mfma2_cert) && n_done_dev && (!lbda_dev || (flags & (PB_FLAG_FORCE_MFMA | PB_FLAG_FORCE_MFMA2))) &&
+      ((stop_mode == PB_STOP_NONE || mfma2_cert || split_loops) && n_done_dev && (!lbda_dev || (flags & (PB_FLAG_FORCE_MFMA | PB_FLAG_FORCE_MFMA2))) &&
        !(flags & (PB_FLAG_FORCE_GENERIC | PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_FORCE_WIDE | PB_FLAG_DIRECT_FIR |
                   PB_FLAG_NO_MFMA))) ? pick_mfma2(N, K) : nullptr;
   // (round 5) the same call shapes at 311..640 scans, partitioned on the device: dense class on whole passes of the split
   // form, sparse class on the pair form over two slots (or the backup form), handed-back problems compacted
   {
     const bool four = N > 640;                       // 641 .. 1 280 scans: the form split over four waves (fista_mfma4.h)
-    const bool shape_ok = (stop_mode == PB_STOP_NONE || mfma2_cert) && n_done_dev &&
+    const bool shape_ok = (stop_mode == PB_STOP_NONE || mfma2_cert || split_loops) && n_done_dev &&
                           !(flags & (PB_FLAG_FORCE_GENERIC | PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_FORCE_WIDE | PB_FLAG_DIRECT_FIR | PB_FLAG_NO_MFMA));
     const mfma2_launch_fn mfma2_l = four ? ((shape_ok && mfma4_serves(N, K)) ? pick_mfma4(N, K) : nullptr)
-                                         : ((mfma2 || !lbda_dev || !(stop_mode == PB_STOP_NONE || mfma2_cert)) ? mfma2 : pick_mfma2(N, K));
+                                         : ((mfma2 || !lbda_dev || !(stop_mode == PB_STOP_NONE || mfma2_cert || split_loops)) ? mfma2 : pick_mfma2(N, K));
     if (mfma2_l && part_ws && (four || (mfma2_serves_long(N, K) && P >= MFMA2_LONG_MIN_P))) {
       const FastEntry* fe1 = pick_fast(N, K);
       const WideEntry* we1 = pick_wide(N, K);
       const bool use_wide = we1 && (!fe1 || N > 320);
-      const bool backup_ok = (fe1 || we1) && (stop_mode == PB_STOP_NONE || (use_wide ? we1->S <= 20 : fe1->S <= 20));
+      const bool backup_ok = (fe1 || we1) && (stop_mode != PB_STOP_WINDOW || (use_wide ? we1->S <= 20 : fe1->S <= 20));
       const FastEntry* se = pick_split(N, K);
       const bool scert_l = se && stop_mode == PB_STOP_WINDOW && wind == 6 && we1 && we1->S <= 20 && !(flags & PB_FLAG_NO_CERT) &&
                            ((flags & PB_FLAG_FORCE_CERT) || tol * (double)n_iter < 0.5);
@@ -925,12 +927,12 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
   }
   // 641 .. 1 280 scans: the same call shapes on the form split over four waves (fista_mfma4.h)
   const mfma2_launch_fn mfma4 =
-      ((stop_mode == PB_STOP_NONE || mfma2_cert) && n_done_dev && (!lbda_dev || (flags & (PB_FLAG_FORCE_MFMA | PB_FLAG_FORCE_MFMA2))) &&
+      ((stop_mode == PB_STOP_NONE || mfma2_cert || split_loops) && n_done_dev && (!lbda_dev || (flags & (PB_FLAG_FORCE_MFMA | PB_FLAG_FORCE_MFMA2))) &&
        !(flags & (PB_FLAG_FORCE_GENERIC | PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_FORCE_WIDE | PB_FLAG_DIRECT_FIR |
                   PB_FLAG_NO_MFMA)) && mfma4_serves(N, K)) ? pick_mfma4(N, K) : nullptr;
   if (mfma4) {
     const WideEntry* we1 = pick_wide(N, K);
-    if (stop_mode == PB_STOP_NONE || we1->S <= 20) {       // (the window rule's re-solve needs the rule's increment ring)
+    if (stop_mode != PB_STOP_WINDOW || we1->S <= 20) {     // (the window rule's re-solve needs the rule's increment ring)
       auto backup = [&](const pb::FistaArgs& b) -> int { return we1->fn(b, taps_host, K, J_dev != nullptr, stop_mode, (hipStream_t)stream); };
       const int base = (flags & PB_FLAG_FORCE_MFMA2) ? P : mfma4_base(P, (flags & PB_FLAG_ONE_LAUNCH) != 0);
       pb::FistaArgs b = a;
@@ -964,7 +966,7 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
     const bool use_wide = we1 && (!fe1 || N > 320);
     // the exact vector form behind it (remainder, re-solve): single row, else one per wave -- with the window rule it
     // must hold the rule's increment ring (strips of at most 20 samples)
-    const bool backup_ok = (fe1 || we1) && (stop_mode == PB_STOP_NONE || (use_wide ? we1->S <= 20 : fe1->S <= 20));
+    const bool backup_ok = (fe1 || we1) && (stop_mode != PB_STOP_WINDOW || (use_wide ? we1->S <= 20 : fe1->S <= 20));
     if (backup_ok) {
       auto backup = [&](const pb::FistaArgs& b) -> int {
         return use_wide ? we1->fn(b, taps_host, K, J_dev != nullptr, stop_mode, (hipStream_t)stream)

@@ -32,16 +32,19 @@ namespace pb {
 // areas (fragment, far fields, scale, guards, cost-trace parts), the taps, the certificate's per-lane state
 constexpr size_t mfma2_lds_bytes(int nbm) {
   return ((size_t)2 * nbm * 2 * 64 + 2 * 64) * sizeof(u4) +
-         (size_t)(2 * 64 + 64 + 64 + 2 * 64 + 4 * 64 + 6 * 64 + 7 * 128) * sizeof(float);
+         (size_t)(2 * 64 + 64 + 64 + 2 * 64 + 4 * 64 + 6 * 64 + 7 * 128) * sizeof(float) + (size_t)2 * 2 * 64 * sizeof(double);
 }
 
 // ROLE 0: the left wave (blocks 0 .. NBA-1), ROLE 1: the right wave (blocks NBA .. NBA+NBB-1; padding in its last block)
 // WITH_J: cost trace (the loop rotated as in fista_mfma.h; each wave adds up its half, the halves meet in LDS at the
 //   barrier that is there anyway).  CERT: the window rule (wind = 6) as the no-fire certificate of fista_mfma.h, four
 //   tracked samples per WAVE (eight per problem); implies WITH_J; a problem that cannot be cleared is handed back.
-template <int NBA, int NBB, bool TAPS_DEV, int ROLE, bool WITH_J = false, bool CERT = false>
+// LOOPS: the _loops_deconv stop rule in full, as on the one-wave form (fista_mfma.h): each wave adds up its half of the two
+//   norms next to the update, the halves meet in LDS at the barrier that ends the iteration; plain variant only.
+template <int NBA, int NBB, bool TAPS_DEV, int ROLE, bool WITH_J = false, bool CERT = false, bool LOOPS = false>
 __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& tp, char* smem) {
   static_assert(!CERT || (WITH_J && !TAPS_DEV), "the certificate runs in the rotated (cost trace) loop");
+  static_assert(!LOOPS || (!WITH_J && !TAPS_DEV && !CERT), "the _loops_deconv rule rides the plain variant");
   static_assert(NBB >= NBA && NBB <= NBA + 1 && NBA >= 2 && NBB <= 10, "right half = the larger one; two blocks at least per wave");
   constexpr int NBM = NBB;                         // blocks of the larger half: the size of a wave's fragment area
   constexpr int NT = 2, LCW = 64;
@@ -69,6 +72,7 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
   float* const xg = fbase + 2 * LCW + 256;                         // [2][2][64] guard, largest |w| of each half
   float* const xj = fbase + 2 * LCW + 512;                         // [2][3][64] cost-trace parts of each half: ||r||^2, ||w||_1, certificate
   float* const lt = fbase + 2 * LCW + 896 + threadIdx.x;           // [7][128] certificate state of every lane (as fista_mfma.h)
+  double* const xl = reinterpret_cast<double*>(fbase + 2 * LCW + 896 + 7 * 128) + lane;     // [2][2][64] _loops_deconv rule: ||d||^2, ||w'||^2 of each half
   if constexpr (CERT) {
 #pragma unroll
     for (int q = 0; q < 7; ++q) lt[q * 128] = 0.0f;
@@ -199,6 +203,8 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
   const double th = lb * step * (double)sigma;
   const double nstep = -step * g_scale;
   float guard = 0.0f, wlast = 0.0f;
+  double ldsq0 = 0.0, ldsq1 = 0.0, lwsq0 = 0.0, lwsq1 = 0.0;     // LOOPS: this lane's parts of ||d||^2 and ||w_{k+1}||^2
+  bool lactive = true;                           // LOOPS: this problem has not met its rule yet
   // cost trace: 0.5 ||r''||^2 / (2^a sigma)^2 + lbda ||w'||_1 / sigma
   const float jq = 0.5f * (inv_sigma / y_scale) * (inv_sigma / y_scale), jl = (float)lb * inv_sigma;
   float jsq = 0.0f, jl1 = 0.0f;
@@ -364,6 +370,10 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
       const double u = fma(nstep, gj, w[q][j]);
       const double d = fmin(fmax(u, -th), th);
       w[q][j] = fma(nb1, d, u);
+      if constexpr (LOOPS) {
+        if constexpr ((j & 1) == 0) { ldsq0 = fma(d, d, ldsq0); lwsq0 = fma(w[q][j], w[q][j], lwsq0); }
+        else { ldsq1 = fma(d, d, ldsq1); lwsq1 = fma(w[q][j], w[q][j], lwsq1); }
+      }
       if constexpr (ROLE == 0 && q <= NBW - 2) {
         if constexpr ((j & 1) == 0) sum0 += w[q][j]; else sum1 += w[q][j];
       }
@@ -451,9 +461,59 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
       const double beta = a.betas[it];
       forward();
       wg_sync();                                   // residual fragments and their far field are out
+      if constexpr (LOOPS) { ldsq0 = ldsq1 = lwsq0 = lwsq1 = 0.0; }
       backward(beta);
+      if constexpr (LOOPS) {                       // this wave's half of the rule's two norms (fista_mfma.h)
+        double num = ldsq0 + ldsq1, den = lwsq0 + lwsq1;
+        num += __shfl_xor(num, 16, 64);
+        den += __shfl_xor(den, 16, 64);
+        num += __shfl_xor(num, 32, 64);
+        den += __shfl_xor(den, 32, 64);
+        xl[(2 * ROLE) * 64] = num;
+        xl[(2 * ROLE + 1) * 64] = den;
+      }
       if (PB_MFMA_CHECKS && (((it & 7) == 7) || (it == a.n_iter - 1) || (it == 0 && !a.cold))) range_check();
       wg_sync();                                   // the updated iterate's fragment and far field are out
+      if constexpr (LOOPS) {
+        // both waves add the halves in the same order: the same verdict in both (the branches below are workgroup-uniform)
+        const double num = xl[0 * 64] + xl[2 * 64], den = xl[1 * 64] + xl[3 * 64];
+        const bool fire = lactive && it >= 3 &&
+                          (1.0 + beta) * sqrt(num) / (sqrt(den) + 1.0e-10 * (double)sigma) < a.tol;
+        if (__builtin_amdgcn_ballot_w64(fire) != 0) {         // (rare: at most once per problem)
+          range_check();                                      // this moment's operands, for the problems that finish now
+          float gq = guard, wq = wlast;
+          gq = fmaxf(gq, __shfl_xor(gq, 16, 64));
+          gq = fmaxf(gq, __shfl_xor(gq, 32, 64));
+          wq = fmaxf(wq, __shfl_xor(wq, 16, 64));
+          wq = fmaxf(wq, __shfl_xor(wq, 32, 64));
+          xg[(ROLE * 2 + 0) * 64 + lane] = gq;
+          xg[(ROLE * 2 + 1) * 64 + lane] = wq;
+          wg_sync();
+          const float go = xg[((1 - ROLE) * 2 + 0) * 64 + lane], wo = xg[((1 - ROLE) * 2 + 1) * 64 + lane];
+          const bool in_range = gq < 60000.0f && go < 60000.0f;
+          const float wm = fmaxf(wq, wo);
+          const bool badq = !in_range || (a.rho_guard && wm > 0.0f && (float)th > MFMA_RHO_MAX * wm) || degenerate;
+          if (fire) {
+            lactive = false;
+            if (live && !badq) {
+              // (addresses made HERE, from laundered values: hoisted out of the loop they cost registers through the whole solve)
+              double* wrow = a.w + (int64_t)p * a.ldw;
+              int tbv = tb;
+              asm volatile("" : "+v"(wrow), "+v"(tbv));
+#pragma unroll
+              for (int q = 0; q < NBW; ++q)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                  const int t = 32 * (QOFF + q) + tbv + j;
+                  if (t < a.N) wrow[t] = w[q][j] * (double)inv_sigma;
+                }
+            }
+            if (ROLE == 0 && live && a.n_done && g == 0) a.n_done[p] = badq ? -1 : it + 1;
+          }
+          if (__builtin_amdgcn_ballot_w64(lactive && live) == 0) return;       // every problem of the workgroup has finished (both waves agree)
+          wg_sync();                                 // (the guard area is read again at the next finish)
+        }
+      }
     }
   } else {
     // rotated: the cost of iterate k+1 comes from the residual of the NEXT forward pass (one pass in front)
@@ -508,7 +568,7 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
     wlast = fmaxf(wlast, wo);
   }
   const bool bad = !(guard < 60000.0f) || degenerate || (a.rho_guard && wlast > 0.0f && (float)th > MFMA_RHO_MAX * wlast) || (CERT && cflag);
-  if (live && !bad) {
+  if (live && !bad && (!LOOPS || lactive)) {
     double* wrow = a.w + (int64_t)p * a.ldw;
 #pragma unroll
     for (int q = 0; q < NBW; ++q)
@@ -518,29 +578,30 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
         if (t < a.N) wrow[t] = w[q][j] * (double)inv_sigma;
       }
   }
-  if (ROLE == 0 && live && a.n_done && g == 0) a.n_done[p] = bad ? -1 : a.n_iter;
+  if (ROLE == 0 && live && a.n_done && g == 0 && (!LOOPS || lactive)) a.n_done[p] = bad ? -1 : a.n_iter;
 }
 
 // one workgroup = two waves = 16 problems; the wave index picks the half (a scalar branch: each wave runs one role)
-template <int NBA, int NBB, bool TAPS_DEV = false, bool WITH_J = false, bool CERT = false>
+template <int NBA, int NBB, bool TAPS_DEV = false, bool WITH_J = false, bool CERT = false, bool LOOPS = false>
 __global__ __launch_bounds__(128) void fista_mfma2_kernel(FistaArgs a, MfmaTaps tp) {
   extern __shared__ __attribute__((aligned(16))) char mf2_smem[];
   if (a.range) {                                   // a candidate launch of a device-side plan: workgroups beyond its slots leave
     if ((int)blockIdx.x * 16 + a.range[0] >= a.range[1]) return;      // (both waves: before any barrier)
   }
-  if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) mfma2_role<NBA, NBB, TAPS_DEV, 0, WITH_J, CERT>(a, tp, mf2_smem);
-  else mfma2_role<NBA, NBB, TAPS_DEV, 1, WITH_J, CERT>(a, tp, mf2_smem);
+  if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) mfma2_role<NBA, NBB, TAPS_DEV, 0, WITH_J, CERT, LOOPS>(a, tp, mf2_smem);
+  else mfma2_role<NBA, NBB, TAPS_DEV, 1, WITH_J, CERT, LOOPS>(a, tp, mf2_smem);
 }
 
-// Plain solves, with or without the cost trace, and the window rule (wind = 6) as a no-fire certificate; HRFs of up to
-// 33 taps, 32 (NBA+NBB-1) < N <= 32 (NBA+NBB).  The shared-HRF z-step (taps in device memory): plain only.
+// Plain solves, with or without the cost trace, the window rule (wind = 6) as a no-fire certificate, the _loops_deconv
+// rule in full (no cost trace); HRFs of up to 33 taps, 32 (NBA+NBB-1) < N <= 32 (NBA+NBB).  The shared-HRF z-step (taps in device memory): plain only.
 template <int NBA, int NBB>
 int launch_mfma2(const FistaArgs& a, const double* taps, int K, bool with_j, hipStream_t st) {
   constexpr int NB = NBA + NBB;
   if (a.N > 32 * NB || a.N <= 32 * (NB - 1) || K < 1 || K > 33) return 1;
-  const bool cert = a.stop_mode == PB_STOP_WINDOW;
-  if ((a.stop_mode != PB_STOP_NONE && !cert) || !a.n_done) return 1;
-  if ((with_j || cert) && a.taps_pp) return 1;
+  const bool cert = a.stop_mode == PB_STOP_WINDOW, loops = a.stop_mode == PB_STOP_LOOPS;
+  if (!a.n_done) return 1;
+  if ((with_j || cert || loops) && a.taps_pp) return 1;
+  if (loops && with_j) return 1;                   // (the _loops_deconv rule: plain variant, as on the one-wave form)
   const int64_t groups = (launch_count(a) + 15) / 16;
   const dim3 grid((unsigned)groups), block(128);
   const size_t lds = mfma2_lds_bytes(NBB);
@@ -550,7 +611,8 @@ int launch_mfma2(const FistaArgs& a, const double* taps, int K, bool with_j, hip
     return 0;
   }
   const MfmaTaps tp = make_mfma_taps(taps, K);
-  if (cert) hipLaunchKernelGGL((fista_mfma2_kernel<NBA, NBB, false, true, true>), grid, block, lds, st, a, tp);
+  if (loops) hipLaunchKernelGGL((fista_mfma2_kernel<NBA, NBB, false, false, false, true>), grid, block, lds, st, a, tp);
+  else if (cert) hipLaunchKernelGGL((fista_mfma2_kernel<NBA, NBB, false, true, true>), grid, block, lds, st, a, tp);
   else if (with_j) hipLaunchKernelGGL((fista_mfma2_kernel<NBA, NBB, false, true, false>), grid, block, lds, st, a, tp);
   else hipLaunchKernelGGL((fista_mfma2_kernel<NBA, NBB, false>), grid, block, lds, st, a, tp);
   return 0;

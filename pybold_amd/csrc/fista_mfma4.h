@@ -26,18 +26,19 @@ constexpr int MFMA4_WAVES = 4;
 // bytes of dynamic LDS of one workgroup (four waves of A blocks): residual fragments, last-block fragments, cumulative
 // taps, the float64 sums of the iterate, residual sums, scale, guards, cost-trace parts, certificate state
 constexpr size_t mfma4_lds_bytes(int A) {
-  return ((size_t)MFMA4_WAVES * A * 2 * 64 + MFMA4_WAVES * 2 * 64) * sizeof(u4) + (size_t)MFMA4_WAVES * 2 * 64 * sizeof(double) +
+  return ((size_t)MFMA4_WAVES * A * 2 * 64 + MFMA4_WAVES * 2 * 64) * sizeof(u4) + (size_t)2 * MFMA4_WAVES * 2 * 64 * sizeof(double) +
          (size_t)MFMA4_WAVES * (64 + 2 * 64 + 64 + 2 * 64 + 3 * 64) * sizeof(float) + (size_t)7 * 256 * sizeof(float);
 }
 
 // One wave's share, KW = wave index.  HAS_L / HAS_R: there is a wave to the left / right; LASTW: the wave holding the end
 // of the series (any of its blocks may be padding).  (Four bodies per kernel: with the index at run time the two middle
 // waves could share one, at the price of a dozen address registers -- and of scratch, at ten blocks per wave.)
-template <int NBW, int KW, bool TAPS_DEV, bool WITH_J = false, bool CERT = false>
+template <int NBW, int KW, bool TAPS_DEV, bool WITH_J = false, bool CERT = false, bool LOOPS = false>
 __device__ __forceinline__ void mfma4_role(const FistaArgs& a, const MfmaTaps& tp, char* smem) {
   constexpr int k = KW;
   constexpr bool HAS_L = KW > 0, HAS_R = KW < MFMA4_WAVES - 1, LASTW = KW == MFMA4_WAVES - 1;
   static_assert(!CERT || (WITH_J && !TAPS_DEV), "the certificate runs in the rotated (cost trace) loop");
+  static_assert(!LOOPS || (!WITH_J && !TAPS_DEV && !CERT), "the _loops_deconv rule rides the plain variant");
   static_assert(NBW >= 2 && NBW <= 10, "two blocks at least per wave, ten at most");
   constexpr int NW = MFMA4_WAVES;
   constexpr int NT = 2, LCW = 64;
@@ -59,7 +60,8 @@ __device__ __forceinline__ void mfma4_role(const FistaArgs& a, const MfmaTaps& t
   u4* const lrf_next = lbase + (k + 1) * (NBW * 2 * 64) + lane;    // the right neighbour's (its block 0)
   u4* const xwb = lbase + NW * (NBW * 2 * 64) + lane;              // [NW][2][64]: fragment (hi, lo) of wave j's last block
   double* const xs = reinterpret_cast<double*>(lbase + NW * (NBW * 2 * 64) + NW * 2 * 64) + lane;   // [NW][2][64]: E_j, T_j
-  float* const fbase = reinterpret_cast<float*>(lbase + NW * (NBW * 2 * 64) + NW * 2 * 64) + NW * 2 * 64 * 2;
+  double* const xl = xs + NW * 2 * 64;                             // [NW][2][64]: _loops_deconv rule, each wave's ||d||^2, ||w'||^2
+  float* const fbase = reinterpret_cast<float*>(lbase + NW * (NBW * 2 * 64) + NW * 2 * 64) + 2 * NW * 2 * 64 * 2;
   float* const lc = fbase + k * LCW;                               // [NW][64] cumulative taps, one copy per wave
   float* const xr = fbase + NW * LCW + lane;                       // [NW][2][64]: S RE_j, S RT_j
   float* const xm = fbase + NW * LCW + NW * 128 + lane;            // [NW][64] max |y| of each share
@@ -193,6 +195,8 @@ __device__ __forceinline__ void mfma4_role(const FistaArgs& a, const MfmaTaps& t
   const double th = lb * step * (double)sigma;
   const double nstep = -step * g_scale;
   float guard = 0.0f, wlast = 0.0f;
+  double ldsq0 = 0.0, ldsq1 = 0.0, lwsq0 = 0.0, lwsq1 = 0.0;     // LOOPS: this lane's parts of ||d||^2 and ||w_{k+1}||^2
+  bool lactive = true;                           // LOOPS: this problem has not met its rule yet
   // cost trace: 0.5 ||r''||^2 / (2^a sigma)^2 + lbda ||w'||_1 / sigma
   const float jq = 0.5f * (inv_sigma / y_scale) * (inv_sigma / y_scale), jl = (float)lb * inv_sigma;
   float jsq = 0.0f, jl1 = 0.0f;
@@ -374,6 +378,10 @@ __device__ __forceinline__ void mfma4_role(const FistaArgs& a, const MfmaTaps& t
       const double u = fma(nstep, gj, w[q][j]);
       const double d = fmin(fmax(u, -th), th);
       w[q][j] = fma(nb1, d, u);
+      if constexpr (LOOPS) {
+        if constexpr ((j & 1) == 0) { ldsq0 = fma(d, d, ldsq0); lwsq0 = fma(w[q][j], w[q][j], lwsq0); }
+        else { ldsq1 = fma(d, d, ldsq1); lwsq1 = fma(w[q][j], w[q][j], lwsq1); }
+      }
       if constexpr (HAS_R) {
         if constexpr (q == NBW - 1) suml += w[q][j];
         else if constexpr ((j & 1) == 0) sum0 += w[q][j];
@@ -466,9 +474,62 @@ __device__ __forceinline__ void mfma4_role(const FistaArgs& a, const MfmaTaps& t
       const double beta = a.betas[it];
       forward();
       wg_sync();                                   // residual fragments and their sums are out
+      if constexpr (LOOPS) { ldsq0 = ldsq1 = lwsq0 = lwsq1 = 0.0; }
       backward(beta);
+      if constexpr (LOOPS) {                       // this wave's share of the rule's two norms (fista_mfma.h)
+        double num = ldsq0 + ldsq1, den = lwsq0 + lwsq1;
+        num += __shfl_xor(num, 16, 64);
+        den += __shfl_xor(den, 16, 64);
+        num += __shfl_xor(num, 32, 64);
+        den += __shfl_xor(den, 32, 64);
+        xl[(2 * k) * 64] = num;
+        xl[(2 * k + 1) * 64] = den;
+      }
       if (PB_MFMA_CHECKS && (((it & 7) == 7) || (it == a.n_iter - 1) || (it == 0 && !a.cold))) range_check();
       wg_sync();                                   // the updated iterate's fragments and sums are out
+      if constexpr (LOOPS) {
+        // every wave adds the shares in the same order: the same verdict everywhere (the branches below are workgroup-uniform)
+        const double num = (xl[0 * 64] + xl[2 * 64]) + (xl[4 * 64] + xl[6 * 64]);
+        const double den = (xl[1 * 64] + xl[3 * 64]) + (xl[5 * 64] + xl[7 * 64]);
+        const bool fire = lactive && it >= 3 &&
+                          (1.0 + beta) * sqrt(num) / (sqrt(den) + 1.0e-10 * (double)sigma) < a.tol;
+        if (__builtin_amdgcn_ballot_w64(fire) != 0) {         // (rare: at most once per problem)
+          range_check();                                      // this moment's operands, for the problems that finish now
+          float gq = guard, wq = wlast;
+          gq = fmaxf(gq, __shfl_xor(gq, 16, 64));
+          gq = fmaxf(gq, __shfl_xor(gq, 32, 64));
+          wq = fmaxf(wq, __shfl_xor(wq, 16, 64));
+          wq = fmaxf(wq, __shfl_xor(wq, 32, 64));
+          xg[(k * 2 + 0) * 64] = gq;
+          xg[(k * 2 + 1) * 64] = wq;
+          wg_sync();
+          bool in_range = true;
+          float wm = 0.0f;
+#pragma unroll
+          for (int j = 0; j < NW; ++j) {
+            in_range = in_range && (xg[(j * 2 + 0) * 64] < 60000.0f);
+            wm = fmaxf(wm, xg[(j * 2 + 1) * 64]);
+          }
+          const bool badq = !in_range || (a.rho_guard && wm > 0.0f && (float)th > MFMA_RHO_MAX * wm) || degenerate;
+          if (fire) {
+            lactive = false;
+            if (live && !badq) {
+              // (addresses made HERE, from laundered values: hoisted out of the loop they cost registers through the whole solve)
+              double* wrow = a.w + (int64_t)p * a.ldw + 32 * qoff + tb;
+              int nrv = nrem;
+              asm volatile("" : "+v"(wrow), "+v"(nrv));
+#pragma unroll
+              for (int q = 0; q < NBW; ++q)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                  if (!(LASTW && q >= NBW - 4) || 32 * q + j < nrv) wrow[32 * q + j] = w[q][j] * (double)inv_sigma;
+            }
+            if (!HAS_L && live && a.n_done && g == 0) a.n_done[p] = badq ? -1 : it + 1;
+          }
+          if (__builtin_amdgcn_ballot_w64(lactive && live) == 0) return;       // every problem of the workgroup has finished (all waves agree)
+          wg_sync();                                 // (the guard area is read again at the next finish)
+        }
+      }
     }
   } else {
     // rotated: the cost of iterate k+1 comes from the residual of the NEXT forward pass (one pass in front)
@@ -532,7 +593,7 @@ __device__ __forceinline__ void mfma4_role(const FistaArgs& a, const MfmaTaps& t
     wlast = wm;
   }
   const bool bad = !(guard < 60000.0f) || degenerate || (a.rho_guard && wlast > 0.0f && (float)th > MFMA_RHO_MAX * wlast) || (CERT && cflag);
-  if (live && !bad) {
+  if (live && !bad && (!LOOPS || lactive)) {
     double* wrow = a.w + (int64_t)p * a.ldw + 32 * qoff + tb;
 #pragma unroll
     for (int q = 0; q < NBW; ++q)
@@ -541,32 +602,33 @@ __device__ __forceinline__ void mfma4_role(const FistaArgs& a, const MfmaTaps& t
         if (!(LASTW && q >= NBW - 4) || 32 * q + j < nrem) wrow[32 * q + j] = w[q][j] * (double)inv_sigma;
       }
   }
-  if (!HAS_L && live && a.n_done && g == 0) a.n_done[p] = bad ? -1 : a.n_iter;
+  if (!HAS_L && live && a.n_done && g == 0 && (!LOOPS || lactive)) a.n_done[p] = bad ? -1 : a.n_iter;
 }
 
 // one workgroup = four waves = 16 problems; the wave index picks the share (scalar branches: each wave runs one role)
-template <int A, bool TAPS_DEV = false, bool WITH_J = false, bool CERT = false>
+template <int A, bool TAPS_DEV = false, bool WITH_J = false, bool CERT = false, bool LOOPS = false>
 __global__ __launch_bounds__(256) void fista_mfma4_kernel(FistaArgs a, MfmaTaps tp) {
   extern __shared__ __attribute__((aligned(16))) char mf4_smem[];
   if (a.range) {                                   // a candidate launch of a device-side plan: workgroups beyond its slots leave
     if ((int)blockIdx.x * 16 + a.range[0] >= a.range[1]) return;      // (all waves: before any barrier)
   }
   const int k = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  if (k == 0) mfma4_role<A, 0, TAPS_DEV, WITH_J, CERT>(a, tp, mf4_smem);
-  else if (k == 1) mfma4_role<A, 1, TAPS_DEV, WITH_J, CERT>(a, tp, mf4_smem);
-  else if (k == 2) mfma4_role<A, 2, TAPS_DEV, WITH_J, CERT>(a, tp, mf4_smem);
-  else mfma4_role<A, 3, TAPS_DEV, WITH_J, CERT>(a, tp, mf4_smem);
+  if (k == 0) mfma4_role<A, 0, TAPS_DEV, WITH_J, CERT, LOOPS>(a, tp, mf4_smem);
+  else if (k == 1) mfma4_role<A, 1, TAPS_DEV, WITH_J, CERT, LOOPS>(a, tp, mf4_smem);
+  else if (k == 2) mfma4_role<A, 2, TAPS_DEV, WITH_J, CERT, LOOPS>(a, tp, mf4_smem);
+  else mfma4_role<A, 3, TAPS_DEV, WITH_J, CERT, LOOPS>(a, tp, mf4_smem);
 }
 
-// Plain solves, with or without the cost trace, and the window rule (wind = 6) as a no-fire certificate; HRFs of up to
-// 33 taps; 128 (A - 1) < N <= 128 A: the series ends in one of the last wave's last four blocks.  Shared HRF in device memory
+// Plain solves, with or without the cost trace, the window rule (wind = 6) as a no-fire certificate, the _loops_deconv rule
+// in full (no cost trace); HRFs of up to 33 taps; 128 (A - 1) < N <= 128 A: the series ends in one of the last wave's last four blocks.  Shared HRF in device memory
 // (the blind step's z-step): plain only.
 template <int A>
 int launch_mfma4(const FistaArgs& a, const double* taps, int K, bool with_j, hipStream_t st) {
   if (a.N > 128 * A || a.N <= 128 * (A - 1) || K < 1 || K > 33) return 1;
-  const bool cert = a.stop_mode == PB_STOP_WINDOW;
-  if ((a.stop_mode != PB_STOP_NONE && !cert) || !a.n_done) return 1;
-  if ((with_j || cert) && a.taps_pp) return 1;
+  const bool cert = a.stop_mode == PB_STOP_WINDOW, loops = a.stop_mode == PB_STOP_LOOPS;
+  if (!a.n_done) return 1;
+  if ((with_j || cert || loops) && a.taps_pp) return 1;
+  if (loops && with_j) return 1;                   // (the _loops_deconv rule: plain variant, as on the one-wave form)
   const int64_t groups = (launch_count(a) + 15) / 16;
   const dim3 grid((unsigned)groups), block(256);
   const size_t lds = mfma4_lds_bytes(A);
@@ -576,6 +638,7 @@ int launch_mfma4(const FistaArgs& a, const double* taps, int K, bool with_j, hip
     hipLaunchKernelGGL(kernel, grid, block, lds, st, a, a.taps_pp ? MfmaTaps{} : make_mfma_taps(taps, K));
   };
   if (a.taps_pp) go(fista_mfma4_kernel<A, true>);
+  else if (loops) go(fista_mfma4_kernel<A, false, false, false, true>);
   else if (cert) go(fista_mfma4_kernel<A, false, true, true>);
   else if (with_j) go(fista_mfma4_kernel<A, false, true, false>);
   else go(fista_mfma4_kernel<A, false>);

@@ -501,3 +501,48 @@ def test_partition_and_guard_for_series_of_1200_scans(solver):
     W, _, nd = solver.fista_solve(Y, hrf, 0.05, 1.0 / lip, 150)
     Wo1, _, _ = c_oracle.fista_batch(Yo, hrf, 0.05, 1.0 / lip, 150, threads=8)
     assert int(nd.min()) == 150 and rel_rows(W[idx].cpu().numpy()[nz], Wo1[nz]).max() < 1e-5
+
+
+@pytest.mark.parametrize("n,k", [(600, 30), (330, 27), (640, 33), (1200, 28), (700, 30)])
+def test_loops_rule_inside_the_split_forms(solver, n, k):
+    """`_loops_deconv`'s criterion (pybold/bold_signal.py:267-273) in full inside `fista_mfma2_kernel<..., LOOPS>` (311 .. 640
+    scans) and `fista_mfma4_kernel<..., LOOPS>` (641 .. 1 280): every wave adds up its share of the two float64 norms beside the
+    update, the shares meet in LDS at the barrier that ends the iteration; a problem that meets the rule is written out at
+    that moment and its lanes keep iterating.  Stop iterations and iterates against the float64 oracle on series whose
+    stops spread over the run (a criterion within ~1e-6 of `tol` may cross one iteration apart: +-1 on 2 % at most);
+    through the library's own dispatch too (whole passes on the split form, the rest on the one-problem-per-wave form)."""
+    rng = np.random.RandomState(n + k)
+    hrf = orc.spm_hrf(1.0, 1.0, float(k), False)[0][:k]
+    lip = orc.gram_lipschitz(hrf, n)
+    V = 96
+    Z = np.zeros((V, n))
+    for v in range(V):
+        for _ in range(max(5, n // 60)):
+            o = rng.randint(0, n - 20)
+            Z[v, o:o + rng.randint(8, 16)] = 1.0
+    X = orc.causal_conv(hrf, Z)
+    noise = rng.randn(V, n)
+    noise *= (np.linalg.norm(X, axis=1) / np.linalg.norm(noise, axis=1) / np.sqrt(10 ** (np.linspace(-5, 20, V) / 10)))[:, None]
+    Y = torch.from_numpy((X + noise).astype(np.float32)).cuda()
+    Yh = Y.cpu().numpy().astype(np.float64)
+    # (the rule compares (1 + beta) ||clamp(u, +-th)|| with ||w'||: it fires where lambda is small against the signal)
+    lmed = float(np.median(orc.lambda_max(Yh, hrf)))
+    stops = set()
+    for lbda, tol in ((0.003 * lmed, 1e-3), (0.003 * lmed, 7e-4)):
+        Wo, ndo = orc.loops_batch(Yh, hrf, lbda, 1.0 / lip, 300, tol)
+        W, _, nd = solver.fista_solve(Y, hrf, lbda, 1.0 / lip, 300, stop="loops", tol=tol, force="mfma2only")
+        ndn = nd.cpu().numpy()
+        same = ndn == ndo
+        assert np.abs(ndn - ndo).max() <= 1 and same.mean() >= 0.97, (lbda, tol, ndn, ndo)       # (nothing handed back: dense solutions)
+        assert rel_rows(W.cpu().numpy()[same], Wo[same]).max() < 1e-5
+        stops |= set(ndo.tolist())
+    assert len(stops) > 10 and min(stops) < 300
+    # the default dispatch at a batch size that fills passes
+    reps = 6000 // V + 1
+    Yl = Y.repeat(reps, 1)[:6000].contiguous()
+    assert ("split over" in solver.which_kernel(n, k, 6000, stop="loops")) or ("four waves" in solver.which_kernel(n, k, 6000, stop="loops"))
+    Wl, _, ndl = solver.fista_solve(Yl, hrf, lbda, 1.0 / lip, 300, stop="loops", tol=tol)
+    ref_nd = ndo[np.arange(6000) % V]
+    assert np.abs(ndl.cpu().numpy() - ref_nd).max() <= 1 and (ndl.cpu().numpy() == ref_nd).mean() >= 0.97
+    ok = (ndl.cpu().numpy() == ref_nd)[:V]
+    assert rel_rows(Wl[:V].cpu().numpy()[ok], Wo[ok]).max() < 1e-5
