@@ -477,8 +477,11 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
       if constexpr (LOOPS) {
         // both waves add the halves in the same order: the same verdict in both (the branches below are workgroup-uniform)
         const double num = xl[0 * 64] + xl[2 * 64], den = xl[1 * 64] + xl[3 * 64];
-        const bool fire = lactive && it >= 3 &&
-                          (1.0 + beta) * sqrt(num) / (sqrt(den) + 1.0e-10 * (double)sigma) < a.tol;
+        // (the criterion in EVERY lane, pinned: under `lactive &&` the compiler evaluated it in an exec-masked region and
+        // parked live registers in accumulator registers there -- the pattern tools/isa_spill_lint.py refuses)
+        double crit = (1.0 + beta) * sqrt(num) / (sqrt(den) + 1.0e-10 * (double)sigma);
+        asm volatile("" : "+v"(crit));
+        const bool fire = lactive && it >= 3 && crit < a.tol;
         if (__builtin_amdgcn_ballot_w64(fire) != 0) {         // (rare: at most once per problem)
           range_check();                                      // this moment's operands, for the problems that finish now
           float gq = guard, wq = wlast;

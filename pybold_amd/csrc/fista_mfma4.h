@@ -108,7 +108,12 @@ __device__ __forceinline__ void mfma4_role(const FistaArgs& a, const MfmaTaps& t
   Frag An[2][NT], Bn[2][NT], Ff;
   {
     const int rho = lane & 15, kg = lane >> 4, gp = rho >> 2, i = rho & 3;
-    auto cval = [&](int lag) -> float { return lag < 0 ? 0.0f : lc[lag > LCW - 1 ? LCW - 1 : lag]; };
+    // (branch-free: an unconditional load from a clamped address, then a select -- under the per-lane `lag < 0 ? 0 : load`
+    // the compiler parked live registers in accumulator registers inside the exec-masked load: tools/isa_spill_lint.py)
+    auto cval = [&](int lag) -> float {
+      const float c = lc[lag < 0 ? 0 : (lag > LCW - 1 ? LCW - 1 : lag)];
+      return lag < 0 ? 0.0f : c;
+    };
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -491,8 +496,11 @@ __device__ __forceinline__ void mfma4_role(const FistaArgs& a, const MfmaTaps& t
         // every wave adds the shares in the same order: the same verdict everywhere (the branches below are workgroup-uniform)
         const double num = (xl[0 * 64] + xl[2 * 64]) + (xl[4 * 64] + xl[6 * 64]);
         const double den = (xl[1 * 64] + xl[3 * 64]) + (xl[5 * 64] + xl[7 * 64]);
-        const bool fire = lactive && it >= 3 &&
-                          (1.0 + beta) * sqrt(num) / (sqrt(den) + 1.0e-10 * (double)sigma) < a.tol;
+        // (the criterion in EVERY lane, pinned: under `lactive &&` the compiler evaluated it in an exec-masked region and
+        // parked live registers in accumulator registers there -- the pattern tools/isa_spill_lint.py refuses)
+        double crit = (1.0 + beta) * sqrt(num) / (sqrt(den) + 1.0e-10 * (double)sigma);
+        asm volatile("" : "+v"(crit));
+        const bool fire = lactive && it >= 3 && crit < a.tol;
         if (__builtin_amdgcn_ballot_w64(fire) != 0) {         // (rare: at most once per problem)
           range_check();                                      // this moment's operands, for the problems that finish now
           float gq = guard, wq = wlast;
