@@ -746,6 +746,7 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
     const ExactEntry* e = pick_exact(N, K);
     return (e && stop_mode == PB_STOP_WINDOW && wind != 6) ? nullptr : e;
   };
+  bool no_dense_class = false;                     // a partitioned call without a matrix-pipe form: every problem in the vector class
   auto run_partition = [&](const pb::PlanSpec& dense, const pb::PlanSpec& sparse, const pb::PlanSpec& flagged,
                            auto&& launch_form, auto&& has_form, auto&& bound) -> int {
     const WorkLayout wl = work_layout(P, V_series);
@@ -776,7 +777,7 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
     int32_t* rg_flag = rg_sparse + 2 * pb::CAND_COUNT;
     int32_t* rg_ill = rg_flag + 2 * pb::CAND_COUNT;
     {
-      pb::ClassPred cp{lbda_dev, lbda, lmax, y_rep, dense_ratio > 0.0 ? dense_ratio : (N > MFMA1_NMAX ? PB_PATH_DENSE_RATIO_LONG : PB_PATH_DENSE_RATIO), nullptr};
+      pb::ClassPred cp{lbda_dev, lbda, lmax, y_rep, no_dense_class ? 0.0 : (dense_ratio > 0.0 ? dense_ratio : (N > MFMA1_NMAX ? PB_PATH_DENSE_RATIO_LONG : PB_PATH_DENSE_RATIO)), nullptr};
       hipLaunchKernelGGL(pb::path_count_kernel, dim3(nblk), dim3(pb::PATH_THREADS), 0, user, cp, P, work_dev);
       pb::PlanSpec front = dense;
       front.merged = 1;
@@ -1097,9 +1098,14 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
     // (round 5: the call partitioned on the device -- run_partition above)
     const bool part_mfma = mfma != nullptr || (fe && (stop_mode == PB_STOP_NONE || mfma_cert || mfma_loops) && lbda_dev &&
                                                pick_mfma(N, K, stop_mode != PB_STOP_NONE) != nullptr);
-    if (part_mfma && part_ws) {
-      const mfma_launch_fn mfma_p = mfma ? mfma : pick_mfma(N, K, stop_mode != PB_STOP_NONE);
-      const mfma2_launch_fn mfma2_p = (mfma2 || !lbda_dev) ? mfma2 : (((stop_mode == PB_STOP_NONE || mfma2_cert) && K <= MFMA_K2) ? pick_mfma2(N, K) : nullptr);
+    // (... and a call no matrix-pipe form carries -- another window, a cost trace beside the _loops_deconv rule, a long HRF --
+    // is partitioned all the same, with an empty dense class: the conditioning guard is the partition's, and float32 vector
+    // forms need it too (ill-conditioned series: 3e-5 .. 5e-3 without it))
+    const bool part_guard_only = !part_mfma && !(flags & PB_FLAG_NO_ILL_GUARD);
+    if ((part_mfma || part_guard_only) && part_ws) {
+      no_dense_class = !part_mfma;
+      const mfma_launch_fn mfma_p = !part_mfma ? nullptr : (mfma ? mfma : pick_mfma(N, K, stop_mode != PB_STOP_NONE));
+      const mfma2_launch_fn mfma2_p = !part_mfma ? nullptr : ((mfma2 || !lbda_dev) ? mfma2 : (((stop_mode == PB_STOP_NONE || mfma2_cert) && K <= MFMA_K2) ? pick_mfma2(N, K) : nullptr));
       const bool one_stream = (flags & PB_FLAG_ONE_STREAM) != 0 || stream_is_capturing((hipStream_t)stream);
       const double slots = wave_slots();
       const bool has_wide = pick_wide_small(N, K) != nullptr;
@@ -1119,7 +1125,7 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
           return fe->fn(b, taps_host, K, wj, stop_mode, st);
         },
         [&](int form, int list) -> bool {
-          if (form == FORM_MFMA) return list <= 1;
+          if (form == FORM_MFMA) return list <= 1 && mfma_p != nullptr;
           if (form == FORM_MFMA2) return list <= 1 && has_mfma2;
           if (list == 1) return false;                                // (aid: matrix-pipe candidates only)
           if (form == FORM_PAIR) return list != 3 && has_pair;
