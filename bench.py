@@ -69,6 +69,14 @@ def mfma_per_wave_iteration(n, k, split=False):
     fista_mfma2_kernel together (fista_mfma2.h: floor(NB/2) + ceil(NB/2) blocks of 32 samples with the
     carry tile; the waves' carry chains restart at the cut: 270 at N = 300)."""
     nt = 2 if k <= 33 else 3
+    if split == 4:
+        # fista_mfma4_kernel: four waves of A = ceil(N / 128) blocks of 32 samples; per wave and pass 15 A matrix
+        # instructions less what the ends of the series lack (fista_mfma4.h; 576 at N = 1 200: 147 x 7 passes + 138)
+        a = (n + 127) // 128
+        mid = 2 * (3 * (a - 1) + 12 * a)                       # a middle wave, both passes (neighbours on both sides)
+        first = (3 * (a - 2) + 6 * a + 6 * (a - 1)) + (3 * (a - 1) + 12 * a)
+        last = (3 * (a - 1) + 12 * a) + (3 * (a - 2) + 6 * a + 6 * (a - 1))
+        return 2 * mid + first + last
     if split:
         nb = (n + 31) // 32
         a, b = nb // 2, nb - nb // 2
@@ -348,6 +356,8 @@ def run(args):
     P_dom = n_main if (args.kernel in ("auto", "seq") and n_main > 0) else P
     matrix_pipe = args.kernel in ("auto", "seq") and "matrix pipe" in (main_kernel if n_main else tail_kernel)
     split_form = matrix_pipe and "split over two" in (main_kernel if n_main else tail_kernel)
+    if matrix_pipe and "four waves" in (main_kernel if n_main else tail_kernel):
+        split_form = 4                                          # (641 .. 1 280 scans: one series over the four waves of a workgroup)
     if P_dom != P and P_dom % y_rep == 0:
         lam_dom = lam[:P_dom] if torch.is_tensor(lam) else lam
         plan_dom = solver.FistaPlan(Y[:P_dom // y_rep], hrf, lam_dom, step, n_iter, y_rep=y_rep,
@@ -391,7 +401,7 @@ def run(args):
         mfma_flop = n_mfma * MFMA_FLOP / 16.0
         exec_launch = mfma_flop * float(P_dom) * n_iter
         mfma_block = {"mfma_instructions_per_16_problems_and_iteration": n_mfma,
-                      "waves_per_16_problems": 2 if split_form else 1,
+                      "waves_per_16_problems": 4 if split_form == 4 else (2 if split_form else 1),
                       "f16_flops_per_voxel_iteration": mfma_flop,
                       "matrix_pipe_busy_estimate": n_mfma * 16.0 / 16.0 * float(P_dom) * n_iter /
                                                    (1024.0 * 2.1e9 * dom_ms * 1e-3),

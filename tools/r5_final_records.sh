@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-5 records in one GPU call: bench lines of the four configs (+ the 600-scan shape and the shard sizes), kernel
 # trace of the default bench command, counter passes (HBM traffic; SQ issue counters; matrix-pipe counters) for the
-# one-wave kernel of config 3 and for the split form at 600 scans.
+# one-wave kernel of config 3 and for the split form at 600 scans; bench line and kernel trace of the four-wave form at 1 200 scans.
 # (counter passes at 98 304 voxels = six whole rounds: every launch of the dominant kernel, partitioned call or alone, then has
 # the same 6 144 waves -- a partitioned call of 100 000 sizes its grid for 6 250 of which 106 leave at once)
 # Usage (on the GPU box, from the repo root):  bash tools/r5_final_records.sh <tag>
@@ -17,6 +17,8 @@ done
 python3 bench.py > "$out/${tag}_bench_c3.json" 2> "$out/${tag}_bench_c3.err" || exit 1
 echo "config 3 done"
 python3 bench.py --scans 600 --voxels 50000 --cpu-seconds 4 > "$out/${tag}_bench_600_scans.json" 2> "$out/${tag}_bench_600_scans.err" || exit 1
+python3 bench.py --scans 1200 --voxels 16384 --cpu-seconds 4 > "$out/${tag}_bench_1200_scans.json" 2> "$out/${tag}_bench_1200_scans.err" || exit 1
+echo "long series done"
 for v in 12500 25000 50000; do
   python3 bench.py --voxels $v --cpu-seconds 0 --busy-seconds 0 > "$out/${tag}_bench_${v}_voxels.json" 2> "$out/${tag}_bench_${v}_voxels.err" || exit 1
 done
@@ -33,6 +35,7 @@ run write "--voxels 98304" --pmc WRITE_SIZE || exit 1
 run sq "--voxels 98304" --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY || exit 1
 run mfma "--voxels 98304" --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_LDS || exit 1
 run trace600 "--scans 600 --voxels 49152" --kernel-trace --stats || exit 1
+run trace1200 "--scans 1200 --voxels 16384" --kernel-trace --stats || exit 1
 run sq600 "--scans 600 --voxels 49152" --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY || exit 1
 run mfma600 "--scans 600 --voxels 49152" --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_LDS || exit 1
 PB_PMC_KERNEL=fista_mfma_kernel python3 tools/summarise_pmc.py traffic "$out/${tag}_fetch" "$out/${tag}_write" "$out/${tag}_pmc_hbm_traffic.json" && \
@@ -42,5 +45,6 @@ PB_VOXELS_PER_WAVE=8 PB_PMC_KERNEL=fista_mfma2_kernel python3 tools/summarise_pm
 PB_PMC_KERNEL=fista_mfma2_kernel python3 tools/summarise_pmc.py sq "$out/${tag}_mfma600" "$out/${tag}_pmc_mfma_600_scans.json"
 find "$out/${tag}_trace" -name "*kernel_stats.csv" -exec cp {} "$out/${tag}_kernel_stats.csv" \;
 find "$out/${tag}_trace600" -name "*kernel_stats.csv" -exec cp {} "$out/${tag}_kernel_stats_600_scans.csv" \;
-rm -rf "$out/${tag}_trace" "$out/${tag}_trace600" "$out/${tag}_fetch" "$out/${tag}_write" "$out/${tag}_sq" "$out/${tag}_mfma" "$out/${tag}_sq600" "$out/${tag}_mfma600"
+find "$out/${tag}_trace1200" -name "*kernel_stats.csv" -exec cp {} "$out/${tag}_kernel_stats_1200_scans.csv" \;
+rm -rf "$out/${tag}_trace" "$out/${tag}_trace600" "$out/${tag}_trace1200" "$out/${tag}_fetch" "$out/${tag}_write" "$out/${tag}_sq" "$out/${tag}_mfma" "$out/${tag}_sq600" "$out/${tag}_mfma600"
 echo "all done"
