@@ -62,8 +62,9 @@ extern "C" {
                                      back to the float32 operators.  For INTERMEDIATE solves of an outer loop (the z-steps
                                      of the blind loop but the last): their errors, relative 1e-5..1e-4 of a still tiny
                                      iterate, are forgotten by the warm-started solves that follow */
-#define PB_FLAG_FORCE_MFMA2 65536u /* the matrix-pipe form with every series split over two waves (fista_mfma2_kernel:
-                                     129..640 scans, HRFs of up to 33 taps, plain solves), one launch */
+#define PB_FLAG_FORCE_MFMA2 65536u /* the matrix-pipe form with every series split over the waves of a workgroup, one launch:
+                                     two waves (fista_mfma2_kernel, 129..640 scans) or four (fista_mfma4_kernel, 641..1280);
+                                     HRFs of up to 33 taps; plain, cost trace, window certificate, _loops_deconv rule */
 #define PB_FLAG_NO_MFMA 8192u      /* plain solves: never the matrix-pipe form (fista_mfma_kernel), vector forms only */
 #define PB_FLAG_FORCE_CERT 1024u   /* PB_STOP_WINDOW, wind = 6: certificate path whatever tol * n_iter is */
 #define PB_FLAG_NO_PARTITION 4096u  /* never partition a call on the device (see pb_fista_solve_ex): the host-side plan of round 4 */
@@ -101,7 +102,8 @@ int pb_fista_has_fast_path(int N, int K);
  * one problem per wave (long series), 4 = register-resident, 16 problems per wave, both operators
  * on the matrix pipe (fista_mfma_kernel: 129..310 scans; HRFs of up to 48 taps, the window-rule certificate up to
  * 33; one lambda for the batch; assumes n_done_dev is given), 5 = the same with every series split over the two waves
- * of a workgroup (fista_mfma2_kernel: small batches, and series of 311..640 scans).  Host-only query. */
+ * of a workgroup (fista_mfma2_kernel: small batches, and series of 311..640 scans), 6 = split over the four waves of a
+ * workgroup (fista_mfma4_kernel: series of 641..1280 scans, HRFs of up to 33 taps).  Host-only query. */
 int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mode, int wind);
 
 /* How pb_fista_solve (no flags) lays P problems out: problems [0, *n_main) in one launch of

@@ -78,12 +78,12 @@ def _warn_if_slow_kernel(lib, N, K, P, want_J, stop, wind, flags):
         why = []
         if N <= 128:
             why = []                                  # (short series: the pair form is the fast one there)
-        elif N > 640:
-            why.append("series of %d scans (matrix-pipe forms: 129..640)" % N)
+        elif N > 1280:
+            why.append("series of %d scans (matrix-pipe forms: 129..1280)" % N)
         elif K > 48 or (K > 33 and N > 310):
             why.append("HRF of %d taps (matrix-pipe forms: <= 33 taps, <= 48 up to 310 scans)" % K)
-        elif _STOP[stop] == PB_STOP_LOOPS and (want_J or N > 310):
-            why.append("the _loops_deconv rule %s" % ("with a cost trace" if want_J else "beyond 310 scans"))
+        elif _STOP[stop] == PB_STOP_LOOPS and want_J:
+            why.append("the _loops_deconv rule with a cost trace")
         elif _STOP[stop] == PB_STOP_WINDOW:
             why.append("the window rule with wind=%d / this tolerance (matrix pipe: wind = 6 and tol * n_iter < 0.02)" % wind)
         if why:

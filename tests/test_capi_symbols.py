@@ -40,11 +40,16 @@ def test_version_and_dispatch_table(lib):
     assert lib.pb_fista_has_fast_path(300, 30) == 1     # BASELINE configs 1-3, 5
     assert lib.pb_fista_has_fast_path(300, 27) == 1     # config 4
     assert lib.pb_fista_has_fast_path(240, 27) == 1     # golden _loops_deconv case
-    assert lib.pb_fista_has_fast_path(1200, 28) == 1    # HCP-length runs: one problem per wave
-    assert lib.pb_fista_which_kernel(1200, 28, 5000, 0, 0, 6) == 3
-    assert lib.pb_fista_which_kernel(1200, 28, 5000, 1, 0, 6) == 3
-    assert lib.pb_fista_which_kernel(1200, 28, 5000, 0, 1, 6) == 3
-    assert lib.pb_fista_which_kernel(1200, 28, 5000, 1, 2, 6) == 3      # default deconv path
+    assert lib.pb_fista_has_fast_path(1200, 28) == 1    # HCP-length runs
+    assert lib.pb_fista_which_kernel(1200, 28, 5000, 0, 0, 6) == 6      # round 5: one series over the four waves of a workgroup (641..1280 scans)
+    assert lib.pb_fista_which_kernel(1200, 28, 5000, 1, 0, 6) == 6
+    assert lib.pb_fista_which_kernel(1200, 28, 5000, 0, 1, 6) == 6      # the _loops_deconv rule inside it
+    assert lib.pb_fista_which_kernel(1200, 28, 5000, 1, 1, 6) == 3      # ... with a cost trace: one problem per wave
+    assert lib.pb_fista_which_kernel(1200, 28, 5000, 1, 2, 6) == 6      # default deconv path: window-rule certificate
+    assert lib.pb_fista_which_kernel(1200, 28, 5000, 1, 2, 4) == 3      # another window: the exact rule, one problem per wave
+    assert lib.pb_fista_which_kernel(1200, 28, 2000, 0, 0, 6) == 3      # under 5/8 of a pass: the vector form finishes first
+    assert lib.pb_fista_which_kernel(1200, 40, 5000, 0, 0, 6) == 3      # 34+ taps: one problem per wave
+    assert lib.pb_fista_which_kernel(600, 30, 6000, 0, 1, 6) == 5       # the _loops_deconv rule inside the two-wave form
     assert lib.pb_fista_which_kernel(2400, 28, 5000, 1, 2, 6) == 0      # S = 38: ring too large
     assert lib.pb_fista_has_fast_path(100000, 30) == 0
     assert lib.pb_fista_has_fast_path(300, 48) == 1     # short TR: HRFs of up to 48 taps
@@ -90,7 +95,9 @@ def test_version_and_dispatch_table(lib):
     assert lib.pb_fista_which_kernel(129, 30, 100000, 0, 0, 6) == 4      # five blocks
     assert lib.pb_fista_which_kernel(640, 30, 100000, 0, 0, 6) == 5      # up to 640 scans on the split matrix-pipe form
     assert lib.pb_fista_which_kernel(640, 30, 100000, 1, 0, 6) == 5      # ... with the cost trace too
-    assert lib.pb_fista_which_kernel(641, 30, 100000, 0, 0, 6) == 3
+    assert lib.pb_fista_which_kernel(641, 30, 100000, 0, 0, 6) == 6      # ... one scan more: four waves per series (round 5), up to 1 280
+    assert lib.pb_fista_which_kernel(1280, 30, 100000, 0, 0, 6) == 6
+    assert lib.pb_fista_which_kernel(1281, 30, 100000, 0, 0, 6) == 3
     assert lib.pb_fista_which_kernel(5000, 30, 10, 0, 0, 6) == 0
 
 

@@ -14,11 +14,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "pybold_amd", "csrc")
 
 
-@pytest.mark.parametrize("target", ["mfma2_8_9", "mfma_10", "mfma4_10"])
-def test_no_spill_under_a_partial_exec_mask(target):
+LISTINGS = ["mfma2_8_9", "mfma_10", "mfma4_10"]
+
+
+@pytest.fixture(scope="module")
+def listings():
+    """The three listings in ONE parallel make (about a minute each on one core)."""
     if subprocess.call(["which", "hipcc"], stdout=subprocess.DEVNULL) != 0 and not os.path.exists("/opt/rocm/bin/hipcc"):
         pytest.skip("no hipcc")
-    subprocess.check_call(["make", "-s", "-C", CSRC, "build/%s.s" % target])
+    subprocess.check_call(["make", "-s", "-j4", "-C", CSRC] + ["build/%s.s" % t for t in LISTINGS])
+
+
+@pytest.mark.parametrize("target", LISTINGS)
+def test_no_spill_under_a_partial_exec_mask(listings, target):
     lst = os.path.join(CSRC, "build", target + ".s")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_spill_lint.py"), lst], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
