@@ -32,7 +32,8 @@ namespace pb {
 // areas (fragment, far fields, scale, guards, cost-trace parts), the taps, the certificate's per-lane state
 constexpr size_t mfma2_lds_bytes(int nbm) {
   return ((size_t)2 * nbm * 2 * 64 + 2 * 64) * sizeof(u4) +
-         (size_t)(2 * 64 + 64 + 64 + 2 * 64 + 4 * 64 + 6 * 64 + 7 * 128) * sizeof(float) + (size_t)2 * 2 * 64 * sizeof(double);
+         (size_t)(2 * 64 + 64 + 64 + 2 * 64 + 4 * 64 + 6 * 64 + 7 * 128) * sizeof(float) + (size_t)2 * 2 * 64 * sizeof(double) +
+         (size_t)256 * sizeof(double) + (size_t)256 * sizeof(float);
 }
 
 // ROLE 0: the left wave (blocks 0 .. NBA-1), ROLE 1: the right wave (blocks NBA .. NBA+NBB-1; padding in its last block)
@@ -66,13 +67,18 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
   u4* const xw = lbase + 2 * (NBM * 2 * 64) + lane;                // [2][64]: fragment (hi, lo) of the left wave's last block
   float* const fbase = reinterpret_cast<float*>(lbase + 2 * (NBM * 2 * 64) + 2 * 64);
   float* const lc = fbase + ROLE * LCW;                            // [2][64] cumulative taps, one copy per wave
-  float* const xc = fbase + 2 * LCW + lane;                        // [64] left -> right: S sum(w, blocks 0 .. NBA-2)
-  float* const xr = fbase + 2 * LCW + 64 + lane;                   // [64] right -> left: S sum(r, blocks NBA+1 ..)
+  // (fbase + 2 LCW .. + 128: round 4's far-field scalars; since round 5 they cross as lane parts, xcp / xrp below)
   float* const xm = fbase + 2 * LCW + 128;                         // [2][64] max |y| of each half
   float* const xg = fbase + 2 * LCW + 256;                         // [2][2][64] guard, largest |w| of each half
   float* const xj = fbase + 2 * LCW + 512;                         // [2][3][64] cost-trace parts of each half: ||r||^2, ||w||_1, certificate
   float* const lt = fbase + 2 * LCW + 896 + threadIdx.x;           // [7][128] certificate state of every lane (as fista_mfma.h)
   double* const xl = reinterpret_cast<double*>(fbase + 2 * LCW + 896 + 7 * 128) + lane;     // [2][2][64] _loops_deconv rule: ||d||^2, ||w'||^2 of each half
+  // The two far-field scalars cross the cut as the four LANE PARTS of each problem (slot 4 v + g), added up by the wave that
+  // reads them: a lane-crossing sum at the END of a pass is two dependent ds_bpermute round trips with nothing left to
+  // overlap them (round 5: ~250 cycles per pass, 10 % of an iteration of five-block waves); at the START of the next pass the
+  // reads hide behind the float16 split of the first block.
+  double* const xcp = reinterpret_cast<double*>(fbase + 2 * LCW + 896 + 7 * 128) + 2 * 2 * 64;   // [16][4] left -> right: sum(w, blocks 0 .. NBA-2), lane parts
+  float* const xrp = reinterpret_cast<float*>(xcp + 256);                                         // [16][4] right -> left: sum(r, blocks NBA+1 ..), lane parts
   if constexpr (CERT) {
 #pragma unroll
     for (int q = 0; q < 7; ++q) lt[q * 128] = 0.0f;
@@ -210,7 +216,7 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
   float jsq = 0.0f, jl1 = 0.0f;
   // CERT: lane group g tracks sample 3 of block CQ[g] of this wave's half
   constexpr int CQ0 = NBW / 8, CQ1 = (3 * NBW) / 8, CQ2 = (5 * NBW) / 8, CQ3 = (7 * NBW) / 8;
-  const int cq_mine = g == 0 ? CQ0 : (g == 1 ? CQ1 : (g == 2 ? CQ2 : CQ3));
+  const int cq_mine = ((2 * g + 1) * NBW) >> 3;    // = CQ0 .. CQ3 of lane group g (arithmetic: the chained selects became branches writing an accumulator register under partial exec masks)
   double cu = 0.0, cw = 0.0;
   float jw2 = 0.0f, cvsq = 0.0f;
   bool cflag = false;
@@ -246,11 +252,7 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
     xw[64] = __builtin_bit_cast(u4, f.lo);
   };
   // ... and the far field of the blocks before it (float64 sum over this lane's samples -> the problem's four lanes)
-  auto publish_far_field = [&](double s) {
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
-    *xc = (float)(s * (double)s_far);
-  };
+  auto publish_far_field = [&](double s) { xcp[4 * v + g] = s; };
 
   // ---- forward: r = T_c w - y over this wave's blocks (ascending) ---------------------------------------------
   auto forward = [&]() __attribute__((always_inline)) {
@@ -258,7 +260,8 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
     Frag wfX;                                      // right wave: the left wave's last block
     f2v rs2 = f2v{0.f, 0.f};                       // right wave: sum of the residual samples of its blocks 1 ..
     if constexpr (ROLE == 1) {
-      const float c = *xc;
+      const double* pc = xcp + 4 * v;               // (every lane of a problem adds the same four parts in the same order)
+      const float c = (float)(((pc[0] + pc[1]) + (pc[2] + pc[3])) * (double)s_far);
       carry = f4{c, c, c, c};
       wfX.hi = __builtin_bit_cast(h8, xw[0]);
       wfX.lo = __builtin_bit_cast(h8, xw[64]);
@@ -338,10 +341,7 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
     });
     static_for<0, 4>([&](auto pc) { finish_pair(std::integral_constant<int, NBW - 1>{}, pc); });
     if constexpr (ROLE == 1) {                     // what the left wave's adjoint pass needs of the far blocks
-      float rs = rs2[0] + rs2[1];
-      rs += __shfl_xor(rs, 16, 64);
-      rs += __shfl_xor(rs, 32, 64);
-      *xr = rs * s_far;
+      xrp[4 * v + g] = rs2[0] + rs2[1];
     }
   };
 
@@ -352,7 +352,8 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
     Frag rfX;                                      // left wave: the right wave's first block
     double sum0 = 0.0, sum1 = 0.0;                 // left wave: sum of the updated iterate over blocks 0 .. NBW-2
     if constexpr (ROLE == 0) {
-      const float c = *xr;
+      const float* pr = xrp + 4 * v;
+      const float c = ((pr[0] + pr[1]) + (pr[2] + pr[3])) * s_far;
       carry = f4{c, c, c, c};
       rfX.hi = __builtin_bit_cast(h8, lrf_right[0]);
       rfX.lo = __builtin_bit_cast(h8, lrf_right[64]);

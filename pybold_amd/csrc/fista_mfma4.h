@@ -26,8 +26,9 @@ constexpr int MFMA4_WAVES = 4;
 // bytes of dynamic LDS of one workgroup (four waves of A blocks): residual fragments, last-block fragments, cumulative
 // taps, the float64 sums of the iterate, residual sums, scale, guards, cost-trace parts, certificate state
 constexpr size_t mfma4_lds_bytes(int A) {
-  return ((size_t)MFMA4_WAVES * A * 2 * 64 + MFMA4_WAVES * 2 * 64) * sizeof(u4) + (size_t)2 * MFMA4_WAVES * 2 * 64 * sizeof(double) +
-         (size_t)MFMA4_WAVES * (64 + 2 * 64 + 64 + 2 * 64 + 3 * 64) * sizeof(float) + (size_t)7 * 256 * sizeof(float);
+  return ((size_t)MFMA4_WAVES * A * 2 * 64 + MFMA4_WAVES * 2 * 64) * sizeof(u4) +
+         ((size_t)MFMA4_WAVES * 2 * 256 + MFMA4_WAVES * 2 * 64) * sizeof(double) +
+         (size_t)MFMA4_WAVES * (64 + 2 * 256 + 64 + 2 * 64 + 3 * 64) * sizeof(float) + (size_t)7 * 256 * sizeof(float);
 }
 
 // One wave's share, KW = wave index.  HAS_L / HAS_R: there is a wave to the left / right; LASTW: the wave holding the end
@@ -59,15 +60,18 @@ __device__ __forceinline__ void mfma4_role(const FistaArgs& a, const MfmaTaps& t
   u4* const lrf = lbase + k * (NBW * 2 * 64) + lane;               // this wave's residual fragments
   u4* const lrf_next = lbase + (k + 1) * (NBW * 2 * 64) + lane;    // the right neighbour's (its block 0)
   u4* const xwb = lbase + NW * (NBW * 2 * 64) + lane;              // [NW][2][64]: fragment (hi, lo) of wave j's last block
-  double* const xs = reinterpret_cast<double*>(lbase + NW * (NBW * 2 * 64) + NW * 2 * 64) + lane;   // [NW][2][64]: E_j, T_j
-  double* const xl = xs + NW * 2 * 64;                             // [NW][2][64]: _loops_deconv rule, each wave's ||d||^2, ||w'||^2
-  float* const fbase = reinterpret_cast<float*>(lbase + NW * (NBW * 2 * 64) + NW * 2 * 64) + 2 * NW * 2 * 64 * 2;
+  // The sums cross the cuts as the four LANE PARTS of each problem (slot 4 v + g), added up by the wave that reads them: a
+  // lane-crossing sum at the end of a pass is two dependent ds_bpermute round trips with nothing to overlap them; at the
+  // start of the next pass the reads hide behind the float16 split of the first block (fista_mfma2.h).
+  double* const xsp = reinterpret_cast<double*>(lbase + NW * (NBW * 2 * 64) + NW * 2 * 64);        // [NW][2][16][4]: E_j, T_j lane parts
+  double* const xl = xsp + NW * 2 * 256 + lane;                    // [NW][2][64]: _loops_deconv rule, each wave's ||d||^2, ||w'||^2
+  float* const fbase = reinterpret_cast<float*>(xsp + NW * 2 * 256 + NW * 2 * 64);
   float* const lc = fbase + k * LCW;                               // [NW][64] cumulative taps, one copy per wave
-  float* const xr = fbase + NW * LCW + lane;                       // [NW][2][64]: S RE_j, S RT_j
-  float* const xm = fbase + NW * LCW + NW * 128 + lane;            // [NW][64] max |y| of each share
-  float* const xg = fbase + NW * LCW + NW * 192 + lane;            // [NW][2][64] guard, largest |w| of each share
-  float* const xj = fbase + NW * LCW + NW * 320 + lane;            // [NW][3][64] cost-trace parts: ||r||^2, ||w||_1, certificate
-  float* const lt = fbase + NW * LCW + NW * 512 + 64 * k + lane;    // [7][256] certificate state of every lane (fista_mfma.h)
+  float* const xrp = fbase + NW * LCW;                             // [NW][2][16][4]: RE_j, RT_j lane parts
+  float* const xm = fbase + NW * LCW + NW * 512 + lane;            // [NW][64] max |y| of each share
+  float* const xg = fbase + NW * LCW + NW * 576 + lane;            // [NW][2][64] guard, largest |w| of each share
+  float* const xj = fbase + NW * LCW + NW * 704 + lane;            // [NW][3][64] cost-trace parts: ||r||^2, ||w||_1, certificate
+  float* const lt = fbase + NW * LCW + NW * 896 + 64 * k + lane;   // [7][256] certificate state of every lane (fista_mfma.h)
   if constexpr (CERT) {
 #pragma unroll
     for (int q = 0; q < 7; ++q) lt[q * 256] = 0.0f;
@@ -207,7 +211,7 @@ __device__ __forceinline__ void mfma4_role(const FistaArgs& a, const MfmaTaps& t
   float jsq = 0.0f, jl1 = 0.0f;
   // CERT: lane group g tracks sample 3 of block CQ[g] of this wave's share
   constexpr int CQ0 = NBW / 8, CQ1 = (3 * NBW) / 8, CQ2 = (5 * NBW) / 8, CQ3 = (7 * NBW) / 8;
-  const int cq_mine = g == 0 ? CQ0 : (g == 1 ? CQ1 : (g == 2 ? CQ2 : CQ3));
+  const int cq_mine = ((2 * g + 1) * NBW) >> 3;    // = CQ0 .. CQ3 of lane group g (arithmetic: the chained selects became branches writing an accumulator register under partial exec masks)
   double cu = 0.0, cw = 0.0;
   float jw2 = 0.0f, cvsq = 0.0f;
   bool cflag = false;
@@ -244,12 +248,8 @@ __device__ __forceinline__ void mfma4_role(const FistaArgs& a, const MfmaTaps& t
   };
   // ... and the float64 sums of this wave's blocks without / with the last one (this lane's samples -> the problem's four lanes)
   auto publish_sums = [&](double se, double sl) {
-    se += __shfl_xor(se, 16, 64);
-    sl += __shfl_xor(sl, 16, 64);
-    se += __shfl_xor(se, 32, 64);
-    sl += __shfl_xor(sl, 32, 64);
-    xs[(2 * k) * 64] = se;
-    xs[(2 * k + 1) * 64] = se + sl;
+    xsp[(2 * k) * 256 + 4 * v + g] = se;
+    xsp[(2 * k + 1) * 256 + 4 * v + g] = se + sl;
   };
 
   // ---- forward: r = T_c w - y over this wave's blocks (ascending) ---------------------------------------------------
@@ -258,8 +258,14 @@ __device__ __forceinline__ void mfma4_role(const FistaArgs& a, const MfmaTaps& t
     Frag wfX;                                      // the left neighbour's last block
     f2v rs2 = f2v{0.f, 0.f}, rs0 = f2v{0.f, 0.f};  // sums of the residual samples of blocks 1 .. / of block 0
     if constexpr (HAS_L) {
-      double s = xs[(2 * (k - 1)) * 64];           // E_{k-1} + T_{k-2} + ... + T_0
-      for (int j = k - 2; j >= 0; --j) s += xs[(2 * j + 1) * 64];
+      // E_{k-1} + T_{k-2} + ... + T_0 (every lane of a problem adds the same parts in the same order)
+      const double* pe = xsp + (2 * (k - 1)) * 256 + 4 * v;
+      double s = (pe[0] + pe[1]) + (pe[2] + pe[3]);
+#pragma unroll
+      for (int j = k - 2; j >= 0; --j) {
+        const double* pt = xsp + (2 * j + 1) * 256 + 4 * v;
+        s += (pt[0] + pt[1]) + (pt[2] + pt[3]);
+      }
       const float c = (float)(s * (double)s_far);
       carry = f4{c, c, c, c};
       wfX.hi = __builtin_bit_cast(h8, xwb[(2 * (k - 1)) * 64]);
@@ -347,13 +353,9 @@ __device__ __forceinline__ void mfma4_role(const FistaArgs& a, const MfmaTaps& t
     });
     static_for<0, 4>([&](auto pc) { finish_pair(std::integral_constant<int, NBW - 1>{}, pc); });
     if constexpr (HAS_L) {                         // what the waves to the left need of this wave's residual
-      float re = rs2[0] + rs2[1], r0 = rs0[0] + rs0[1];
-      re += __shfl_xor(re, 16, 64);
-      r0 += __shfl_xor(r0, 16, 64);
-      re += __shfl_xor(re, 32, 64);
-      r0 += __shfl_xor(r0, 32, 64);
-      xr[(2 * k) * 64] = re * s_far;
-      xr[(2 * k + 1) * 64] = (re + r0) * s_far;
+      const float re = rs2[0] + rs2[1], r0 = rs0[0] + rs0[1];
+      xrp[(2 * k) * 256 + 4 * v + g] = re;
+      xrp[(2 * k + 1) * 256 + 4 * v + g] = re + r0;
     }
   };
 
@@ -364,8 +366,14 @@ __device__ __forceinline__ void mfma4_role(const FistaArgs& a, const MfmaTaps& t
     Frag rfX;                                      // the right neighbour's first block
     double sum0 = 0.0, sum1 = 0.0, suml = 0.0;     // sums of the updated iterate over blocks 0 .. NBW-2 / over block NBW-1
     if constexpr (HAS_R) {
-      float c = xr[(2 * (k + 1)) * 64];            // S (RE_{k+1} + RT_{k+2} + ...)
-      for (int j = k + 2; j < NW; ++j) c += xr[(2 * j + 1) * 64];
+      const float* pe = xrp + (2 * (k + 1)) * 256 + 4 * v;          // S (RE_{k+1} + RT_{k+2} + ...)
+      float c = (pe[0] + pe[1]) + (pe[2] + pe[3]);
+#pragma unroll
+      for (int j = k + 2; j < NW; ++j) {
+        const float* pt = xrp + (2 * j + 1) * 256 + 4 * v;
+        c += (pt[0] + pt[1]) + (pt[2] + pt[3]);
+      }
+      c *= s_far;
       carry = f4{c, c, c, c};
       rfX.hi = __builtin_bit_cast(h8, lrf_next[0]);
       rfX.lo = __builtin_bit_cast(h8, lrf_next[64]);

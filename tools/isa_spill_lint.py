@@ -24,8 +24,13 @@ for path in sys.argv[1:]:
         if s.startswith("s_endpgm"):
             kernel = None
             continue
-        if re.match(r"s_and_saveexec_b64|s_or_saveexec_b64|s_andn2_saveexec_b64", s):
+        if re.match(r"s_and_saveexec_b64", s):
             stack.append(n)
+        elif re.match(r"s_or_saveexec_b64|s_andn2_saveexec_b64", s):   # the else-part of the region on top: same level
+            if stack:
+                stack[-1] = n
+            else:
+                stack.append(n)
         elif re.match(r"s_or_b64 exec, exec,", s) or re.match(r"s_mov_b64 exec,", s):
             if stack:
                 stack.pop()
