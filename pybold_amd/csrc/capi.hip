@@ -110,11 +110,12 @@ mfma2_launch_fn pick_mfma2(int N, int K) {
   return tab[nb - 5];
 }
 // the same with one series split over the FOUR waves of a workgroup (fista_mfma4.h): 641 .. 1 280 scans, A = ceil(N / 128)
-// blocks per wave (6 .. 10); K <= 33; the call shapes of the two-wave form
-mfma2_launch_fn pick_mfma4(int N, int K) {
+// blocks per wave (6 .. 10); K <= 33 with two near tiles: the call shapes of the two-wave form; 34 <= K <= 65 with three: plain
+// solves and the cost trace (`extras` = certificate, _loops_deconv rule: not built for those)
+mfma2_launch_fn pick_mfma4(int N, int K, bool extras = false) {
   static const mfma2_launch_fn tab[] = {&pb::launch_mfma4<6>, &pb::launch_mfma4<7>, &pb::launch_mfma4<8>, &pb::launch_mfma4<9>,
                                         &pb::launch_mfma4<10>};
-  if (K < 1 || K > 33 || N <= 640 || N > 1280) return nullptr;
+  if (K < 1 || K > 65 || (K > 33 && extras) || N <= 640 || N > 1280) return nullptr;
   return tab[(N + 127) / 128 - 6];
 }
 typedef int (*mfma_launch_fn)(const pb::FistaArgs&, const double*, int, bool, hipStream_t);
@@ -354,7 +355,7 @@ int mfma2_long_base(int P, bool one_launch) {
 // the batch; whole passes, a remainder above MFMA4_MIN_R of a pass too, a smaller one -- and batches below it -- on the
 // one-problem-per-wave form
 constexpr int MFMA4_MIN_R_NUM = 10, MFMA4_MIN_R_DEN = 16;   // (N = 1 200: 2 048 problems 1.89 ms against 2.31, 3 072 2.59 against 2.30 -- profiles/r5_long_series_1200_scans.txt)
-bool mfma4_serves(int N, int K) { return pick_mfma4(N, K) != nullptr && pick_wide(N, K) != nullptr; }
+bool mfma4_serves(int N, int K, bool extras = false) { return pick_mfma4(N, K, extras) != nullptr && pick_wide(N, K) != nullptr; }
 int mfma4_base(int P, bool one_launch) {
   const int pass = (int)wave_slots() * 2;            // 16 problems x (slots / 2 per SIMD / 4 SIMDs per workgroup)
   const int base = (P / pass) * pass;
@@ -577,7 +578,7 @@ int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mod
   const bool mfma_plain = stop_mode == PB_STOP_NONE && mfma_serves_plain(N, K);
   const bool split_shape = stop_mode == PB_STOP_NONE || (stop_mode == PB_STOP_WINDOW && wind == 6) || (stop_mode == PB_STOP_LOOPS && !with_cost_trace);
   const bool mfma2_ok = (stop_mode == PB_STOP_NONE || (stop_mode == PB_STOP_WINDOW && wind == 6)) && pick_mfma2(N, K) != nullptr;
-  if (split_shape && mfma4_serves(N, K) && (stop_mode != PB_STOP_WINDOW || pick_wide(N, K)->S <= 20))
+  if (split_shape && mfma4_serves(N, K, stop_mode != PB_STOP_NONE) && (stop_mode != PB_STOP_WINDOW || pick_wide(N, K)->S <= 20))
     return mfma4_base(P, false) > 0 ? pb::FORM_MFMA4 : FORM_WIDE;
   if (split_shape && pick_mfma2(N, K) && mfma2_serves_long(N, K) && P >= MFMA2_LONG_MIN_P && (stop_mode != PB_STOP_WINDOW || pick_wide(N, K)->S <= 20))
     return mfma2_long_base(P, false) > 0 ? FORM_MFMA2 : ((pick_fast(N, K) && N <= 320) ? FORM_FAST1 : FORM_WIDE);   // (the solve's own backup form)
@@ -618,7 +619,7 @@ int pb_fista_plan_ex(int N, int K, int P, int stop_mode, int wind, unsigned flag
                         pick_mfma2(N, K) != nullptr;
   const bool split_shape = stop_mode == PB_STOP_NONE || (stop_mode == PB_STOP_WINDOW && wind == 6) || stop_mode == PB_STOP_LOOPS;
   if (N >= 1 && K >= 1 && P >= 1 && split_shape && !no_mfma &&
-      mfma4_serves(N, K) && (stop_mode != PB_STOP_WINDOW || pick_wide(N, K)->S <= 20)) {
+      mfma4_serves(N, K, stop_mode != PB_STOP_NONE) && (stop_mode != PB_STOP_WINDOW || pick_wide(N, K)->S <= 20)) {
     const int base = mfma4_base(P, (flags & (PB_FLAG_ONE_LAUNCH | PB_FLAG_FORCE_MFMA2)) != 0);
     if (base > 0 && base < P) { nm = base; mf = pb::FORM_MFMA4; tf = FORM_WIDE; }
     else tf = base > 0 ? pb::FORM_MFMA4 : FORM_WIDE;
@@ -887,7 +888,7 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
     const bool four = N > 640;                       // 641 .. 1 280 scans: the form split over four waves (fista_mfma4.h)
     const bool shape_ok = (stop_mode == PB_STOP_NONE || mfma2_cert || split_loops) && n_done_dev &&
                           !(flags & (PB_FLAG_FORCE_GENERIC | PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_FORCE_WIDE | PB_FLAG_DIRECT_FIR | PB_FLAG_NO_MFMA));
-    const mfma2_launch_fn mfma2_l = four ? ((shape_ok && mfma4_serves(N, K)) ? pick_mfma4(N, K) : nullptr)
+    const mfma2_launch_fn mfma2_l = four ? ((shape_ok && mfma4_serves(N, K, stop_mode != PB_STOP_NONE)) ? pick_mfma4(N, K, stop_mode != PB_STOP_NONE) : nullptr)
                                          : ((mfma2 || !lbda_dev || !(stop_mode == PB_STOP_NONE || mfma2_cert || split_loops)) ? mfma2 : pick_mfma2(N, K));
     if (mfma2_l && part_ws && (four || (mfma2_serves_long(N, K) && P >= MFMA2_LONG_MIN_P))) {
       const FastEntry* fe1 = pick_fast(N, K);
@@ -930,7 +931,7 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
   const mfma2_launch_fn mfma4 =
       ((stop_mode == PB_STOP_NONE || mfma2_cert || split_loops) && n_done_dev && (!lbda_dev || (flags & (PB_FLAG_FORCE_MFMA | PB_FLAG_FORCE_MFMA2))) &&
        !(flags & (PB_FLAG_FORCE_GENERIC | PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_FORCE_WIDE | PB_FLAG_DIRECT_FIR |
-                  PB_FLAG_NO_MFMA)) && mfma4_serves(N, K)) ? pick_mfma4(N, K) : nullptr;
+                  PB_FLAG_NO_MFMA)) && mfma4_serves(N, K, stop_mode != PB_STOP_NONE)) ? pick_mfma4(N, K, stop_mode != PB_STOP_NONE) : nullptr;
   if (mfma4) {
     const WideEntry* we1 = pick_wide(N, K);
     if (stop_mode != PB_STOP_WINDOW || we1->S <= 20) {     // (the window rule's re-solve needs the rule's increment ring)

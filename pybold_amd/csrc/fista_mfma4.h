@@ -26,23 +26,26 @@ constexpr int MFMA4_WAVES = 4;
 // bytes of dynamic LDS of one workgroup (four waves of A blocks): residual fragments, last-block fragments, cumulative
 // taps, the float64 sums of the iterate, residual sums, scale, guards, cost-trace parts, certificate state
 constexpr size_t mfma4_lds_bytes(int A) {
-  return ((size_t)MFMA4_WAVES * A * 2 * 64 + MFMA4_WAVES * 2 * 64) * sizeof(u4) +
+  return ((size_t)MFMA4_WAVES * A * 2 * 64 + MFMA4_WAVES * 2 * 2 * 64) * sizeof(u4) +
          ((size_t)MFMA4_WAVES * 2 * 256 + MFMA4_WAVES * 2 * 64) * sizeof(double) +
-         (size_t)MFMA4_WAVES * (64 + 2 * 256 + 64 + 2 * 64 + 3 * 64) * sizeof(float) + (size_t)7 * 256 * sizeof(float);
+         (size_t)MFMA4_WAVES * (96 + 2 * 256 + 64 + 2 * 64 + 3 * 64) * sizeof(float) + (size_t)7 * 256 * sizeof(float);
 }
 
 // One wave's share, KW = wave index.  HAS_L / HAS_R: there is a wave to the left / right; LASTW: the wave holding the end
 // of the series (any of its blocks may be padding).  (Four bodies per kernel: with the index at run time the two middle
 // waves could share one, at the price of a dozen address registers -- and of scratch, at ten blocks per wave.)
-template <int NBW, int KW, bool TAPS_DEV, bool WITH_J = false, bool CERT = false, bool LOOPS = false>
+template <int NBW, int KW, bool TAPS_DEV, bool WITH_J = false, bool CERT = false, bool LOOPS = false, int NT = 2>
 __device__ __forceinline__ void mfma4_role(const FistaArgs& a, const MfmaTaps& tp, char* smem) {
   constexpr int k = KW;
   constexpr bool HAS_L = KW > 0, HAS_R = KW < MFMA4_WAVES - 1, LASTW = KW == MFMA4_WAVES - 1;
   static_assert(!CERT || (WITH_J && !TAPS_DEV), "the certificate runs in the rotated (cost trace) loop");
   static_assert(!LOOPS || (!WITH_J && !TAPS_DEV && !CERT), "the _loops_deconv rule rides the plain variant");
-  static_assert(NBW >= 2 && NBW <= 10, "two blocks at least per wave, ten at most");
+  static_assert(NT == 2 || NT == 3, "two near tiles (K <= 33) or three (K <= 65)");
+  static_assert(NT == 2 || (!TAPS_DEV && !CERT && !LOOPS), "three near tiles: plain solves and the cost trace");
+  static_assert(NBW > NT && NBW <= 10, "more blocks per wave than near tiles (a tile reaches the neighbour only), ten at most");
   constexpr int NW = MFMA4_WAVES;
-  constexpr int NT = 2, LCW = 64;
+  constexpr int LCW = 32 * NT, LCS = 96;             // cumulative taps kept: lags 0 .. 32 NT - 1 (LCS: a wave's slice of the area)
+  constexpr int NX = NT - 1;                       // blocks of a neighbour the near tiles reach into
   constexpr int NBT = NW * NBW;
   const int qoff = k * NBW;                        // this wave's first block within the series
   // (the lane from the exec mask, not from threadIdx: nothing of the kernel's entry state stays live across the roles)
@@ -59,19 +62,19 @@ __device__ __forceinline__ void mfma4_role(const FistaArgs& a, const MfmaTaps& t
   u4* const lbase = reinterpret_cast<u4*>(smem);
   u4* const lrf = lbase + k * (NBW * 2 * 64) + lane;               // this wave's residual fragments
   u4* const lrf_next = lbase + (k + 1) * (NBW * 2 * 64) + lane;    // the right neighbour's (its block 0)
-  u4* const xwb = lbase + NW * (NBW * 2 * 64) + lane;              // [NW][2][64]: fragment (hi, lo) of wave j's last block
+  u4* const xwb = lbase + NW * (NBW * 2 * 64) + lane;              // [NW][2][2][64]: fragments (hi, lo) of wave j's last block and (three near tiles) the one before
   // The sums cross the cuts as the four LANE PARTS of each problem (slot 4 v + g), added up by the wave that reads them: a
   // lane-crossing sum at the end of a pass is two dependent ds_bpermute round trips with nothing to overlap them; at the
   // start of the next pass the reads hide behind the float16 split of the first block (fista_mfma2.h).
-  double* const xsp = reinterpret_cast<double*>(lbase + NW * (NBW * 2 * 64) + NW * 2 * 64);        // [NW][2][16][4]: E_j, T_j lane parts
+  double* const xsp = reinterpret_cast<double*>(lbase + NW * (NBW * 2 * 64) + NW * 2 * 2 * 64);    // [NW][2][16][4]: E_j, T_j lane parts
   double* const xl = xsp + NW * 2 * 256 + lane;                    // [NW][2][64]: _loops_deconv rule, each wave's ||d||^2, ||w'||^2
   float* const fbase = reinterpret_cast<float*>(xsp + NW * 2 * 256 + NW * 2 * 64);
-  float* const lc = fbase + k * LCW;                               // [NW][64] cumulative taps, one copy per wave
-  float* const xrp = fbase + NW * LCW;                             // [NW][2][16][4]: RE_j, RT_j lane parts
-  float* const xm = fbase + NW * LCW + NW * 512 + lane;            // [NW][64] max |y| of each share
-  float* const xg = fbase + NW * LCW + NW * 576 + lane;            // [NW][2][64] guard, largest |w| of each share
-  float* const xj = fbase + NW * LCW + NW * 704 + lane;            // [NW][3][64] cost-trace parts: ||r||^2, ||w||_1, certificate
-  float* const lt = fbase + NW * LCW + NW * 896 + 64 * k + lane;   // [7][256] certificate state of every lane (fista_mfma.h)
+  float* const lc = fbase + k * LCS;                               // [NW][96] cumulative taps, one copy per wave
+  float* const xrp = fbase + NW * LCS;                             // [NW][2][16][4]: RE_j, RT_j lane parts
+  float* const xm = fbase + NW * LCS + NW * 512 + lane;            // [NW][64] max |y| of each share
+  float* const xg = fbase + NW * LCS + NW * 576 + lane;            // [NW][2][64] guard, largest |w| of each share
+  float* const xj = fbase + NW * LCS + NW * 704 + lane;            // [NW][3][64] cost-trace parts: ||r||^2, ||w||_1, certificate
+  float* const lt = fbase + NW * LCS + NW * 896 + 64 * k + lane;   // [7][256] certificate state of every lane (fista_mfma.h)
   if constexpr (CERT) {
 #pragma unroll
     for (int q = 0; q < 7; ++q) lt[q * 256] = 0.0f;
@@ -105,6 +108,9 @@ __device__ __forceinline__ void mfma4_role(const FistaArgs& a, const MfmaTaps& t
     step = a.step_vec[0];
   } else {
     lc[lane] = tp.c[lane];
+    if constexpr (NT == 3) {
+      if (lane < 32) lc[64 + lane] = tp.c[64 + lane];
+    }
   }
   wave_sync();
 
@@ -237,16 +243,17 @@ __device__ __forceinline__ void mfma4_role(const FistaArgs& a, const MfmaTaps& t
            : part == 1 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(A.hi, B.lo, acc, 0, 0, 0)
                        : __builtin_amdgcn_mfma_f32_16x16x32_f16(A.lo, B.hi, acc, 0, 0, 0);
   };
-  // what the right neighbour needs of the current iterate -- the fragment of this wave's last block ...
-  auto publish_last_block = [&]() {
-    float x[8];
+  // what the right neighbour needs of the current iterate -- the fragments of this wave's last NX blocks (x = 0: the last) ...
+  auto publish_block = [&](auto xc_) {
+    constexpr int x = decltype(xc_)::value;
+    float xv[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = (float)w[NBW - 1][j];
-    const Frag f = split8(x);
-    xwb[(2 * k) * 64] = __builtin_bit_cast(u4, f.hi);
-    xwb[(2 * k + 1) * 64] = __builtin_bit_cast(u4, f.lo);
+    for (int j = 0; j < 8; ++j) xv[j] = (float)w[NBW - 1 - x][j];
+    const Frag f = split8(xv);
+    xwb[((2 * k + x) * 2) * 64] = __builtin_bit_cast(u4, f.hi);
+    xwb[((2 * k + x) * 2 + 1) * 64] = __builtin_bit_cast(u4, f.lo);
   };
-  // ... and the float64 sums of this wave's blocks without / with the last one (this lane's samples -> the problem's four lanes)
+  // ... and the float64 sums of this wave's blocks without / with the last NX ones (lane parts)
   auto publish_sums = [&](double se, double sl) {
     xsp[(2 * k) * 256 + 4 * v + g] = se;
     xsp[(2 * k + 1) * 256 + 4 * v + g] = se + sl;
@@ -255,7 +262,7 @@ __device__ __forceinline__ void mfma4_role(const FistaArgs& a, const MfmaTaps& t
   // ---- forward: r = T_c w - y over this wave's blocks (ascending) ---------------------------------------------------
   auto forward = [&]() __attribute__((always_inline)) {
     f4 carry = f4{0.f, 0.f, 0.f, 0.f};
-    Frag wfX;                                      // the left neighbour's last block
+    Frag wfX[NX];                                  // the left neighbour's last NX blocks ([0]: the last)
     f2v rs2 = f2v{0.f, 0.f}, rs0 = f2v{0.f, 0.f};  // sums of the residual samples of blocks 1 .. / of block 0
     if constexpr (HAS_L) {
       // E_{k-1} + T_{k-2} + ... + T_0 (every lane of a problem adds the same parts in the same order)
@@ -268,8 +275,11 @@ __device__ __forceinline__ void mfma4_role(const FistaArgs& a, const MfmaTaps& t
       }
       const float c = (float)(s * (double)s_far);
       carry = f4{c, c, c, c};
-      wfX.hi = __builtin_bit_cast(h8, xwb[(2 * (k - 1)) * 64]);
-      wfX.lo = __builtin_bit_cast(h8, xwb[(2 * (k - 1) + 1) * 64]);
+#pragma unroll
+      for (int x = 0; x < NX; ++x) {
+        wfX[x].hi = __builtin_bit_cast(h8, xwb[((2 * (k - 1) + x) * 2) * 64]);
+        wfX[x].lo = __builtin_bit_cast(h8, xwb[((2 * (k - 1) + x) * 2 + 1) * 64]);
+      }
     }
     Frag wf[NBW + 1];
     f4 acc[NBW + 1][2];
@@ -307,7 +317,7 @@ __device__ __forceinline__ void mfma4_role(const FistaArgs& a, const MfmaTaps& t
         x1 = (32 * q + 2 * pp + 1 < nr) ? x1 : 0.0f;
       }
       if constexpr (HAS_L) {
-        if constexpr (q >= 1) rs2 += f2v{x0, x1};
+        if constexpr (q >= NX) rs2 += f2v{x0, x1};     // (the neighbour's near tiles reach this wave's first NX blocks)
         else rs0 += f2v{x0, x1};
       }
       if constexpr (WITH_J) jsq = fmaf(x1, x1, fmaf(x0, x0, jsq));
@@ -328,19 +338,20 @@ __device__ __forceinline__ void mfma4_role(const FistaArgs& a, const MfmaTaps& t
         if constexpr (sl < 3) {                      // carry of block q+1: + S (sum of block q+1-NT)
           if constexpr (q + 1 < NBW) {
             if constexpr (q >= NT - 1) cn = mfma_part(Ff, wf[q >= NT - 1 ? q - (NT - 1) : 0], cn, sl);
-            else if constexpr (HAS_L) cn = mfma_part(Ff, wfX, cn, sl);      // (q = 0: the left neighbour's last block)
+            else if constexpr (HAS_L) cn = mfma_part(Ff, wfX[q < NT - 1 ? NT - 2 - q : 0], cn, sl);   // (block q+1-NT < 0: the left neighbour's)
           }
         } else {
           constexpr int c = sl - 3, r = c & 1, kk = c >> 1, o = kk / 3;        // near tile o: block q-o
           if constexpr (q >= o) acc[q][r] = mfma_part(An[r][o], wf[q >= o ? q - o : 0], acc[q][r], kk - 3 * o);
-          else if constexpr (HAS_L) acc[q][r] = mfma_part(An[r][o], wfX, acc[q][r], kk - 3 * o);
+          else if constexpr (HAS_L) acc[q][r] = mfma_part(An[r][o], wfX[q < o ? o - q - 1 : 0], acc[q][r], kk - 3 * o);
         }
         if constexpr (sl < 4) {
-          if constexpr (HAS_R && q + 1 == NBW - 1 && !WITH_J) {       // this wave's last block: split when it was updated
-            // (with the cost trace its samples are converted again: ||w||_1 needs them)
+          if constexpr (HAS_R && q + 1 >= NBW - NX && !WITH_J) {      // this wave's last NX blocks: split when they were updated
+            // (with the cost trace their samples are converted again: ||w||_1 needs them)
             if constexpr (sl == 0) {
-              wf[q + 1].hi = __builtin_bit_cast(h8, xwb[(2 * k) * 64]);
-              wf[q + 1].lo = __builtin_bit_cast(h8, xwb[(2 * k + 1) * 64]);
+              constexpr int x = NBW - 1 - (q + 1);
+              wf[q + 1].hi = __builtin_bit_cast(h8, xwb[((2 * k + x) * 2) * 64]);
+              wf[q + 1].lo = __builtin_bit_cast(h8, xwb[((2 * k + x) * 2 + 1) * 64]);
             }
           } else if constexpr (q + 1 < NBW) prep_pair(std::integral_constant<int, q + 1>{}, sc);
         } else if constexpr (sl < 8) {
@@ -363,7 +374,7 @@ __device__ __forceinline__ void mfma4_role(const FistaArgs& a, const MfmaTaps& t
   auto backward = [&](const double beta) __attribute__((always_inline)) {
     const double nb1 = -(1.0 + beta);
     f4 carry = f4{0.f, 0.f, 0.f, 0.f};
-    Frag rfX;                                      // the right neighbour's first block
+    Frag rfX[NX];                                  // the right neighbour's first NX blocks
     double sum0 = 0.0, sum1 = 0.0, suml = 0.0;     // sums of the updated iterate over blocks 0 .. NBW-2 / over block NBW-1
     if constexpr (HAS_R) {
       const float* pe = xrp + (2 * (k + 1)) * 256 + 4 * v;          // S (RE_{k+1} + RT_{k+2} + ...)
@@ -375,8 +386,11 @@ __device__ __forceinline__ void mfma4_role(const FistaArgs& a, const MfmaTaps& t
       }
       c *= s_far;
       carry = f4{c, c, c, c};
-      rfX.hi = __builtin_bit_cast(h8, lrf_next[0]);
-      rfX.lo = __builtin_bit_cast(h8, lrf_next[64]);
+#pragma unroll
+      for (int x = 0; x < NX; ++x) {
+        rfX[x].hi = __builtin_bit_cast(h8, lrf_next[(2 * x) * 64]);
+        rfX[x].lo = __builtin_bit_cast(h8, lrf_next[(2 * x + 1) * 64]);
+      }
     }
     f4 acc[NBW + 1][2];
     Frag rf[NBW + 2];
@@ -396,7 +410,7 @@ __device__ __forceinline__ void mfma4_role(const FistaArgs& a, const MfmaTaps& t
         else { ldsq1 = fma(d, d, ldsq1); lwsq1 = fma(w[q][j], w[q][j], lwsq1); }
       }
       if constexpr (HAS_R) {
-        if constexpr (q == NBW - 1) suml += w[q][j];
+        if constexpr (q >= NBW - NX) suml += w[q][j];
         else if constexpr ((j & 1) == 0) sum0 += w[q][j];
         else sum1 += w[q][j];
       }
@@ -415,20 +429,21 @@ __device__ __forceinline__ void mfma4_role(const FistaArgs& a, const MfmaTaps& t
         if constexpr (sl < 3) {                      // carry of block q-1: + S (sum of block q-1+NT)
           if constexpr (q >= 1) {
             if constexpr (q - 1 + NT < NBW) cn = mfma_part(Ff, rf[q - 1 + NT < NBW ? q - 1 + NT : 0], cn, sl);
-            else if constexpr (HAS_R && q - 1 + NT == NBW) cn = mfma_part(Ff, rfX, cn, sl);
+            else if constexpr (HAS_R) cn = mfma_part(Ff, rfX[q - 1 + NT >= NBW ? q - 1 + NT - NBW : 0], cn, sl);
           }
         } else {
           constexpr int c = sl - 3, r = c & 1, kk = c >> 1, o = kk / 3;        // near tile o: block q+o
           if constexpr (kk == 0) acc[q][r] = mfma_part(Bn[r][0], rf[q], carry, 0);
           else if constexpr (q + o < NBW) acc[q][r] = mfma_part(Bn[r][o], rf[q + o < NBW ? q + o : 0], acc[q][r], kk - 3 * o);
-          else if constexpr (HAS_R && q + o == NBW) acc[q][r] = mfma_part(Bn[r][o], rfX, acc[q][r], kk - 3 * o);
+          else if constexpr (HAS_R) acc[q][r] = mfma_part(Bn[r][o], rfX[q + o >= NBW ? q + o - NBW : 0], acc[q][r], kk - 3 * o);
         }
         if constexpr ((sl & 1) == 0 && sl < 16 && q + 1 < NBW)
           update(std::integral_constant<int, q + 1>{}, std::integral_constant<int, sl / 2>{});
       });
       carry = cn;
-      // this wave's last block is complete once the block before it has run: its fragment goes out at once
-      if constexpr (HAS_R && q == NBW - 2) publish_last_block();
+      // a block is complete once the block before it has run: the fragments the neighbour needs go out at once
+      if constexpr (HAS_R && q == NBW - 2) publish_block(std::integral_constant<int, 0>{});
+      if constexpr (HAS_R && NX == 2 && q == NBW - 3) publish_block(std::integral_constant<int, 1>{});
     });
     static_for<0, 8>([&](auto jc) { update(std::integral_constant<int, 0>{}, jc); });
     if constexpr (HAS_R) publish_sums(sum0 + sum1, suml);
@@ -470,13 +485,14 @@ __device__ __forceinline__ void mfma4_role(const FistaArgs& a, const MfmaTaps& t
 
   // ---- iterations: both passes in all waves at once, one barrier per phase boundary -----------------------------------
   if constexpr (HAS_R) {                           // the start iterate's contribution to the waves on the right
-    publish_last_block();
+    publish_block(std::integral_constant<int, 0>{});
+    if constexpr (NX == 2) publish_block(std::integral_constant<int, 1>{});
     double se = 0.0, sl = 0.0;
 #pragma unroll
     for (int q = 0; q < NBW; ++q)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        if (q == NBW - 1) sl += w[q][j];
+        if (q >= NBW - NX) sl += w[q][j];
         else se += w[q][j];
       }
     publish_sums(se, sl);
@@ -622,29 +638,31 @@ __device__ __forceinline__ void mfma4_role(const FistaArgs& a, const MfmaTaps& t
 }
 
 // one workgroup = four waves = 16 problems; the wave index picks the share (scalar branches: each wave runs one role)
-template <int A, bool TAPS_DEV = false, bool WITH_J = false, bool CERT = false, bool LOOPS = false>
+template <int A, bool TAPS_DEV = false, bool WITH_J = false, bool CERT = false, bool LOOPS = false, int NT = 2>
 __global__ __launch_bounds__(256) void fista_mfma4_kernel(FistaArgs a, MfmaTaps tp) {
   extern __shared__ __attribute__((aligned(16))) char mf4_smem[];
   if (a.range) {                                   // a candidate launch of a device-side plan: workgroups beyond its slots leave
     if ((int)blockIdx.x * 16 + a.range[0] >= a.range[1]) return;      // (all waves: before any barrier)
   }
   const int k = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  if (k == 0) mfma4_role<A, 0, TAPS_DEV, WITH_J, CERT, LOOPS>(a, tp, mf4_smem);
-  else if (k == 1) mfma4_role<A, 1, TAPS_DEV, WITH_J, CERT, LOOPS>(a, tp, mf4_smem);
-  else if (k == 2) mfma4_role<A, 2, TAPS_DEV, WITH_J, CERT, LOOPS>(a, tp, mf4_smem);
-  else mfma4_role<A, 3, TAPS_DEV, WITH_J, CERT, LOOPS>(a, tp, mf4_smem);
+  if (k == 0) mfma4_role<A, 0, TAPS_DEV, WITH_J, CERT, LOOPS, NT>(a, tp, mf4_smem);
+  else if (k == 1) mfma4_role<A, 1, TAPS_DEV, WITH_J, CERT, LOOPS, NT>(a, tp, mf4_smem);
+  else if (k == 2) mfma4_role<A, 2, TAPS_DEV, WITH_J, CERT, LOOPS, NT>(a, tp, mf4_smem);
+  else mfma4_role<A, 3, TAPS_DEV, WITH_J, CERT, LOOPS, NT>(a, tp, mf4_smem);
 }
 
 // Plain solves, with or without the cost trace, the window rule (wind = 6) as a no-fire certificate, the _loops_deconv rule
-// in full (no cost trace); HRFs of up to 33 taps; 128 (A - 1) < N <= 128 A: the series ends in one of the last wave's last four blocks.  Shared HRF in device memory
+// in full (no cost trace); HRFs of up to 33 taps -- 34 .. 65 with three near tiles: plain solves and the cost trace --; 128 (A - 1) < N <= 128 A: the series ends in one of the last wave's last four blocks.  Shared HRF in device memory
 // (the blind step's z-step): plain only.
 template <int A>
 int launch_mfma4(const FistaArgs& a, const double* taps, int K, bool with_j, hipStream_t st) {
-  if (a.N > 128 * A || a.N <= 128 * (A - 1) || K < 1 || K > 33) return 1;
+  if (a.N > 128 * A || a.N <= 128 * (A - 1) || K < 1 || K > 65) return 1;
+  const bool three = K > 33;                       // three near tiles: plain solves and the cost trace only
   const bool cert = a.stop_mode == PB_STOP_WINDOW, loops = a.stop_mode == PB_STOP_LOOPS;
   if (!a.n_done) return 1;
   if ((with_j || cert || loops) && a.taps_pp) return 1;
   if (loops && with_j) return 1;                   // (the _loops_deconv rule: plain variant, as on the one-wave form)
+  if (three && (cert || loops || a.taps_pp)) return 1;
   const int64_t groups = (launch_count(a) + 15) / 16;
   const dim3 grid((unsigned)groups), block(256);
   const size_t lds = mfma4_lds_bytes(A);
@@ -653,7 +671,8 @@ int launch_mfma4(const FistaArgs& a, const double* taps, int K, bool with_j, hip
     if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kernel, grid, block, lds, st, a, a.taps_pp ? MfmaTaps{} : make_mfma_taps(taps, K));
   };
-  if (a.taps_pp) go(fista_mfma4_kernel<A, true>);
+  if (three) go(with_j ? fista_mfma4_kernel<A, false, true, false, false, 3> : fista_mfma4_kernel<A, false, false, false, false, 3>);
+  else if (a.taps_pp) go(fista_mfma4_kernel<A, true>);
   else if (loops) go(fista_mfma4_kernel<A, false, false, false, true>);
   else if (cert) go(fista_mfma4_kernel<A, false, true, true>);
   else if (with_j) go(fista_mfma4_kernel<A, false, true, false>);

@@ -420,12 +420,15 @@ def test_ill_conditioned_series_are_solved_in_float64(solver, golden):
 # --------------------------------------------------------------------------------------------
 # Round 5: series of 641 .. 1 280 scans on the matrix pipe (fista_mfma4.h: one series over the four waves of a workgroup)
 @pytest.mark.parametrize("n,k", [(641, 30), (700, 27), (768, 33), (769, 16), (900, 30), (1000, 2), (1024, 30), (1025, 30),
-                                 (1200, 28), (1216, 33), (1217, 30), (1279, 30), (1280, 32)])
+                                 (1200, 28), (1216, 33), (1217, 30), (1279, 30), (1280, 32),
+                                 (700, 34), (900, 40), (1200, 42), (1216, 48), (641, 48)])
 def test_four_wave_matrix_pipe_form_matches_oracle(solver, n, k):
     """`fista_mfma4_kernel`: 16 problems per workgroup of four waves, wave j owning blocks j A .. j A + A - 1 of 32 samples
     (A = ceil(N / 128): 6 .. 10; the last wave holds the end of the series and the padding behind it) -- HCP-length
     runs (examples/icassp_2019/validation.py:41-48).  Warm and cold start against the C float64 oracle, nothing handed
-    back on ordinary data, any batch position the same bits; the cost trace; the window rule as a certificate."""
+    back on ordinary data, any batch position the same bits; the cost trace; the window rule as a certificate.  HRFs of
+    34 .. 48 taps (short TR): three near tiles -- the tiles reach TWO blocks into the neighbouring wave --, plain solves
+    and the cost trace."""
     from oracle import c_oracle
     rng = np.random.RandomState(n + k)
     hrf = orc.spm_hrf(1.0, 1.0, float(k), False)[0][:k] if k >= 20 else (np.hanning(k + 2)[1:-1] * 0.3 if k > 2 else np.array([0.0, 0.7])[:k])
@@ -450,7 +453,7 @@ def test_four_wave_matrix_pipe_form_matches_oracle(solver, n, k):
     W2, _, _ = solver.fista_solve(Yd[perm].contiguous(), hrf, 0.3, 1.0 / lip, 200, W0=W0d[perm].contiguous(), force="mfma2only")
     assert torch.equal(W2, W[perm])
     # the window rule (far from firing) as a certificate: cleared everywhere; a tolerance it fires at: handed back, re-solved
-    if n <= 1216:
+    if n <= 1216 and k <= 33:
         Wk, Jk, ndk = solver.fista_solve(Yd, hrf, 0.3, 1.0 / lip, 200, force="mfma2certonly", want_J=True, stop="window", tol=1e-9, wind=6)
         assert int(ndk.min()) == 200 and torch.equal(Wk, Wc)
         # (the exact rule on the one-problem-per-wave form: tests/test_gpu_parity.py pins that one to the reference's stops)
