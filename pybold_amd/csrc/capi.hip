@@ -99,14 +99,17 @@ namespace {
 // (129 .. 640 scans), floor(nb / 2) of them in the left wave; K <= 33; plain solves, the cost
 // trace and the window rule (wind = 6) as a no-fire certificate; the shared-HRF z-step plain only
 typedef int (*mfma2_launch_fn)(const pb::FistaArgs&, const double*, int, bool, hipStream_t);
-mfma2_launch_fn pick_mfma2(int N, int K) {
+// (34 <= K <= 65: three near tiles -- series of 311+ scans only (shorter ones: the one-wave form), plain solves and the cost
+// trace only: `extras` = certificate / _loops_deconv rule / taps from device memory wanted)
+mfma2_launch_fn pick_mfma2(int N, int K, bool extras = true) {
   static const mfma2_launch_fn tab[] = {
       &pb::launch_mfma2<2, 3>, &pb::launch_mfma2<3, 3>, &pb::launch_mfma2<3, 4>, &pb::launch_mfma2<4, 4>,
       &pb::launch_mfma2<4, 5>, &pb::launch_mfma2<5, 5>, &pb::launch_mfma2<5, 6>, &pb::launch_mfma2<6, 6>,
       &pb::launch_mfma2<6, 7>, &pb::launch_mfma2<7, 7>, &pb::launch_mfma2<7, 8>, &pb::launch_mfma2<8, 8>,
       &pb::launch_mfma2<8, 9>, &pb::launch_mfma2<9, 9>, &pb::launch_mfma2<9, 10>, &pb::launch_mfma2<10, 10>};
   const int nb = (N + 31) / 32;
-  if (K < 1 || K > 33 || nb < 5 || nb > 20) return nullptr;
+  if (K < 1 || K > 65 || nb < 5 || nb > 20) return nullptr;
+  if (K > 33 && (extras || N <= 310)) return nullptr;
   return tab[nb - 5];
 }
 // the same with one series split over the FOUR waves of a workgroup (fista_mfma4.h): 641 .. 1 280 scans, A = ceil(N / 128)
@@ -345,7 +348,7 @@ inline int beside_chunks_for(int N) { return N > 9 * pb::MFMA_SPAN ? MFMA2_BESID
 // 1.58 ms against 1.93, 8 192 2.87 against 1.97 -- profiles/r4_split_form_passes.txt); whole passes of 8 192
 // problems, a remainder above 5/16 of a pass too, a smaller one on the one-problem-per-wave form.
 constexpr int MFMA2_LONG_MIN_P = 5120;
-bool mfma2_serves_long(int N, int K) { return N > MFMA1_NMAX && pick_mfma2(N, K) != nullptr && pick_wide(N, K) != nullptr; }
+bool mfma2_serves_long(int N, int K, bool extras = true) { return N > MFMA1_NMAX && pick_mfma2(N, K, extras) != nullptr && pick_wide(N, K) != nullptr; }
 int mfma2_long_base(int P, bool one_launch) {
   const int pass = (int)wave_slots() * 4;            // 16 problems x (slots / 2 SIMDs / 2 waves)
   const int base = (P / pass) * pass;
@@ -580,7 +583,7 @@ int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mod
   const bool mfma2_ok = (stop_mode == PB_STOP_NONE || (stop_mode == PB_STOP_WINDOW && wind == 6)) && pick_mfma2(N, K) != nullptr;
   if (split_shape && mfma4_serves(N, K, stop_mode != PB_STOP_NONE) && (stop_mode != PB_STOP_WINDOW || pick_wide(N, K)->S <= 20))
     return mfma4_base(P, false) > 0 ? pb::FORM_MFMA4 : FORM_WIDE;
-  if (split_shape && pick_mfma2(N, K) && mfma2_serves_long(N, K) && P >= MFMA2_LONG_MIN_P && (stop_mode != PB_STOP_WINDOW || pick_wide(N, K)->S <= 20))
+  if (split_shape && mfma2_serves_long(N, K, stop_mode != PB_STOP_NONE) && P >= MFMA2_LONG_MIN_P && (stop_mode != PB_STOP_WINDOW || pick_wide(N, K)->S <= 20))
     return mfma2_long_base(P, false) > 0 ? FORM_MFMA2 : ((pick_fast(N, K) && N <= 320) ? FORM_FAST1 : FORM_WIDE);   // (the solve's own backup form)
   if (const FastEntry* se = pick_split(N, K))
     if (!mfma_plain && P >= SPLIT_MIN_P && pair_carries(se, stop_mode, wind) && (stop_mode == PB_STOP_NONE || pick_wide(N, K)))
@@ -623,7 +626,7 @@ int pb_fista_plan_ex(int N, int K, int P, int stop_mode, int wind, unsigned flag
     const int base = mfma4_base(P, (flags & (PB_FLAG_ONE_LAUNCH | PB_FLAG_FORCE_MFMA2)) != 0);
     if (base > 0 && base < P) { nm = base; mf = pb::FORM_MFMA4; tf = FORM_WIDE; }
     else tf = base > 0 ? pb::FORM_MFMA4 : FORM_WIDE;
-  } else if (N >= 1 && K >= 1 && split_shape && !no_mfma && pick_mfma2(N, K) && mfma2_serves_long(N, K) && (P >= MFMA2_LONG_MIN_P || (flags & PB_FLAG_FORCE_MFMA2)) &&
+  } else if (N >= 1 && K >= 1 && split_shape && !no_mfma && mfma2_serves_long(N, K, stop_mode != PB_STOP_NONE) && (P >= MFMA2_LONG_MIN_P || (flags & PB_FLAG_FORCE_MFMA2)) &&
       (stop_mode != PB_STOP_WINDOW || pick_wide(N, K)->S <= 20)) {
     const int base = mfma2_long_base(P, (flags & (PB_FLAG_ONE_LAUNCH | PB_FLAG_FORCE_MFMA2)) != 0);
     const int backup_form = (pick_fast(N, K) && N <= 320) ? FORM_FAST1 : FORM_WIDE;      // what pb_fista_solve uses behind the split form
@@ -881,7 +884,7 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
   const mfma2_launch_fn mfma2 =
       ((stop_mode == PB_STOP_NONE || mfma2_cert || split_loops) && n_done_dev && (!lbda_dev || (flags & (PB_FLAG_FORCE_MFMA | PB_FLAG_FORCE_MFMA2))) &&
        !(flags & (PB_FLAG_FORCE_GENERIC | PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_FORCE_WIDE | PB_FLAG_DIRECT_FIR |
-                  PB_FLAG_NO_MFMA))) ? pick_mfma2(N, K) : nullptr;
+                  PB_FLAG_NO_MFMA))) ? pick_mfma2(N, K, stop_mode != PB_STOP_NONE) : nullptr;
   // (round 5) the same call shapes at 311..640 scans, partitioned on the device: dense class on whole passes of the split
   // form, sparse class on the pair form over two slots (or the backup form), handed-back problems compacted
   {
@@ -889,8 +892,8 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
     const bool shape_ok = (stop_mode == PB_STOP_NONE || mfma2_cert || split_loops) && n_done_dev &&
                           !(flags & (PB_FLAG_FORCE_GENERIC | PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_FORCE_WIDE | PB_FLAG_DIRECT_FIR | PB_FLAG_NO_MFMA));
     const mfma2_launch_fn mfma2_l = four ? ((shape_ok && mfma4_serves(N, K, stop_mode != PB_STOP_NONE)) ? pick_mfma4(N, K, stop_mode != PB_STOP_NONE) : nullptr)
-                                         : ((mfma2 || !lbda_dev || !(stop_mode == PB_STOP_NONE || mfma2_cert || split_loops)) ? mfma2 : pick_mfma2(N, K));
-    if (mfma2_l && part_ws && (four || (mfma2_serves_long(N, K) && P >= MFMA2_LONG_MIN_P))) {
+                                         : ((mfma2 || !lbda_dev || !(stop_mode == PB_STOP_NONE || mfma2_cert || split_loops)) ? mfma2 : pick_mfma2(N, K, stop_mode != PB_STOP_NONE));
+    if (mfma2_l && part_ws && (four || (mfma2_serves_long(N, K, stop_mode != PB_STOP_NONE) && P >= MFMA2_LONG_MIN_P))) {
       const FastEntry* fe1 = pick_fast(N, K);
       const WideEntry* we1 = pick_wide(N, K);
       const bool use_wide = we1 && (!fe1 || N > 320);
@@ -962,7 +965,7 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
       return PB_OK;
     }
   }
-  if (mfma2 && ((flags & PB_FLAG_FORCE_MFMA2) || (mfma2_serves_long(N, K) && P >= MFMA2_LONG_MIN_P))) {
+  if (mfma2 && ((flags & PB_FLAG_FORCE_MFMA2) || (mfma2_serves_long(N, K, stop_mode != PB_STOP_NONE) && P >= MFMA2_LONG_MIN_P))) {
     const FastEntry* fe1 = pick_fast(N, K);
     const WideEntry* we1 = pick_wide(N, K);
     const bool use_wide = we1 && (!fe1 || N > 320);
@@ -1667,6 +1670,42 @@ int pb_fista_solve_pp(const float* y_dev, int64_t ldy, double* w_dev, int64_t ld
   a.cold = (flags & PB_FLAG_COLD_START) ? 1 : 0;
   a.rho_guard = (flags & PB_FLAG_NO_RHO_GUARD) ? 0 : 1;
 
+  // ONE shared HRF, no stop rule, series of 311 .. 1 280 scans (round 5): whole passes on the matrix-pipe form split over two
+  // (up to 640 scans) or four waves, which read the HRF and its step from device memory; the rest, and what the guards hand
+  // back, on the one-problem-per-wave form
+  if (N > MFMA1_NMAX && ldt == 0 && stop_mode == PB_STOP_NONE && n_done_dev && K <= MFMA_K2 &&
+      !(flags & (PB_FLAG_FORCE_GENERIC | PB_FLAG_FORCE_PAIR | PB_FLAG_NO_PAIR | PB_FLAG_NO_MFMA | PB_FLAG_FORCE_WIDE | PB_FLAG_DIRECT_FIR))) {
+    const bool four = N > 640;
+    const mfma2_launch_fn split = four ? pick_mfma4(N, K, true) : pick_mfma2(N, K, true);
+    const WideEntry* we = pick_wide(N, K);
+    if (split && we && (four || P >= MFMA2_LONG_MIN_P || (flags & PB_FLAG_FORCE_MFMA2))) {
+      const bool all = (flags & (PB_FLAG_ONE_LAUNCH | PB_FLAG_FORCE_MFMA2)) != 0;
+      const int base = four ? mfma4_base(P, all) : mfma2_long_base(P, all);
+      pb::FistaArgs b = a;
+      if (base > 0) {
+        b.P = base;
+        if (split(b, nullptr, K, false, (hipStream_t)stream) != 0)
+          return fail(PB_ERR_INVALID, "pb_fista_solve_pp: split matrix-pipe kernel rejected the launch");
+        const int rc = check_launch(four ? "fista_mfma4_kernel(shared taps)" : "fista_mfma2_kernel(shared taps)");
+        if (rc != PB_OK) return rc;
+      }
+      if (base < P) {
+        b = a;
+        b.p0 = base;
+        if (we->fn_pp(b, stop_mode, (hipStream_t)stream) != 0) return fail(PB_ERR_INVALID, "pb_fista_solve_pp: launch rejected");
+        const int rc = check_launch("fista_fast_kernel(wide, pp, remainder)");
+        if (rc != PB_OK) return rc;
+      }
+      if (base > 0 && !(flags & PB_FLAG_CERT_NO_RESOLVE)) {
+        b = a;
+        b.P = base;
+        b.only_flagged = 1;
+        if (we->fn_pp(b, stop_mode, (hipStream_t)stream) != 0) return fail(PB_ERR_INVALID, "pb_fista_solve_pp: launch rejected");
+        return check_launch("fista_fast_kernel(wide, pp, re-solve)");
+      }
+      return PB_OK;
+    }
+  }
   const FastEntry* fe = (flags & PB_FLAG_FORCE_GENERIC) ? nullptr : pick_fast(N, K);
   if (fe) {
     // ONE shared HRF, no stop rule: the pair form (taps read from device memory) wherever the

@@ -33,7 +33,7 @@ namespace pb {
 constexpr size_t mfma2_lds_bytes(int nbm) {
   return ((size_t)2 * nbm * 2 * 64 + 2 * 64) * sizeof(u4) +
          (size_t)(2 * 64 + 64 + 64 + 2 * 64 + 4 * 64 + 6 * 64 + 7 * 128) * sizeof(float) + (size_t)2 * 2 * 64 * sizeof(double) +
-         (size_t)256 * sizeof(double) + (size_t)256 * sizeof(float);
+         (size_t)256 * sizeof(double) + (size_t)256 * sizeof(float) + (size_t)2 * 64 * sizeof(u4) + (size_t)2 * 96 * sizeof(float);
 }
 
 // ROLE 0: the left wave (blocks 0 .. NBA-1), ROLE 1: the right wave (blocks NBA .. NBA+NBB-1; padding in its last block)
@@ -42,13 +42,15 @@ constexpr size_t mfma2_lds_bytes(int nbm) {
 //   tracked samples per WAVE (eight per problem); implies WITH_J; a problem that cannot be cleared is handed back.
 // LOOPS: the _loops_deconv stop rule in full, as on the one-wave form (fista_mfma.h): each wave adds up its half of the two
 //   norms next to the update, the halves meet in LDS at the barrier that ends the iteration; plain variant only.
-template <int NBA, int NBB, bool TAPS_DEV, int ROLE, bool WITH_J = false, bool CERT = false, bool LOOPS = false>
+// NT: near tiles -- 2 (K <= 33), or 3 (K <= 65: the tiles reach TWO blocks across the cut; plain solves and the cost trace).
+template <int NBA, int NBB, bool TAPS_DEV, int ROLE, bool WITH_J = false, bool CERT = false, bool LOOPS = false, int NT = 2>
 __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& tp, char* smem) {
   static_assert(!CERT || (WITH_J && !TAPS_DEV), "the certificate runs in the rotated (cost trace) loop");
   static_assert(!LOOPS || (!WITH_J && !TAPS_DEV && !CERT), "the _loops_deconv rule rides the plain variant");
   static_assert(NBB >= NBA && NBB <= NBA + 1 && NBA >= 2 && NBB <= 10, "right half = the larger one; two blocks at least per wave");
   constexpr int NBM = NBB;                         // blocks of the larger half: the size of a wave's fragment area
-  constexpr int NT = 2, LCW = 64;
+  static_assert(NT == 2 || (NT == 3 && !TAPS_DEV && !CERT && !LOOPS && NBA > 3), "three near tiles: plain solves and the cost trace, four blocks at least per wave");
+  constexpr int LCW = 32 * NT, NX = NT - 1;        // cumulative taps kept: lags 0 .. 32 NT - 1; NX: blocks of the neighbour the near tiles reach into
   constexpr int NBW = ROLE == 0 ? NBA : NBB;       // blocks of this wave
   constexpr int QOFF = ROLE == 0 ? 0 : NBA;        // its first block within the series
   constexpr int NBT = NBA + NBB;
@@ -66,19 +68,21 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
   u4* const lrf_right = lbase + (NBM * 2 * 64) + lane;             // the right wave's (its block 0: what the left wave reads)
   u4* const xw = lbase + 2 * (NBM * 2 * 64) + lane;                // [2][64]: fragment (hi, lo) of the left wave's last block
   float* const fbase = reinterpret_cast<float*>(lbase + 2 * (NBM * 2 * 64) + 2 * 64);
-  float* const lc = fbase + ROLE * LCW;                            // [2][64] cumulative taps, one copy per wave
+  // (areas below are laid out for LCW = 64; with three near tiles the taps live behind everything else, lc3)
   // (fbase + 2 LCW .. + 128: round 4's far-field scalars; since round 5 they cross as lane parts, xcp / xrp below)
-  float* const xm = fbase + 2 * LCW + 128;                         // [2][64] max |y| of each half
-  float* const xg = fbase + 2 * LCW + 256;                         // [2][2][64] guard, largest |w| of each half
-  float* const xj = fbase + 2 * LCW + 512;                         // [2][3][64] cost-trace parts of each half: ||r||^2, ||w||_1, certificate
-  float* const lt = fbase + 2 * LCW + 896 + threadIdx.x;           // [7][128] certificate state of every lane (as fista_mfma.h)
-  double* const xl = reinterpret_cast<double*>(fbase + 2 * LCW + 896 + 7 * 128) + lane;     // [2][2][64] _loops_deconv rule: ||d||^2, ||w'||^2 of each half
+  float* const xm = fbase + 128 + 128;                         // [2][64] max |y| of each half
+  float* const xg = fbase + 128 + 256;                         // [2][2][64] guard, largest |w| of each half
+  float* const xj = fbase + 128 + 512;                         // [2][3][64] cost-trace parts of each half: ||r||^2, ||w||_1, certificate
+  float* const lt = fbase + 128 + 896 + threadIdx.x;           // [7][128] certificate state of every lane (as fista_mfma.h)
+  double* const xl = reinterpret_cast<double*>(fbase + 128 + 896 + 7 * 128) + lane;     // [2][2][64] _loops_deconv rule: ||d||^2, ||w'||^2 of each half
   // The two far-field scalars cross the cut as the four LANE PARTS of each problem (slot 4 v + g), added up by the wave that
   // reads them: a lane-crossing sum at the END of a pass is two dependent ds_bpermute round trips with nothing left to
   // overlap them (round 5: ~250 cycles per pass, 10 % of an iteration of five-block waves); at the START of the next pass the
   // reads hide behind the float16 split of the first block.
-  double* const xcp = reinterpret_cast<double*>(fbase + 2 * LCW + 896 + 7 * 128) + 2 * 2 * 64;   // [16][4] left -> right: sum(w, blocks 0 .. NBA-2), lane parts
+  double* const xcp = reinterpret_cast<double*>(fbase + 128 + 896 + 7 * 128) + 2 * 2 * 64;   // [16][4] left -> right: sum(w, blocks 0 .. NBA-2), lane parts
   float* const xrp = reinterpret_cast<float*>(xcp + 256);                                         // [16][4] right -> left: sum(r, blocks NBA+1 ..), lane parts
+  u4* const xw2 = reinterpret_cast<u4*>(xrp + 256) + lane;                                        // [2][64] three near tiles: the left wave's block before its last
+  float* const lc = NT == 2 ? fbase + ROLE * 64 : reinterpret_cast<float*>(xw2 - lane + 2 * 64) + ROLE * 96;   // cumulative taps, one copy per wave
   if constexpr (CERT) {
 #pragma unroll
     for (int q = 0; q < 7; ++q) lt[q * 128] = 0.0f;
@@ -112,6 +116,9 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
     step = a.step_vec[0];
   } else {
     lc[lane] = tp.c[lane];
+    if constexpr (NT == 3) {
+      if (lane < 32) lc[64 + lane] = tp.c[64 + lane];
+    }
   }
   wave_sync();
 
@@ -242,14 +249,16 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
            : part == 1 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(A.hi, B.lo, acc, 0, 0, 0)
                        : __builtin_amdgcn_mfma_f32_16x16x32_f16(A.lo, B.hi, acc, 0, 0, 0);
   };
-  // left wave: what the right wave needs of the current iterate -- the fragment of the last block ...
-  auto publish_last_block = [&]() {
-    float x[8];
+  // left wave: what the right wave needs of the current iterate -- the fragments of its last NX blocks (x = 0: the last) ...
+  auto publish_block = [&](auto xc_) {
+    constexpr int x = decltype(xc_)::value;
+    float xv[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = (float)w[NBW - 1][j];
-    const Frag f = split8(x);
-    xw[0] = __builtin_bit_cast(u4, f.hi);
-    xw[64] = __builtin_bit_cast(u4, f.lo);
+    for (int j = 0; j < 8; ++j) xv[j] = (float)w[NBW - 1 - x][j];
+    const Frag f = split8(xv);
+    u4* const dst = x == 0 ? xw : xw2;
+    dst[0] = __builtin_bit_cast(u4, f.hi);
+    dst[64] = __builtin_bit_cast(u4, f.lo);
   };
   // ... and the far field of the blocks before it (float64 sum over this lane's samples -> the problem's four lanes)
   auto publish_far_field = [&](double s) { xcp[4 * v + g] = s; };
@@ -257,14 +266,18 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
   // ---- forward: r = T_c w - y over this wave's blocks (ascending) ---------------------------------------------
   auto forward = [&]() __attribute__((always_inline)) {
     f4 carry = f4{0.f, 0.f, 0.f, 0.f};
-    Frag wfX;                                      // right wave: the left wave's last block
+    Frag wfX[NX];                                  // right wave: the left wave's last NX blocks ([0]: the last)
     f2v rs2 = f2v{0.f, 0.f};                       // right wave: sum of the residual samples of its blocks 1 ..
     if constexpr (ROLE == 1) {
       const double* pc = xcp + 4 * v;               // (every lane of a problem adds the same four parts in the same order)
       const float c = (float)(((pc[0] + pc[1]) + (pc[2] + pc[3])) * (double)s_far);
       carry = f4{c, c, c, c};
-      wfX.hi = __builtin_bit_cast(h8, xw[0]);
-      wfX.lo = __builtin_bit_cast(h8, xw[64]);
+      wfX[0].hi = __builtin_bit_cast(h8, xw[0]);
+      wfX[0].lo = __builtin_bit_cast(h8, xw[64]);
+      if constexpr (NX == 2) {
+        wfX[1].hi = __builtin_bit_cast(h8, xw2[0]);
+        wfX[1].lo = __builtin_bit_cast(h8, xw2[64]);
+      }
     }
     Frag wf[NBW + 1];
     f4 acc[NBW + 1][2];
@@ -297,7 +310,7 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
         x0 = (32 * (QOFF + q) + tb + 2 * pp < a.N) ? x0 : 0.0f;
         x1 = (32 * (QOFF + q) + tb + 2 * pp + 1 < a.N) ? x1 : 0.0f;
       }
-      if constexpr (ROLE == 1 && q >= 1) rs2 += f2v{x0, x1};
+      if constexpr (ROLE == 1 && q >= NX) rs2 += f2v{x0, x1};     // (the left wave's near tiles reach this wave's first NX blocks)
       if constexpr (WITH_J) jsq = fmaf(x1, x1, fmaf(x0, x0, jsq));
       split_pair(x0, x1, rh[q][pp], rl[q][pp]);
       if constexpr (pp == 3) {
@@ -316,19 +329,20 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
         if constexpr (sl < 3) {                      // carry of block q+1: + S (sum of block q+1-NT)
           if constexpr (q + 1 < NBW) {
             if constexpr (q >= NT - 1) cn = mfma_part(Ff, wf[q >= NT - 1 ? q - (NT - 1) : 0], cn, sl);
-            else if constexpr (ROLE == 1) cn = mfma_part(Ff, wfX, cn, sl);      // (q = 0: the left wave's last block)
+            else if constexpr (ROLE == 1) cn = mfma_part(Ff, wfX[q < NT - 1 ? NT - 2 - q : 0], cn, sl);   // (block q+1-NT < 0: the left wave's)
           }
         } else {
           constexpr int c = sl - 3, r = c & 1, k = c >> 1, o = k / 3;          // near tile o: block q-o
           if constexpr (q >= o) acc[q][r] = mfma_part(An[r][o], wf[q >= o ? q - o : 0], acc[q][r], k - 3 * o);
-          else if constexpr (ROLE == 1) acc[q][r] = mfma_part(An[r][o], wfX, acc[q][r], k - 3 * o);
+          else if constexpr (ROLE == 1) acc[q][r] = mfma_part(An[r][o], wfX[q < o ? o - q - 1 : 0], acc[q][r], k - 3 * o);
         }
         if constexpr (sl < 4) {
-          if constexpr (ROLE == 0 && q + 1 == NBW - 1 && !WITH_J) {   // the left wave's last block: split when it was updated (xw)
-            // (with the cost trace its samples are converted again: ||w||_1 needs them)
+          if constexpr (ROLE == 0 && q + 1 >= NBW - NX && !WITH_J) {  // the left wave's last NX blocks: split when they were updated (xw)
+            // (with the cost trace their samples are converted again: ||w||_1 needs them)
             if constexpr (sl == 0) {
-              wf[q + 1].hi = __builtin_bit_cast(h8, xw[0]);
-              wf[q + 1].lo = __builtin_bit_cast(h8, xw[64]);
+              const u4* const src = (NBW - 1 - (q + 1)) == 0 ? xw : xw2;
+              wf[q + 1].hi = __builtin_bit_cast(h8, src[0]);
+              wf[q + 1].lo = __builtin_bit_cast(h8, src[64]);
             }
           } else if constexpr (q + 1 < NBW) prep_pair(std::integral_constant<int, q + 1>{}, sc);
         } else if constexpr (sl < 8) {
@@ -349,14 +363,17 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
   auto backward = [&](const double beta) __attribute__((always_inline)) {
     const double nb1 = -(1.0 + beta);
     f4 carry = f4{0.f, 0.f, 0.f, 0.f};
-    Frag rfX;                                      // left wave: the right wave's first block
+    Frag rfX[NX];                                  // left wave: the right wave's first NX blocks
     double sum0 = 0.0, sum1 = 0.0;                 // left wave: sum of the updated iterate over blocks 0 .. NBW-2
     if constexpr (ROLE == 0) {
       const float* pr = xrp + 4 * v;
       const float c = ((pr[0] + pr[1]) + (pr[2] + pr[3])) * s_far;
       carry = f4{c, c, c, c};
-      rfX.hi = __builtin_bit_cast(h8, lrf_right[0]);
-      rfX.lo = __builtin_bit_cast(h8, lrf_right[64]);
+#pragma unroll
+      for (int x = 0; x < NX; ++x) {
+        rfX[x].hi = __builtin_bit_cast(h8, lrf_right[(2 * x) * 64]);
+        rfX[x].lo = __builtin_bit_cast(h8, lrf_right[(2 * x + 1) * 64]);
+      }
     }
     f4 acc[NBW + 1][2];
     Frag rf[NBW + 2];
@@ -375,7 +392,7 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
         if constexpr ((j & 1) == 0) { ldsq0 = fma(d, d, ldsq0); lwsq0 = fma(w[q][j], w[q][j], lwsq0); }
         else { ldsq1 = fma(d, d, ldsq1); lwsq1 = fma(w[q][j], w[q][j], lwsq1); }
       }
-      if constexpr (ROLE == 0 && q <= NBW - 2) {
+      if constexpr (ROLE == 0 && q <= NBW - 1 - NX) {
         if constexpr ((j & 1) == 0) sum0 += w[q][j]; else sum1 += w[q][j];
       }
       if constexpr (CERT && j == 3 && (q == CQ0 || q == CQ1 || q == CQ2 || q == CQ3)) {
@@ -393,20 +410,21 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
         if constexpr (sl < 3) {                      // carry of block q-1: + S (sum of block q-1+NT)
           if constexpr (q >= 1) {
             if constexpr (q - 1 + NT < NBW) cn = mfma_part(Ff, rf[q - 1 + NT < NBW ? q - 1 + NT : 0], cn, sl);
-            else if constexpr (ROLE == 0 && q - 1 + NT == NBW) cn = mfma_part(Ff, rfX, cn, sl);
+            else if constexpr (ROLE == 0) cn = mfma_part(Ff, rfX[q - 1 + NT >= NBW ? q - 1 + NT - NBW : 0], cn, sl);
           }
         } else {
           constexpr int c = sl - 3, r = c & 1, k = c >> 1, o = k / 3;          // near tile o: block q+o
           if constexpr (k == 0) acc[q][r] = mfma_part(Bn[r][0], rf[q], carry, 0);
           else if constexpr (q + o < NBW) acc[q][r] = mfma_part(Bn[r][o], rf[q + o < NBW ? q + o : 0], acc[q][r], k - 3 * o);
-          else if constexpr (ROLE == 0 && q + o == NBW) acc[q][r] = mfma_part(Bn[r][o], rfX, acc[q][r], k - 3 * o);
+          else if constexpr (ROLE == 0) acc[q][r] = mfma_part(Bn[r][o], rfX[q + o >= NBW ? q + o - NBW : 0], acc[q][r], k - 3 * o);
         }
         if constexpr ((sl & 1) == 0 && sl < 16 && q + 1 < NBW)
           update(std::integral_constant<int, q + 1>{}, std::integral_constant<int, sl / 2>{});
       });
       carry = cn;
       // the left wave's last block is complete once the block before it has run: its fragment goes out at once
-      if constexpr (ROLE == 0 && q == NBW - 2) publish_last_block();
+      if constexpr (ROLE == 0 && q == NBW - 2) publish_block(std::integral_constant<int, 0>{});
+      if constexpr (ROLE == 0 && NX == 2 && q == NBW - 3) publish_block(std::integral_constant<int, 1>{});
     });
     static_for<0, 8>([&](auto jc) { update(std::integral_constant<int, 0>{}, jc); });
     if constexpr (ROLE == 0) publish_far_field(sum0 + sum1);
@@ -448,10 +466,11 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
 
   // ---- iterations: both passes in both waves at once, one barrier per phase boundary ----------------------------
   if constexpr (ROLE == 0) {                       // the start iterate's contribution to the right wave's first pass
-    publish_last_block();
+    publish_block(std::integral_constant<int, 0>{});
+    if constexpr (NX == 2) publish_block(std::integral_constant<int, 1>{});
     double s = 0.0;
 #pragma unroll
-    for (int q = 0; q <= NBW - 2; ++q)
+    for (int q = 0; q <= NBW - 1 - NX; ++q)
 #pragma unroll
       for (int j = 0; j < 8; ++j) s += w[q][j];
     publish_far_field(s);
@@ -586,14 +605,14 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
 }
 
 // one workgroup = two waves = 16 problems; the wave index picks the half (a scalar branch: each wave runs one role)
-template <int NBA, int NBB, bool TAPS_DEV = false, bool WITH_J = false, bool CERT = false, bool LOOPS = false>
+template <int NBA, int NBB, bool TAPS_DEV = false, bool WITH_J = false, bool CERT = false, bool LOOPS = false, int NT = 2>
 __global__ __launch_bounds__(128) void fista_mfma2_kernel(FistaArgs a, MfmaTaps tp) {
   extern __shared__ __attribute__((aligned(16))) char mf2_smem[];
   if (a.range) {                                   // a candidate launch of a device-side plan: workgroups beyond its slots leave
     if ((int)blockIdx.x * 16 + a.range[0] >= a.range[1]) return;      // (both waves: before any barrier)
   }
-  if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) mfma2_role<NBA, NBB, TAPS_DEV, 0, WITH_J, CERT, LOOPS>(a, tp, mf2_smem);
-  else mfma2_role<NBA, NBB, TAPS_DEV, 1, WITH_J, CERT, LOOPS>(a, tp, mf2_smem);
+  if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) mfma2_role<NBA, NBB, TAPS_DEV, 0, WITH_J, CERT, LOOPS, NT>(a, tp, mf2_smem);
+  else mfma2_role<NBA, NBB, TAPS_DEV, 1, WITH_J, CERT, LOOPS, NT>(a, tp, mf2_smem);
 }
 
 // Plain solves, with or without the cost trace, the window rule (wind = 6) as a no-fire certificate, the _loops_deconv
@@ -601,11 +620,13 @@ __global__ __launch_bounds__(128) void fista_mfma2_kernel(FistaArgs a, MfmaTaps 
 template <int NBA, int NBB>
 int launch_mfma2(const FistaArgs& a, const double* taps, int K, bool with_j, hipStream_t st) {
   constexpr int NB = NBA + NBB;
-  if (a.N > 32 * NB || a.N <= 32 * (NB - 1) || K < 1 || K > 33) return 1;
+  if (a.N > 32 * NB || a.N <= 32 * (NB - 1) || K < 1 || K > 65) return 1;
+  const bool three = K > 33;                       // three near tiles: plain solves and the cost trace, four blocks at least per wave
   const bool cert = a.stop_mode == PB_STOP_WINDOW, loops = a.stop_mode == PB_STOP_LOOPS;
   if (!a.n_done) return 1;
   if ((with_j || cert || loops) && a.taps_pp) return 1;
   if (loops && with_j) return 1;                   // (the _loops_deconv rule: plain variant, as on the one-wave form)
+  if (three && (cert || loops || a.taps_pp || NBA <= 3)) return 1;
   const int64_t groups = (launch_count(a) + 15) / 16;
   const dim3 grid((unsigned)groups), block(128);
   const size_t lds = mfma2_lds_bytes(NBB);
@@ -615,6 +636,13 @@ int launch_mfma2(const FistaArgs& a, const double* taps, int K, bool with_j, hip
     return 0;
   }
   const MfmaTaps tp = make_mfma_taps(taps, K);
+  if constexpr (NBA > 3) {
+    if (three) {
+      if (with_j) hipLaunchKernelGGL((fista_mfma2_kernel<NBA, NBB, false, true, false, false, 3>), grid, block, lds, st, a, tp);
+      else hipLaunchKernelGGL((fista_mfma2_kernel<NBA, NBB, false, false, false, false, 3>), grid, block, lds, st, a, tp);
+      return 0;
+    }
+  }
   if (loops) hipLaunchKernelGGL((fista_mfma2_kernel<NBA, NBB, false, false, false, true>), grid, block, lds, st, a, tp);
   else if (cert) hipLaunchKernelGGL((fista_mfma2_kernel<NBA, NBB, false, true, true>), grid, block, lds, st, a, tp);
   else if (with_j) hipLaunchKernelGGL((fista_mfma2_kernel<NBA, NBB, false, true, false>), grid, block, lds, st, a, tp);

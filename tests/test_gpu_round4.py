@@ -160,7 +160,8 @@ def test_adversarial_series_through_the_default_dispatch(solver, n, k):
 
 # ---- the matrix-pipe form with every series split over two waves (fista_mfma2.h) ---------------------------------
 @pytest.mark.parametrize("n,k", [(300, 30), (320, 33), (160, 27), (129, 16), (225, 27), (289, 2), (321, 30), (330, 16),
-                                 (400, 27), (480, 30), (577, 30), (600, 30), (608, 30), (640, 33)])
+                                 (400, 27), (480, 30), (577, 30), (600, 30), (608, 30), (640, 33),
+                                 (330, 34), (400, 40), (600, 42), (640, 48)])      # (round 5: 34+ taps, three near tiles)
 def test_split_matrix_pipe_form_matches_oracle(solver, n, k):
     """`fista_mfma2_kernel`: 16 problems per workgroup of two waves, the left wave owning the first
     ceil(nb / 2) blocks of 32 samples and the right wave the rest (5 <= nb <= 20: 129 .. 640 scans -- the

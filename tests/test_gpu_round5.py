@@ -549,3 +549,25 @@ def test_loops_rule_inside_the_split_forms(solver, n, k):
     assert np.abs(ndl.cpu().numpy() - ref_nd).max() <= 1 and (ndl.cpu().numpy() == ref_nd).mean() >= 0.97
     ok = (ndl.cpu().numpy() == ref_nd)[:V]
     assert rel_rows(Wl[:V].cpu().numpy()[ok], Wo[ok]).max() < 1e-5
+
+
+@pytest.mark.parametrize("n,k,P", [(600, 27, 8192 + 150), (1200, 28, 4096 + 90), (400, 20, 6000)])
+def test_shared_hrf_z_step_of_long_series_on_the_split_forms(solver, n, k, P):
+    """`pb_fista_solve_pp` with ONE HRF and step in device memory (the blind step's z-step, bd_shared) at 321 .. 1 280 scans:
+    whole passes on `fista_mfma2_kernel<..., TAPS_DEV>` / `fista_mfma4_kernel<..., TAPS_DEV>`, the rest and what the guards
+    hand back on the one-problem-per-wave form -- against the float64 oracle and against the vector dispatch."""
+    rng = np.random.RandomState(n + k)
+    h = orc.spm_hrf(0.9, 20.0 / k, 20.0, False)[0][:k]            # (a 20 s HRF sampled at k points)
+    assert len(h) == k
+    lip = orc.gram_lipschitz(h, n)
+    Yb = torch.from_numpy(rng.randn(P, n).astype(np.float32)).cuda()
+    taps, stepc = torch.from_numpy(h.copy()).cuda(), torch.from_numpy(np.array([1.0 / lip])).cuda()
+    lam = 0.02 * float(np.median(orc.lambda_max(Yb[:64].cpu().numpy().astype(np.float64), h)))
+    Wp, ndp = solver.fista_solve_pp(Yb, taps, stepc, lam, 60)
+    assert int(ndp.min()) == 60
+    idx = np.r_[0, 15, 16, P - 1, rng.choice(P, 12, replace=False)]
+    Wop = orc.fista_batch(Yb.cpu().numpy()[idx].astype(np.float64), h, lam, 1.0 / lip, 60)
+    assert rel_rows(Wp.cpu().numpy()[idx], Wop).max() < 1e-5
+    Wv, _ = solver.fista_solve_pp(Yb, taps, stepc, lam, 60, force="valu")
+    d = ((Wp - Wv).norm(dim=1) / Wv.norm(dim=1)).cpu().numpy()
+    assert d.max() < 4e-6 and d[:4096].max() > 0.0            # (and it is not the vector form that ran the whole passes)
