@@ -22,23 +22,23 @@ def variants():
             def num(key):
                 return int(re.search(key + r": (\d+)", b).group(1))
             m1 = re.search(r"fista_mfma_kernelILi(\d+)ELb(\d)ELb(\d)ELb(\d)ELi(\d)ELb(\d)", name)
-            m2 = re.search(r"fista_mfma2_kernelILi(\d+)ELi(\d+)ELb(\d)ELb(\d)ELb(\d)ELb(\d)", name)
-            m4 = re.search(r"fista_mfma4_kernelILi(\d+)ELb(\d)ELb(\d)ELb(\d)ELb(\d)", name)
+            m2 = re.search(r"fista_mfma2_kernelILi(\d+)ELi(\d+)ELb(\d)ELb(\d)ELb(\d)ELb(\d)ELi(\d)", name)
+            m4 = re.search(r"fista_mfma4_kernelILi(\d+)ELb(\d)ELb(\d)ELb(\d)ELb(\d)ELi(\d)", name)
             if m1:
                 nb, j, dev, cert, nt, loops = (int(x) for x in m1.groups())
                 kind = "fista_mfma_kernel<%d>" % nb
                 var = "+".join([v for v, on in (("cost trace", j and not cert), ("certificate", cert), ("taps from device", dev),
                                                 ("3 near tiles", nt == 3), ("_loops_deconv rule", loops)) if on]) or "plain"
             elif m2:
-                a, b2, dev, j, cert, loops = (int(x) for x in m2.groups())
+                a, b2, dev, j, cert, loops, nt = (int(x) for x in m2.groups())
                 kind = "fista_mfma2_kernel<%d,%d>" % (a, b2)
                 var = "+".join([v for v, on in (("cost trace", j and not cert), ("certificate", cert), ("taps from device", dev),
-                                                ("_loops_deconv rule", loops)) if on]) or "plain"
+                                                ("_loops_deconv rule", loops), ("3 near tiles", nt == 3)) if on]) or "plain"
             elif m4:
-                a, dev, j, cert, loops = (int(x) for x in m4.groups())
+                a, dev, j, cert, loops, nt = (int(x) for x in m4.groups())
                 kind = "fista_mfma4_kernel<%d>" % a
                 var = "+".join([v for v, on in (("cost trace", j and not cert), ("certificate", cert), ("taps from device", dev),
-                                                ("_loops_deconv rule", loops)) if on]) or "plain"
+                                                ("_loops_deconv rule", loops), ("3 near tiles", nt == 3)) if on]) or "plain"
             else:
                 continue
             out.append(dict(kernel=kind, variant=var, vgpr=num("VGPRs"), agpr=num("AGPRs"), scratch=num(r"ScratchSize \[bytes/lane\]"),
