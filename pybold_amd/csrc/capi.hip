@@ -348,6 +348,9 @@ inline int beside_chunks_for(int N) { return N > 9 * pb::MFMA_SPAN ? MFMA2_BESID
 // 1.58 ms against 1.93, 8 192 2.87 against 1.97 -- profiles/r4_split_form_passes.txt); whole passes of 8 192
 // problems, a remainder above 5/16 of a pass too, a smaller one on the one-problem-per-wave form.
 constexpr int MFMA2_LONG_MIN_P = 5120;
+// (HRFs of 34+ taps have no pair form to compete with, and the one-problem-per-wave form pays for every tap: N = 600, K = 42,
+// 4 096 problems 2.31 ms on the split form against 4.61 -- profiles/r5_long_series_42_taps.txt)
+inline int mfma2_long_min_p(int K) { return K > 33 ? 2048 : MFMA2_LONG_MIN_P; }
 bool mfma2_serves_long(int N, int K, bool extras = true) { return N > MFMA1_NMAX && pick_mfma2(N, K, extras) != nullptr && pick_wide(N, K) != nullptr; }
 int mfma2_long_base(int P, bool one_launch) {
   const int pass = (int)wave_slots() * 4;            // 16 problems x (slots / 2 SIMDs / 2 waves)
@@ -583,7 +586,7 @@ int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mod
   const bool mfma2_ok = (stop_mode == PB_STOP_NONE || (stop_mode == PB_STOP_WINDOW && wind == 6)) && pick_mfma2(N, K) != nullptr;
   if (split_shape && mfma4_serves(N, K, stop_mode != PB_STOP_NONE) && (stop_mode != PB_STOP_WINDOW || pick_wide(N, K)->S <= 20))
     return mfma4_base(P, false) > 0 ? pb::FORM_MFMA4 : FORM_WIDE;
-  if (split_shape && mfma2_serves_long(N, K, stop_mode != PB_STOP_NONE) && P >= MFMA2_LONG_MIN_P && (stop_mode != PB_STOP_WINDOW || pick_wide(N, K)->S <= 20))
+  if (split_shape && mfma2_serves_long(N, K, stop_mode != PB_STOP_NONE) && P >= mfma2_long_min_p(K) && (stop_mode != PB_STOP_WINDOW || pick_wide(N, K)->S <= 20))
     return mfma2_long_base(P, false) > 0 ? FORM_MFMA2 : ((pick_fast(N, K) && N <= 320) ? FORM_FAST1 : FORM_WIDE);   // (the solve's own backup form)
   if (const FastEntry* se = pick_split(N, K))
     if (!mfma_plain && P >= SPLIT_MIN_P && pair_carries(se, stop_mode, wind) && (stop_mode == PB_STOP_NONE || pick_wide(N, K)))
@@ -626,7 +629,7 @@ int pb_fista_plan_ex(int N, int K, int P, int stop_mode, int wind, unsigned flag
     const int base = mfma4_base(P, (flags & (PB_FLAG_ONE_LAUNCH | PB_FLAG_FORCE_MFMA2)) != 0);
     if (base > 0 && base < P) { nm = base; mf = pb::FORM_MFMA4; tf = FORM_WIDE; }
     else tf = base > 0 ? pb::FORM_MFMA4 : FORM_WIDE;
-  } else if (N >= 1 && K >= 1 && split_shape && !no_mfma && mfma2_serves_long(N, K, stop_mode != PB_STOP_NONE) && (P >= MFMA2_LONG_MIN_P || (flags & PB_FLAG_FORCE_MFMA2)) &&
+  } else if (N >= 1 && K >= 1 && split_shape && !no_mfma && mfma2_serves_long(N, K, stop_mode != PB_STOP_NONE) && (P >= mfma2_long_min_p(K) || (flags & PB_FLAG_FORCE_MFMA2)) &&
       (stop_mode != PB_STOP_WINDOW || pick_wide(N, K)->S <= 20)) {
     const int base = mfma2_long_base(P, (flags & (PB_FLAG_ONE_LAUNCH | PB_FLAG_FORCE_MFMA2)) != 0);
     const int backup_form = (pick_fast(N, K) && N <= 320) ? FORM_FAST1 : FORM_WIDE;      // what pb_fista_solve uses behind the split form
@@ -893,7 +896,7 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
                           !(flags & (PB_FLAG_FORCE_GENERIC | PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_FORCE_WIDE | PB_FLAG_DIRECT_FIR | PB_FLAG_NO_MFMA));
     const mfma2_launch_fn mfma2_l = four ? ((shape_ok && mfma4_serves(N, K, stop_mode != PB_STOP_NONE)) ? pick_mfma4(N, K, stop_mode != PB_STOP_NONE) : nullptr)
                                          : ((mfma2 || !lbda_dev || !(stop_mode == PB_STOP_NONE || mfma2_cert || split_loops)) ? mfma2 : pick_mfma2(N, K, stop_mode != PB_STOP_NONE));
-    if (mfma2_l && part_ws && (four || (mfma2_serves_long(N, K, stop_mode != PB_STOP_NONE) && P >= MFMA2_LONG_MIN_P))) {
+    if (mfma2_l && part_ws && (four || (mfma2_serves_long(N, K, stop_mode != PB_STOP_NONE) && P >= mfma2_long_min_p(K)))) {
       const FastEntry* fe1 = pick_fast(N, K);
       const WideEntry* we1 = pick_wide(N, K);
       const bool use_wide = we1 && (!fe1 || N > 320);
@@ -965,7 +968,7 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
       return PB_OK;
     }
   }
-  if (mfma2 && ((flags & PB_FLAG_FORCE_MFMA2) || (mfma2_serves_long(N, K, stop_mode != PB_STOP_NONE) && P >= MFMA2_LONG_MIN_P))) {
+  if (mfma2 && ((flags & PB_FLAG_FORCE_MFMA2) || (mfma2_serves_long(N, K, stop_mode != PB_STOP_NONE) && P >= mfma2_long_min_p(K)))) {
     const FastEntry* fe1 = pick_fast(N, K);
     const WideEntry* we1 = pick_wide(N, K);
     const bool use_wide = we1 && (!fe1 || N > 320);
@@ -1678,7 +1681,7 @@ int pb_fista_solve_pp(const float* y_dev, int64_t ldy, double* w_dev, int64_t ld
     const bool four = N > 640;
     const mfma2_launch_fn split = four ? pick_mfma4(N, K, true) : pick_mfma2(N, K, true);
     const WideEntry* we = pick_wide(N, K);
-    if (split && we && (four || P >= MFMA2_LONG_MIN_P || (flags & PB_FLAG_FORCE_MFMA2))) {
+    if (split && we && (four || P >= mfma2_long_min_p(K) || (flags & PB_FLAG_FORCE_MFMA2))) {
       const bool all = (flags & (PB_FLAG_ONE_LAUNCH | PB_FLAG_FORCE_MFMA2)) != 0;
       const int base = four ? mfma4_base(P, all) : mfma2_long_base(P, all);
       pb::FistaArgs b = a;

@@ -1,7 +1,7 @@
 """Round 5: series of 641 .. 1 280 scans -- the four-wave matrix-pipe form (fista_mfma4.h) against the one-problem-per-wave
 vector form it replaces, by batch size.  N = 1 200, K = 28 (VERDICT r4 item 6b asks >= 1.0e9 voxel-iterations/s).
 
-    python tools/r5_long_series.py [scans] > profiles/r5_long_series_1200_scans.txt
+    python tools/r5_long_series.py [scans [taps]] > profiles/r5_long_series_1200_scans.txt
 """
 import os
 import sys
@@ -31,12 +31,14 @@ def timed(fn, reps=5, warm=2):
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1200
+    k = int(sys.argv[2]) if len(sys.argv) > 2 else 28
     n_it = 500
-    hrf = orc.spm_hrf(1.0, 1.0, 28.0, False)[0][:28]
+    hrf = orc.spm_hrf(1.0, 1.0, float(k), False)[0][:k]
     lip = orc.gram_lipschitz(hrf, n)
     print("# %d scans, K = %d, %d iterations, lambda = 1 (block signals, SNR 1 dB); ms per solve and 1e9 voxel-iterations/s" % (n, len(hrf), n_it))
     print("%-8s %22s %22s %22s   %s" % ("problems", "default", "four waves (forced)", "vector form (valu)", "handed back"))
-    for P in (512, 1024, 1536, 2048, 3072, 4096, 5120, 6144, 8192, 12288, 16384, 20000, 32768):
+    sizes = (512, 1024, 1536, 2048, 3072, 4096, 5120, 6144, 8192, 12288, 16384, 20000, 32768) if len(sys.argv) <= 2 else (4096, 8192, 16384, 32768)
+    for P in sizes:
         Y, _, _ = data.gen_rnd_bloc_bold_batch(P, dur=n / 60.0, tr=1.0, hrf=hrf, nb_events=5, avg_dur=12.0, std_dur=1.0, snr=1.0, seed=0)
         Y = Y[:, :n].contiguous()
         row = []
@@ -45,7 +47,9 @@ def main():
             row.append("%8.3f ms %6.3f" % (t, P * n_it / t / 1e6))
         _, _, nd = solver.fista_solve(Y, hrf, 1.0, 1.0 / lip, n_it, force="mfma2only")
         print("%-8d %22s %22s %22s   %.2f %%" % (P, row[0], row[1], row[2], 100.0 * float((nd < 0).float().mean())), flush=True)
-    for kw, name in ((dict(want_J=True), "cost trace"), (dict(want_J=True, stop="window", tol=1e-6, wind=6), "cost trace + window rule, tol 1e-6")):
+    shapes = ((dict(want_J=True), "cost trace"), (dict(want_J=True, stop="window", tol=1e-6, wind=6), "cost trace + window rule, tol 1e-6"),
+              (dict(stop="loops", tol=1e-6), "_loops_deconv rule, tol 1e-6"))
+    for kw, name in shapes:
         P = 16384
         Y, _, _ = data.gen_rnd_bloc_bold_batch(P, dur=n / 60.0, tr=1.0, hrf=hrf, nb_events=5, avg_dur=12.0, std_dur=1.0, snr=1.0, seed=0)
         Y = Y[:, :n].contiguous()
