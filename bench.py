@@ -579,6 +579,24 @@ def roofline_block(matrix_pipe, kernel, dom_ms, P_dom, n_iter, N, K, flops_launc
                                           "that run); frac ~ 1 means no issue slot is lost to latency: only fewer instructions, "
                                           "or a second wave per SIMD (x1.15-1.23, not reachable: 304 registers of state per "
                                           "wave), would be faster"}
+        elif mfma_block:
+            # the split forms: the same model on ONE wave's share of the instructions (SQ counters, profiles/r5_pmc_sq_600_scans.json,
+            # r5_pmc_sq_1200_scans.json: 995.6 vector instructions per wave-iteration at 19 blocks over two waves, 1 128.5 at ten
+            # blocks per wave over four); what the model leaves is the price of the two workgroup barriers per iteration
+            wpg = mfma_block["waves_per_16_problems"]
+            n_m = mfma_block["mfma_instructions_per_16_problems_and_iteration"] / float(wpg)
+            blocks_w = math.ceil(N / 32.0) / 2.0 if wpg == 2 else math.ceil(N / 128.0)
+            n_v = 995.6 * blocks_w / 9.5 if wpg == 2 else 1128.5 * blocks_w / 10.0
+            v = n_v / n_m
+            ns_model = n_m * (13.3 + (2.9 if v >= 4.0 else 1.95) * (v - 4.0))
+            groups = float(P_dom) / 16.0
+            model_ms = ns_model * 1e-6 * n_iter * max(1.0, math.ceil(groups * wpg / 1024.0))
+            head["issue_roof"] = {"matrix_instructions_per_wave_iteration": n_m, "vector_instructions_per_wave_iteration": n_v,
+                                  "model_ns_per_wave_iteration": ns_model, "model_ms_per_launch": model_ms,
+                                  "measured_ms_per_launch": dom_ms, "frac": model_ms / dom_ms,
+                                  "note": "split form: the microbenchmark's time for ONE wave's instruction mix (one wave per SIMD); "
+                                          "what is missing to 1 is the two workgroup barriers per iteration (waves wait for the "
+                                          "slowest share, then for the exchanged scalars)"}
         binding = ("issue of ONE wave per SIMD: 996 vector + 228 matrix instructions per 16 voxel-iterations at N = 300 "
                    "(profiles/r4_pmc_sq.json), at the package power limit -- neither HBM nor the MFMA peak.  Round 5 "
                    "measured the roof itself (profiles/r5_mfma_narrow_and_issue_model.txt, r5_valu_one_wave.txt): a lone "

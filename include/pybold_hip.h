@@ -353,7 +353,10 @@ int pb_spectral_radius(const double* x0_dev, int N, const double* taps_dev, int 
  *                     step_dev float64 [P]; stop rule NONE or LOOPS; no cost trace.
  *                     ldt = 0: ONE HRF (taps_dev [K]) and ONE step (step_dev [1]) in device
  *                     memory shared by every problem -- the shared-HRF blind step, whose
- *                     taps come out of pb_theta_fit without passing through the host.
+ *                     taps come out of pb_theta_fit without passing through the host.  With
+ *                     n_done_dev, no stop rule and K <= 33 that form runs on the matrix-pipe
+ *                     kernels (129 .. 1 280 scans: one wave, two or four waves per 16 problems),
+ *                     what they hand back on the vector forms; per-problem HRFs: vector forms.
  * pb_hrf_cost_pv      pb_hrf_cost with one HRF per (candidate, voxel):
  *                     taps_dev float64 [n_hrf][V][K], cost_dev float64 [n_hrf][V].
  * pb_gram_frobenius   out[p] = || A_p^T A_p ||_F with A_p = toeplitz(taps_p, N, N) tril(1):

@@ -571,3 +571,24 @@ def test_shared_hrf_z_step_of_long_series_on_the_split_forms(solver, n, k, P):
     Wv, _ = solver.fista_solve_pp(Yb, taps, stepc, lam, 60, force="valu")
     d = ((Wp - Wv).norm(dim=1) / Wv.norm(dim=1)).cpu().numpy()
     assert d.max() < 4e-6 and d[:4096].max() > 0.0            # (and it is not the vector form that ran the whole passes)
+
+
+def test_bd_shared_graph_on_a_long_series(solver):
+    """`BdSharedGraph` at 1 000 scans: the z-steps run on `fista_mfma4_kernel<..., TAPS_DEV>` (more than 64 KB of dynamic LDS,
+    asked for inside the capture) -- the captured loop replays to the eager loop's bits and follows the vector dispatch."""
+    from pybold_amd import data, distributed
+    from pybold_amd.hrf_model import spm_hrf
+    t_r, dur, V, n = 0.75, 20.0, 4500, 1000
+    h_true = spm_hrf(0.8, t_r, dur, False)[0]
+    Y, _, _ = data.gen_rnd_bloc_bold_batch(V, dur=n * t_r / 60.0, tr=t_r, hrf=h_true, nb_events=12, avg_dur=12.0,
+                                           std_dur=1.0, snr=10.0, seed=3)
+    Y = Y[:, :n].contiguous()
+    We, he, de = distributed.bd_shared(Y, t_r, lbda=1.7, hrf_dur=dur, nb_iter=3, nb_inner=30)
+    runner = distributed.BdSharedGraph(Y, t_r, lbda=1.7, hrf_dur=dur, nb_iter=3, nb_inner=30)
+    assert runner.graph is not None, runner.fallback
+    for _ in range(2):
+        runner.launch()
+    W, h, d = runner.result()
+    assert torch.equal(W, We) and np.array_equal(d["theta"], de["theta"])
+    assert de["theta"][-1] < de["theta"][0]
+    assert "four waves" in solver.which_kernel(n, len(h_true), V)
