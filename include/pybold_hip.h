@@ -65,7 +65,7 @@ extern "C" {
 #define PB_FLAG_FORCE_MFMA2 65536u /* the matrix-pipe form with every series split over the waves of a workgroup, one launch:
                                      two waves (fista_mfma2_kernel, 129..640 scans) or four (fista_mfma4_kernel, 641..1280);
                                      HRFs of up to 33 taps: plain, cost trace, window certificate, _loops_deconv rule; 34..65 taps
-                                     (three near tiles, series of 311+ scans): plain and cost trace */
+                                     (three near tiles, series of 311+ scans): plain, cost trace, window certificate */
 #define PB_FLAG_NO_MFMA 8192u      /* plain solves: never the matrix-pipe form (fista_mfma_kernel), vector forms only */
 #define PB_FLAG_FORCE_CERT 1024u   /* PB_STOP_WINDOW, wind = 6: certificate path whatever tol * n_iter is */
 #define PB_FLAG_NO_PARTITION 4096u  /* never partition a call on the device (see pb_fista_solve_ex): the host-side plan of round 4 */
@@ -104,8 +104,8 @@ int pb_fista_has_fast_path(int N, int K);
  * on the matrix pipe (fista_mfma_kernel: 129..310 scans; HRFs of up to 48 taps, the window-rule certificate up to
  * 33; one lambda for the batch; assumes n_done_dev is given), 5 = the same with every series split over the two waves
  * of a workgroup (fista_mfma2_kernel: small batches, and series of 311..640 scans), 6 = split over the four waves of a
- * workgroup (fista_mfma4_kernel: series of 641..1280 scans; HRFs of up to 33 taps, 34..65 for plain solves and the cost
- * trace).  Host-only query. */
+ * workgroup (fista_mfma4_kernel: series of 641..1280 scans; HRFs of up to 33 taps, 34..65 for everything but the
+ * _loops_deconv rule).  Host-only query. */
 int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mode, int wind);
 
 /* How pb_fista_solve (no flags) lays P problems out: problems [0, *n_main) in one launch of

@@ -362,7 +362,7 @@ def test_loops_rule_inside_the_matrix_pipe_kernel(solver, golden):
     assert torch.equal(Wl[:250], Wl[250:500])
 
 
-@pytest.mark.parametrize("n,k", [(600, 30), (400, 27), (640, 33), (300, 30), (161, 16)])
+@pytest.mark.parametrize("n,k", [(600, 30), (400, 27), (640, 33), (300, 30), (161, 16), (600, 42), (400, 48)])
 def test_split_form_cost_trace_and_window_rule(solver, n, k):
     """`fista_mfma2_kernel<..., WITH_J, CERT>`: the cost trace (each wave adds up its half of ||r||^2 and ||w||_1, the
     halves meet at the barrier of the forward pass) against the float64 oracle's; the window rule (wind = 6) as a

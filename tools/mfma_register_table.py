@@ -46,10 +46,17 @@ def variants():
     return out
 
 
+# Explicit allowances (bytes of scratch per lane), each with its measured reason.  fista_mfma4_kernel<9> certificate + three near
+# tiles: the lane index (one register) is parked in scratch at kernel entry and read back once per role prologue and twice per
+# iteration next to a barrier; A = 8 and A = 10 fit (226 accumulator registers).  Nothing under a partial exec mask
+# (tools/isa_spill_lint.py on build/mfma4_9.s).
+ALLOW = {("fista_mfma4_kernel<9>", "certificate+3 near tiles"): 8}
+
+
 def main():
     vs = variants()
     if "--check" in sys.argv:
-        bad = [v for v in vs if v["scratch"]]
+        bad = [v for v in vs if v["scratch"] > ALLOW.get((v["kernel"], v["variant"]), 0)]
         for v in bad:
             print("%(kernel)s %(variant)s: %(scratch)d B of scratch per lane" % v)
         print("%d variants, %d with scratch" % (len(vs), len(bad)))
