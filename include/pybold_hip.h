@@ -269,10 +269,12 @@ int pb_fista_solve_ex(const float* y_dev, int64_t ldy, int y_rep,
  * shape outside the matrix-pipe form (129..310 scans, <= 33 taps): the call is pb_fista_solve with lbda_dev.
  * (Round 5: = pb_fista_solve_ex with lbda_dev, no cost trace, no stop rule; kept for callers of round 4.)
  */
-/* (round 5: 0.19 for series of up to 310 scans, 0.22 for 311..640 -- with the handed-back problems compacted the
- * break-even moved up from round 4's 0.13: profiles/r5_dense_ratio_sweep.txt) */
+/* (round 5: 0.19 for series of up to 310 scans, 0.22 for 311..640, 0.26 for 641..1280 (the guard hands back 7 % at
+ * lambda / lambda_max = 0.20 there, 50 % at 0.30) -- with the handed-back problems compacted the break-even moved up from
+ * round 4's 0.13: profiles/r5_dense_ratio_sweep.txt, r5_lambda_sweep_1200_scans.txt) */
 #define PB_PATH_DENSE_RATIO 0.19
 #define PB_PATH_DENSE_RATIO_LONG 0.22
+#define PB_PATH_DENSE_RATIO_LONGER 0.26
 int64_t pb_fista_path_work_len(int P);
 int pb_fista_solve_path(const float* y_dev, int64_t ldy, int y_rep, double* w_dev, int64_t ldw, int P, int N,
                         const double* taps_host, const double* taps_dev, int K, double step,

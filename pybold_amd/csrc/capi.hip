@@ -784,7 +784,7 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
     int32_t* rg_flag = rg_sparse + 2 * pb::CAND_COUNT;
     int32_t* rg_ill = rg_flag + 2 * pb::CAND_COUNT;
     {
-      pb::ClassPred cp{lbda_dev, lbda, lmax, y_rep, no_dense_class ? 0.0 : (dense_ratio > 0.0 ? dense_ratio : (N > MFMA1_NMAX ? PB_PATH_DENSE_RATIO_LONG : PB_PATH_DENSE_RATIO)), nullptr};
+      pb::ClassPred cp{lbda_dev, lbda, lmax, y_rep, no_dense_class ? 0.0 : (dense_ratio > 0.0 ? dense_ratio : (N > 640 ? PB_PATH_DENSE_RATIO_LONGER : (N > MFMA1_NMAX ? PB_PATH_DENSE_RATIO_LONG : PB_PATH_DENSE_RATIO))), nullptr};
       hipLaunchKernelGGL(pb::path_count_kernel, dim3(nblk), dim3(pb::PATH_THREADS), 0, user, cp, P, work_dev);
       pb::PlanSpec front = dense;
       front.merged = 1;
