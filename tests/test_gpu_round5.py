@@ -592,3 +592,34 @@ def test_bd_shared_graph_on_a_long_series(solver):
     assert torch.equal(W, We) and np.array_equal(d["theta"], de["theta"])
     assert de["theta"][-1] < de["theta"][0]
     assert "four waves" in solver.which_kernel(n, len(h_true), V)
+
+
+def test_regularisation_path_of_a_long_series(solver):
+    """BASELINE config 5's call shape (one series, a grid of lambdas: y shared by `y_rep` problems) at 700 scans: the partitioned
+    dispatch puts the dense end of every path on the four-wave form, the sparse end on the one-problem-per-wave form; every
+    problem against the C oracle, the top of each path 0."""
+    from oracle import c_oracle
+    from pybold_amd import data
+    n, V, L = 700, 300, 16
+    hrf = orc.spm_hrf(1.0, 1.0, 28.0, False)[0][:28]
+    lip = orc.gram_lipschitz(hrf, n)
+    Y, _, _ = data.gen_rnd_bloc_bold_batch(V, dur=n / 60.0, tr=1.0, hrf=hrf, nb_events=8, avg_dur=12.0, std_dur=1.0, snr=1.0, seed=5)
+    Y = Y[:, :n].contiguous()
+    lmax = solver.lambda_max(Y, hrf)
+    grid = torch.logspace(-2.0, 0.0, L, dtype=torch.float64, device="cuda")
+    lam = (lmax[:, None] * grid[None, :]).reshape(-1)
+    W, _, nd = solver.fista_solve(Y, hrf, lam, 1.0 / lip, 200, y_rep=L)
+    assert int(nd.min()) == 200 and int(nd.max()) == 200
+    idx = np.r_[np.arange(2 * L), np.random.RandomState(0).choice(V * L, 96, replace=False)]
+    Yo = Y.cpu().numpy().astype(np.float64)[idx // L]
+    Wo, _, _ = c_oracle.fista_batch(Yo, hrf, lam[idx].cpu().numpy(), 1.0 / lip, 200, threads=8)
+    # (the top of a path, lambda = lambda_max to the last bit: the solution is 0 or a rounding's worth of it in either arithmetic)
+    scale = np.linalg.norm(Wo, axis=1).max()
+    nz = np.linalg.norm(Wo, axis=1) > 1e-9 * scale
+    Wn = W[idx].cpu().numpy()
+    assert nz.sum() >= 100 and rel_rows(Wn[nz], Wo[nz]).max() < 1e-5
+    assert np.linalg.norm(Wn[~nz], axis=1).max(initial=0.0) <= 1e-9 * scale
+    assert float(W[L - 1].norm()) <= 1e-9 * scale                  # lambda = lambda_max: the zero solution
+    Wv, _, _ = solver.fista_solve(Y, hrf, lam, 1.0 / lip, 200, y_rep=L, force="valu")
+    d = ((W - Wv).norm(dim=1) / (Wv.norm(dim=1) + 1e-300)).cpu().numpy()
+    assert d.max() < 2e-5 and (d > 0).mean() > 0.3                 # (a good part of the path ran on the matrix pipe)
