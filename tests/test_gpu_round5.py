@@ -597,7 +597,7 @@ def test_bd_shared_graph_on_a_long_series(solver):
 def test_regularisation_path_of_a_long_series(solver):
     """BASELINE config 5's call shape (one series, a grid of lambdas: y shared by `y_rep` problems) at 700 scans: the partitioned
     dispatch puts the dense end of every path on the four-wave form, the sparse end on the one-problem-per-wave form; every
-    problem against the C oracle, the top of each path 0."""
+    problem against the C oracle."""
     from oracle import c_oracle
     from pybold_amd import data
     n, V, L = 700, 300, 16
@@ -613,13 +613,10 @@ def test_regularisation_path_of_a_long_series(solver):
     idx = np.r_[np.arange(2 * L), np.random.RandomState(0).choice(V * L, 96, replace=False)]
     Yo = Y.cpu().numpy().astype(np.float64)[idx // L]
     Wo, _, _ = c_oracle.fista_batch(Yo, hrf, lam[idx].cpu().numpy(), 1.0 / lip, 200, threads=8)
-    # (the top of a path, lambda = lambda_max to the last bit: the solution is 0 or a rounding's worth of it in either arithmetic)
-    scale = np.linalg.norm(Wo, axis=1).max()
-    nz = np.linalg.norm(Wo, axis=1) > 1e-9 * scale
+    # (at lambda = lambda_max the prox is 0 at every iteration, the iterate is not: the reference's momentum runs on the
+    # gradient-step point, w_{k+1} = -beta_k u_k there -- pybold/bold_signal.py:65,72; the oracle restates that)
     Wn = W[idx].cpu().numpy()
-    assert nz.sum() >= 100 and rel_rows(Wn[nz], Wo[nz]).max() < 1e-5
-    assert np.linalg.norm(Wn[~nz], axis=1).max(initial=0.0) <= 1e-9 * scale
-    assert float(W[L - 1].norm()) <= 1e-9 * scale                  # lambda = lambda_max: the zero solution
+    assert rel_rows(Wn, Wo).max() < 1e-5
     Wv, _, _ = solver.fista_solve(Y, hrf, lam, 1.0 / lip, 200, y_rep=L, force="valu")
     d = ((W - Wv).norm(dim=1) / (Wv.norm(dim=1) + 1e-300)).cpu().numpy()
     assert d.max() < 2e-5 and (d > 0).mean() > 0.3                 # (a good part of the path ran on the matrix pipe)
