@@ -620,3 +620,32 @@ def test_regularisation_path_of_a_long_series(solver):
     Wv, _, _ = solver.fista_solve(Y, hrf, lam, 1.0 / lip, 200, y_rep=L, force="valu")
     d = ((W - Wv).norm(dim=1) / (Wv.norm(dim=1) + 1e-300)).cpu().numpy()
     assert d.max() < 2e-5 and (d > 0).mean() > 0.3                 # (a good part of the path ran on the matrix pipe)
+
+
+@pytest.mark.parametrize("case", ["hcp", "long42"])
+def test_long_series_against_the_reference_itself(solver, golden, case):
+    """The REAL reference's `deconv` on 1 200 scans (TR 0.72 s, 20 s HRF = 28 taps: examples/icassp_2019/validation.py:41-48) and on
+    900 scans with a 42-tap HRF (tests/golden/make_golden_r5_long.py) against `fista_mfma4_kernel` -- two near tiles / three --:
+    iterate, outputs, cost trace; the window rule through the certificate + exact re-solve stops where the reference stopped."""
+    g = golden("long_series")
+    y, hrf, lip = g[case + "_y"], g[case + "_hrf"], float(g[case + "_lipschitz"])
+    n = len(y)
+    assert "four waves" in solver.which_kernel(n, len(hrf), 4096, want_J=True, stop="window")
+    Yd = torch.from_numpy(np.tile(y.astype(np.float32), (40, 1))).cuda()
+    y32 = y.astype(np.float32).astype(np.float64)
+    in_err = np.linalg.norm(y32 - y) / np.linalg.norm(y)            # (the batch API takes float32 series)
+    for lbda in (0.5, 2.0):
+        tag = "%s_l%g_n100" % (case, lbda)
+        W, J, nd = solver.fista_solve(Yd, hrf, lbda, 1.0 / lip, 100, want_J=True, force="mfma2only")
+        assert int(nd.min()) == 100
+        X, Z = solver.fista_outputs(W, hrf)
+        for a, k in ((W, "dz_"), (Z, "z_"), (X, "x_")):
+            e = np.linalg.norm(a[7].cpu().numpy() - g[k + tag]) / np.linalg.norm(g[k + tag])
+            assert e < 1e-5, (tag, k, e, in_err)
+        Jn = J[7].cpu().numpy().astype(np.float64)
+        np.testing.assert_allclose(Jn / Jn[0], g["J_" + tag], rtol=5e-5)
+        tag = "%s_l%g_n400_es" % (case, lbda)
+        Ww, Jw, ndw = solver.fista_solve(Yd, hrf, lbda, 1.0 / lip, 400, want_J=True, stop="window", tol=1e-2, wind=6, force="mfma2cert")
+        assert int(ndw.min()) == int(ndw.max()) == len(g["J_" + tag])
+        e = np.linalg.norm(Ww[7].cpu().numpy() - g["dz_" + tag]) / np.linalg.norm(g["dz_" + tag])
+        assert e < 1e-5, (tag, e)

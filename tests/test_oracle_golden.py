@@ -341,3 +341,26 @@ def test_auto_lambda_c_oracle_against_reference_incl_defaults(golden):
             # 1e-8: the C form sums in another order than NumPy, and the runs whose alpha comes within 0.02 of zero
             # (lambda up to 25) amplify that by 1e5 (worst 2e-10); every other run agrees to 1e-13
             assert rel(W[v], g["dz_" + tag]) < 1e-8 and rel(zo[0], g["z_" + tag]) < 1e-8 and rel(xo[0], g["x_" + tag]) < 1e-8, tag
+
+
+# ---- round 5: HCP-length series (the shapes the four-wave matrix-pipe form serves) from the REAL reference -----------------
+@pytest.mark.parametrize("case", ["hcp", "long42"])
+def test_long_series_oracle_against_reference(golden, case):
+    """tests/golden/make_golden_r5_long.py: the reference's fixed-lambda `deconv` on 1 200 scans (TR 0.72 s, 28 taps) and on 900
+    scans with a 42-tap HRF; the NumPy and C restatements reproduce its iterate, outputs, cost trace and window-rule stop."""
+    from oracle import c_oracle
+    g = golden("long_series")
+    y, hrf, lip = g[case + "_y"], g[case + "_hrf"], float(g[case + "_lipschitz"])
+    for lbda in (0.5, 2.0):
+        tag = "%s_l%g_n100" % (case, lbda)
+        x, z, w, J, n_done, _ = orc.deconv_fixed_lbda(y, hrf, lbda, nb_iter=100, early_stopping=False, lipschitz=lip, dense=False)
+        assert n_done == 100
+        for a, k in ((w, "dz_"), (z, "z_"), (x, "x_"), (J, "J_")):
+            assert np.linalg.norm(a - g[k + tag]) <= 1e-10 * np.linalg.norm(g[k + tag]), (tag, k)
+        Wc, Jc, _ = c_oracle.fista_batch(y[None, :], hrf, lbda, 1.0 / lip, 100, want_J=True, threads=1)
+        assert np.linalg.norm(Wc[0] - g["dz_" + tag]) <= 1e-10 * np.linalg.norm(g["dz_" + tag])
+        tag = "%s_l%g_n400_es" % (case, lbda)
+        x, z, w, J, n_done, _ = orc.deconv_fixed_lbda(y, hrf, lbda, nb_iter=400, early_stopping=True, tol=1e-2, wind=6,
+                                                       lipschitz=lip, dense=False)
+        assert n_done == len(g["J_" + tag]) < 400                    # the window rule fires where the reference's did
+        assert np.linalg.norm(w - g["dz_" + tag]) <= 1e-10 * np.linalg.norm(g["dz_" + tag])
