@@ -170,8 +170,21 @@ int pb_fista_plan_ex(int N, int K, int P, int stop_mode, int wind, unsigned flag
  *       rounded to nearest), three v_mfma_f32_16x16x32_f16 products per tile, float32 accumulation; every
  *       series scaled by a per-problem power of two into the float16 range (exact: the problem is
  *       scale-covariant).
+ * WHICH SHAPE RUNS WHERE (calls of a few thousand problems or more; pb_fista_which_kernel / pb_fista_plan_ex answer for a shape):
+ *   scans N      taps K    plain / cost trace   window rule, wind 6      _loops_deconv rule    form
+ *   <= 128       <= 32     (a)                  (a) certificate          (a)                   two problems per row / single row
+ *   129 .. 310   <= 33     (b)                  (b) certificate          (b) in full           fista_mfma_kernel, one wave per 16 problems
+ *   129 .. 310   34 .. 48  (b)                  (a)                      (a)                   ... with three near tiles
+ *   311 .. 640   <= 33     (b)                  (b) certificate          (b) in full           fista_mfma2_kernel, two waves per 16 problems
+ *   311 .. 640   34 .. 48  (b)                  (b) certificate          (a)                   ... with three near tiles
+ *   641 .. 1280  <= 33     (b)                  (b) certificate (<=1216) (b) in full           fista_mfma4_kernel, four waves per 16 problems
+ *   641 .. 1216  34 .. 48  (b)                  (b) certificate          (a)                   ... with three near tiles
+ *   longer series, longer HRFs, other windows, a cost trace beside the _loops_deconv rule: (a), one problem per wave up to
+ *   2 432 scans, the LDS kernel beyond (and for the window rule beyond 1 216 scans, for 34+ taps beyond 1 216).  Per-problem HRFs (pb_fista_solve_pp, ldt != 0): (a).  A machine-filling batch that lands
+ *   on (a) although (b) serves neighbouring shapes is 1.5 .. 4x below the matrix-pipe rate; the Python layer says so once.
+ *
  * (b) is chosen for plain solves (PB_STOP_NONE, or PB_STOP_WINDOW as a certificate with tol * n_iter < 0.02)
- * of 129..310 scans (up to 640 on the split form) with ONE lambda for the call (lbda_dev == NULL, or per-problem lambdas with the dense
+ * of 129..1280 scans with ONE lambda for the call (lbda_dev == NULL, or per-problem lambdas with the dense
  * part of a regularisation path: see below) -- AND ONLY IF n_done_dev IS GIVEN: the matrix-pipe kernel
  * reports through n_done the problems it must not keep, namely
  *   - range: a residual fragment reached 2^15 or |sigma w| reached 60000 (checked after the first pass of a
@@ -203,7 +216,7 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep,
  * The matrix-pipe form (b) holds eps only where the solution is dense (threshold <= 0.02 max|w|, see above); for a
  * lambda near lambda_max,v = || H^T y_v ||_inf it used to be solved on (b), handed back and solved again on (a), one
  * handed-back problem per wave -- slower than never using (b) (profiles/r4_path_partition.txt).  Since round 5 every
- * call that (b) can carry (129..310 scans; plain, cost trace, window-rule certificate, _loops_deconv rule; ONE lambda or
+ * call that (b) can carry (129..1280 scans; plain, cost trace, window-rule certificate, _loops_deconv rule; ONE lambda or
  * one per problem) is PARTITIONED ON THE DEVICE before it is solved, without a host synchronisation:
  *     lbda_p < dense_ratio * lmax[p / y_rep]    -> dense class:  matrix-pipe form (b)
  *     otherwise                                 -> sparse class: float32 vector forms (a)
