@@ -177,10 +177,10 @@ int pb_fista_plan_ex(int N, int K, int P, int stop_mode, int wind, unsigned flag
  *   129 .. 310   34 .. 48  (b)                  (a)                      (a)                   ... with three near tiles
  *   311 .. 640   <= 33     (b)                  (b) certificate          (b) in full           fista_mfma2_kernel, two waves per 16 problems
  *   311 .. 640   34 .. 48  (b)                  (b) certificate          (a)                   ... with three near tiles
- *   641 .. 1280  <= 33     (b)                  (b) certificate (<=1216) (b) in full           fista_mfma4_kernel, four waves per 16 problems
- *   641 .. 1216  34 .. 48  (b)                  (b) certificate          (a)                   ... with three near tiles
+ *   641 .. 1280  <= 33     (b)                  (b) certificate          (b) in full           fista_mfma4_kernel, four waves per 16 problems
+ *   641 .. 1280  34 .. 48  (b)                  (b) certificate          (a)                   ... with three near tiles
  *   longer series, longer HRFs, other windows, a cost trace beside the _loops_deconv rule: (a), one problem per wave up to
- *   2 432 scans, the LDS kernel beyond (and for the window rule beyond 1 216 scans, for 34+ taps beyond 1 216).  Per-problem HRFs (pb_fista_solve_pp, ldt != 0): (a).  A machine-filling batch that lands
+ *   2 432 scans, the LDS kernel beyond (and for the window rule beyond 1 280 scans, for 34+ taps beyond 1 280).  Per-problem HRFs (pb_fista_solve_pp, ldt != 0): (a).  A machine-filling batch that lands
  *   on (a) although (b) serves neighbouring shapes is 1.5 .. 4x below the matrix-pipe rate; the Python layer says so once.
  *
  * (b) is chosen for plain solves (PB_STOP_NONE, or PB_STOP_WINDOW as a certificate with tol * n_iter < 0.02)

@@ -421,7 +421,7 @@ def test_ill_conditioned_series_are_solved_in_float64(solver, golden):
 # Round 5: series of 641 .. 1 280 scans on the matrix pipe (fista_mfma4.h: one series over the four waves of a workgroup)
 @pytest.mark.parametrize("n,k", [(641, 30), (700, 27), (768, 33), (769, 16), (900, 30), (1000, 2), (1024, 30), (1025, 30),
                                  (1200, 28), (1216, 33), (1217, 30), (1279, 30), (1280, 32),
-                                 (700, 34), (900, 40), (1200, 42), (1216, 48), (641, 48)])
+                                 (700, 34), (900, 40), (1200, 42), (1216, 48), (641, 48), (1250, 42), (1280, 48)])
 def test_four_wave_matrix_pipe_form_matches_oracle(solver, n, k):
     """`fista_mfma4_kernel`: 16 problems per workgroup of four waves, wave j owning blocks j A .. j A + A - 1 of 32 samples
     (A = ceil(N / 128): 6 .. 10; the last wave holds the end of the series and the padding behind it) -- HCP-length
@@ -452,8 +452,11 @@ def test_four_wave_matrix_pipe_form_matches_oracle(solver, n, k):
     perm = torch.from_numpy(np.r_[np.arange(23, 40), np.arange(23)]).cuda()
     W2, _, _ = solver.fista_solve(Yd[perm].contiguous(), hrf, 0.3, 1.0 / lip, 200, W0=W0d[perm].contiguous(), force="mfma2only")
     assert torch.equal(W2, W[perm])
+    # the vector form behind it (remainders, re-solves: one problem per wave, strips of 10 .. 20 samples) against the oracle too
+    Wv0, _, _ = solver.fista_solve(Yd, hrf, 0.3, 1.0 / lip, 200, W0=W0d, force="valu")
+    assert rel_rows(Wv0.cpu().numpy(), Wo).max() < 3e-6
     # the window rule (far from firing) as a certificate: cleared everywhere; a tolerance it fires at: handed back, re-solved
-    if n <= 1216:                                   # (the re-solve's exact rule needs strips of at most 20 samples per lane)
+    if True:                                        # (641 .. 1 280 scans: the re-solve's exact rule holds strips of up to 20 samples per lane)
         Wk, Jk, ndk = solver.fista_solve(Yd, hrf, 0.3, 1.0 / lip, 200, force="mfma2certonly", want_J=True, stop="window", tol=1e-9, wind=6)
         assert int(ndk.min()) == 200 and torch.equal(Wk, Wc)
         # (the exact rule on the one-problem-per-wave form: tests/test_gpu_parity.py pins that one to the reference's stops)
