@@ -99,7 +99,8 @@ namespace {
 // (129 .. 640 scans), floor(nb / 2) of them in the left wave; K <= 33; plain solves, the cost
 // trace and the window rule (wind = 6) as a no-fire certificate; the shared-HRF z-step plain only
 typedef int (*mfma2_launch_fn)(const pb::FistaArgs&, const double*, int, bool, hipStream_t);
-// (34 <= K <= 65: three near tiles -- series of 311+ scans only (shorter ones: the one-wave form), plain solves, the cost
+// (34 <= K <= 65: three near tiles -- series of 225+ scans (four blocks per wave; the one-wave form carries shorter ones, and
+// everything up to 310 scans but the certificate), plain solves, the cost
 // trace and the certificate: `extras` = _loops_deconv rule / taps from device memory wanted)
 mfma2_launch_fn pick_mfma2(int N, int K, bool extras = true) {
   static const mfma2_launch_fn tab[] = {
@@ -109,7 +110,7 @@ mfma2_launch_fn pick_mfma2(int N, int K, bool extras = true) {
       &pb::launch_mfma2<8, 9>, &pb::launch_mfma2<9, 9>, &pb::launch_mfma2<9, 10>, &pb::launch_mfma2<10, 10>};
   const int nb = (N + 31) / 32;
   if (K < 1 || K > 65 || nb < 5 || nb > 20) return nullptr;
-  if (K > 33 && (extras || N <= 310)) return nullptr;
+  if (K > 33 && (extras || N <= 224)) return nullptr;         // (three near tiles: four blocks at least per wave)
   return tab[nb - 5];
 }
 // the same with one series split over the FOUR waves of a workgroup (fista_mfma4.h): 641 .. 1 280 scans, A = ceil(N / 128)
@@ -352,6 +353,11 @@ constexpr int MFMA2_LONG_MIN_P = 5120;
 // 4 096 problems 2.31 ms on the split form against 4.61 -- profiles/r5_long_series_42_taps.txt)
 inline int mfma2_long_min_p(int K) { return K > 33 ? 2048 : MFMA2_LONG_MIN_P; }
 bool mfma2_serves_long(int N, int K, bool extras = true) { return N > MFMA1_NMAX && pick_mfma2(N, K, extras) != nullptr && pick_wide(N, K) != nullptr; }
+// 225 .. 310 scans with 34+ taps and the window rule: the one-wave form has no certificate beside three near tiles (its state does
+// not fit), the split form has -- it takes such calls like a long series
+bool mfma2_takes_short_cert(int N, int K, int stop_mode, int wind) {
+  return K > 33 && stop_mode == PB_STOP_WINDOW && wind == 6 && N > 224 && N <= MFMA1_NMAX && pick_mfma2(N, K, false) != nullptr && pick_wide(N, K) != nullptr;
+}
 int mfma2_long_base(int P, bool one_launch) {
   const int pass = (int)wave_slots() * 4;            // 16 problems x (slots / 2 SIMDs / 2 waves)
   const int base = (P / pass) * pass;
@@ -586,7 +592,7 @@ int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mod
   const bool mfma2_ok = (stop_mode == PB_STOP_NONE || (stop_mode == PB_STOP_WINDOW && wind == 6)) && pick_mfma2(N, K) != nullptr;
   if (split_shape && mfma4_serves(N, K, stop_mode == PB_STOP_LOOPS) && (stop_mode != PB_STOP_WINDOW || pick_wide(N, K)->S <= 20))
     return mfma4_base(P, false) > 0 ? pb::FORM_MFMA4 : FORM_WIDE;
-  if (split_shape && mfma2_serves_long(N, K, stop_mode == PB_STOP_LOOPS) && P >= mfma2_long_min_p(K) && (stop_mode != PB_STOP_WINDOW || pick_wide(N, K)->S <= 20))
+  if (split_shape && (mfma2_serves_long(N, K, stop_mode == PB_STOP_LOOPS) || mfma2_takes_short_cert(N, K, stop_mode, wind)) && P >= mfma2_long_min_p(K) && (stop_mode != PB_STOP_WINDOW || pick_wide(N, K)->S <= 20))
     return mfma2_long_base(P, false) > 0 ? FORM_MFMA2 : ((pick_fast(N, K) && N <= 320) ? FORM_FAST1 : FORM_WIDE);   // (the solve's own backup form)
   if (const FastEntry* se = pick_split(N, K))
     if (!mfma_plain && P >= SPLIT_MIN_P && pair_carries(se, stop_mode, wind) && (stop_mode == PB_STOP_NONE || pick_wide(N, K)))
@@ -629,7 +635,7 @@ int pb_fista_plan_ex(int N, int K, int P, int stop_mode, int wind, unsigned flag
     const int base = mfma4_base(P, (flags & (PB_FLAG_ONE_LAUNCH | PB_FLAG_FORCE_MFMA2)) != 0);
     if (base > 0 && base < P) { nm = base; mf = pb::FORM_MFMA4; tf = FORM_WIDE; }
     else tf = base > 0 ? pb::FORM_MFMA4 : FORM_WIDE;
-  } else if (N >= 1 && K >= 1 && split_shape && !no_mfma && mfma2_serves_long(N, K, stop_mode == PB_STOP_LOOPS) && (P >= mfma2_long_min_p(K) || (flags & PB_FLAG_FORCE_MFMA2)) &&
+  } else if (N >= 1 && K >= 1 && split_shape && !no_mfma && (mfma2_serves_long(N, K, stop_mode == PB_STOP_LOOPS) || mfma2_takes_short_cert(N, K, stop_mode, wind)) && (P >= mfma2_long_min_p(K) || (flags & PB_FLAG_FORCE_MFMA2)) &&
       (stop_mode != PB_STOP_WINDOW || pick_wide(N, K)->S <= 20)) {
     const int base = mfma2_long_base(P, (flags & (PB_FLAG_ONE_LAUNCH | PB_FLAG_FORCE_MFMA2)) != 0);
     const int backup_form = (pick_fast(N, K) && N <= 320) ? FORM_FAST1 : FORM_WIDE;      // what pb_fista_solve uses behind the split form
@@ -896,7 +902,7 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
                           !(flags & (PB_FLAG_FORCE_GENERIC | PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_FORCE_WIDE | PB_FLAG_DIRECT_FIR | PB_FLAG_NO_MFMA));
     const mfma2_launch_fn mfma2_l = four ? ((shape_ok && mfma4_serves(N, K, stop_mode == PB_STOP_LOOPS)) ? pick_mfma4(N, K, stop_mode == PB_STOP_LOOPS) : nullptr)
                                          : ((mfma2 || !lbda_dev || !(stop_mode == PB_STOP_NONE || mfma2_cert || split_loops)) ? mfma2 : pick_mfma2(N, K, stop_mode == PB_STOP_LOOPS));
-    if (mfma2_l && part_ws && (four || (mfma2_serves_long(N, K, stop_mode == PB_STOP_LOOPS) && P >= mfma2_long_min_p(K)))) {
+    if (mfma2_l && part_ws && (four || ((mfma2_serves_long(N, K, stop_mode == PB_STOP_LOOPS) || mfma2_takes_short_cert(N, K, stop_mode, wind)) && P >= mfma2_long_min_p(K)))) {
       const FastEntry* fe1 = pick_fast(N, K);
       const WideEntry* we1 = pick_wide(N, K);
       const bool use_wide = we1 && (!fe1 || N > 320);
@@ -968,7 +974,7 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
       return PB_OK;
     }
   }
-  if (mfma2 && ((flags & PB_FLAG_FORCE_MFMA2) || (mfma2_serves_long(N, K, stop_mode == PB_STOP_LOOPS) && P >= mfma2_long_min_p(K)))) {
+  if (mfma2 && ((flags & PB_FLAG_FORCE_MFMA2) || ((mfma2_serves_long(N, K, stop_mode == PB_STOP_LOOPS) || mfma2_takes_short_cert(N, K, stop_mode, wind)) && P >= mfma2_long_min_p(K)))) {
     const FastEntry* fe1 = pick_fast(N, K);
     const WideEntry* we1 = pick_wide(N, K);
     const bool use_wide = we1 && (!fe1 || N > 320);

@@ -59,7 +59,8 @@ def test_version_and_dispatch_table(lib):
     assert lib.pb_fista_has_fast_path(300, 48) == 1     # short TR: HRFs of up to 48 taps
     assert lib.pb_fista_which_kernel(300, 48, 100000, 0, 0, 6) == 4      # 34..65 taps: matrix-pipe form with three near tiles
     assert lib.pb_fista_which_kernel(300, 48, 100000, 1, 0, 6) == 4      # ... with the cost trace too
-    assert lib.pb_fista_which_kernel(300, 48, 100000, 1, 2, 6) == 1      # ... but not the window-rule certificate: single-row form (no pair form above 32 taps)
+    assert lib.pb_fista_which_kernel(300, 48, 100000, 1, 2, 6) == 5      # ... the window-rule certificate beside three tiles: the split form (round 5)
+    assert lib.pb_fista_which_kernel(200, 48, 100000, 1, 2, 6) == 1      # ... under 225 scans (three blocks per wave): single-row form
     assert lib.pb_fista_has_fast_path(300, 49) == 0
     assert lib.pb_fista_has_fast_path(300, 5000) == 0
     assert lib.pb_fista_has_fast_path(0, 30) == 0
