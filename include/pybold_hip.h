@@ -65,7 +65,7 @@ extern "C" {
 #define PB_FLAG_FORCE_MFMA2 65536u /* the matrix-pipe form with every series split over the waves of a workgroup, one launch:
                                      two waves (fista_mfma2_kernel, 129..640 scans) or four (fista_mfma4_kernel, 641..1280);
                                      HRFs of up to 33 taps: plain, cost trace, window certificate, _loops_deconv rule; 34..65 taps
-                                     (three near tiles, series of 311+ scans): plain, cost trace, window certificate */
+                                     (three near tiles, series of 225+ scans): the same */
 #define PB_FLAG_NO_MFMA 8192u      /* plain solves: never the matrix-pipe form (fista_mfma_kernel), vector forms only */
 #define PB_FLAG_FORCE_CERT 1024u   /* PB_STOP_WINDOW, wind = 6: certificate path whatever tol * n_iter is */
 #define PB_FLAG_NO_PARTITION 4096u  /* never partition a call on the device (see pb_fista_solve_ex): the host-side plan of round 4 */
@@ -104,8 +104,7 @@ int pb_fista_has_fast_path(int N, int K);
  * on the matrix pipe (fista_mfma_kernel: 129..310 scans; HRFs of up to 48 taps, the window-rule certificate up to
  * 33; one lambda for the batch; assumes n_done_dev is given), 5 = the same with every series split over the two waves
  * of a workgroup (fista_mfma2_kernel: small batches, and series of 311..640 scans), 6 = split over the four waves of a
- * workgroup (fista_mfma4_kernel: series of 641..1280 scans; HRFs of up to 33 taps, 34..65 for everything but the
- * _loops_deconv rule).  Host-only query. */
+ * workgroup (fista_mfma4_kernel: series of 641..1280 scans; HRFs of up to 65 taps).  Host-only query. */
 int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mode, int wind);
 
 /* How pb_fista_solve (no flags) lays P problems out: problems [0, *n_main) in one launch of
@@ -176,9 +175,9 @@ int pb_fista_plan_ex(int N, int K, int P, int stop_mode, int wind, unsigned flag
  *   129 .. 310   <= 33     (b)                  (b) certificate          (b) in full           fista_mfma_kernel, one wave per 16 problems
  *   129 .. 310   34 .. 48  (b)                  (b) from 225 scans on    (a)                   ... with three near tiles (certificate: split form)
  *   311 .. 640   <= 33     (b)                  (b) certificate          (b) in full           fista_mfma2_kernel, two waves per 16 problems
- *   311 .. 640   34 .. 48  (b)                  (b) certificate          (a)                   ... with three near tiles
+ *   311 .. 640   34 .. 48  (b)                  (b) certificate          (b) in full           ... with three near tiles
  *   641 .. 1280  <= 33     (b)                  (b) certificate          (b) in full           fista_mfma4_kernel, four waves per 16 problems
- *   641 .. 1280  34 .. 48  (b)                  (b) certificate          (a)                   ... with three near tiles
+ *   641 .. 1280  34 .. 48  (b)                  (b) certificate          (b) in full           ... with three near tiles
  *   longer series, longer HRFs, other windows, a cost trace beside the _loops_deconv rule: (a), one problem per wave up to
  *   2 432 scans, the LDS kernel beyond (and for the window rule beyond 1 280 scans, for 34+ taps beyond 1 280).  Per-problem HRFs (pb_fista_solve_pp, ldt != 0): (a).  A machine-filling batch that lands
  *   on (a) although (b) serves neighbouring shapes is 1.5 .. 4x below the matrix-pipe rate; the Python layer says so once.

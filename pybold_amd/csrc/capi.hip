@@ -101,7 +101,7 @@ namespace {
 typedef int (*mfma2_launch_fn)(const pb::FistaArgs&, const double*, int, bool, hipStream_t);
 // (34 <= K <= 65: three near tiles -- series of 225+ scans (four blocks per wave; the one-wave form carries shorter ones, and
 // everything up to 310 scans but the certificate), plain solves, the cost
-// trace and the certificate: `extras` = _loops_deconv rule / taps from device memory wanted)
+// trace, the certificate and the _loops_deconv rule: `extras` = taps from device memory wanted)
 mfma2_launch_fn pick_mfma2(int N, int K, bool extras = true) {
   static const mfma2_launch_fn tab[] = {
       &pb::launch_mfma2<2, 3>, &pb::launch_mfma2<3, 3>, &pb::launch_mfma2<3, 4>, &pb::launch_mfma2<4, 4>,
@@ -115,7 +115,7 @@ mfma2_launch_fn pick_mfma2(int N, int K, bool extras = true) {
 }
 // the same with one series split over the FOUR waves of a workgroup (fista_mfma4.h): 641 .. 1 280 scans, A = ceil(N / 128)
 // blocks per wave (6 .. 10); K <= 33 with two near tiles: the call shapes of the two-wave form; 34 <= K <= 65 with three: plain
-// solves, the cost trace and the certificate (`extras` = the _loops_deconv rule: not built beside three tiles)
+// solves, the cost trace, the certificate and the _loops_deconv rule (`extras` = taps from device memory: two tiles only)
 mfma2_launch_fn pick_mfma4(int N, int K, bool extras = false) {
   static const mfma2_launch_fn tab[] = {&pb::launch_mfma4<6>, &pb::launch_mfma4<7>, &pb::launch_mfma4<8>, &pb::launch_mfma4<9>,
                                         &pb::launch_mfma4<10>};
@@ -590,9 +590,9 @@ int pb_fista_which_kernel(int N, int K, int P, int with_cost_trace, int stop_mod
   const bool mfma_plain = stop_mode == PB_STOP_NONE && mfma_serves_plain(N, K);
   const bool split_shape = stop_mode == PB_STOP_NONE || (stop_mode == PB_STOP_WINDOW && wind == 6) || (stop_mode == PB_STOP_LOOPS && !with_cost_trace);
   const bool mfma2_ok = (stop_mode == PB_STOP_NONE || (stop_mode == PB_STOP_WINDOW && wind == 6)) && pick_mfma2(N, K) != nullptr;
-  if (split_shape && mfma4_serves(N, K, stop_mode == PB_STOP_LOOPS) && (stop_mode != PB_STOP_WINDOW || pick_wide(N, K)->S <= 20))
+  if (split_shape && mfma4_serves(N, K, false) && (stop_mode != PB_STOP_WINDOW || pick_wide(N, K)->S <= 20))
     return mfma4_base(P, false) > 0 ? pb::FORM_MFMA4 : FORM_WIDE;
-  if (split_shape && (mfma2_serves_long(N, K, stop_mode == PB_STOP_LOOPS) || mfma2_takes_short_cert(N, K, stop_mode, wind)) && P >= mfma2_long_min_p(K) && (stop_mode != PB_STOP_WINDOW || pick_wide(N, K)->S <= 20))
+  if (split_shape && (mfma2_serves_long(N, K, false) || mfma2_takes_short_cert(N, K, stop_mode, wind)) && P >= mfma2_long_min_p(K) && (stop_mode != PB_STOP_WINDOW || pick_wide(N, K)->S <= 20))
     return mfma2_long_base(P, false) > 0 ? FORM_MFMA2 : ((pick_fast(N, K) && N <= 320) ? FORM_FAST1 : FORM_WIDE);   // (the solve's own backup form)
   if (const FastEntry* se = pick_split(N, K))
     if (!mfma_plain && P >= SPLIT_MIN_P && pair_carries(se, stop_mode, wind) && (stop_mode == PB_STOP_NONE || pick_wide(N, K)))
@@ -631,11 +631,11 @@ int pb_fista_plan_ex(int N, int K, int P, int stop_mode, int wind, unsigned flag
                         pick_mfma2(N, K) != nullptr;
   const bool split_shape = stop_mode == PB_STOP_NONE || (stop_mode == PB_STOP_WINDOW && wind == 6) || stop_mode == PB_STOP_LOOPS;
   if (N >= 1 && K >= 1 && P >= 1 && split_shape && !no_mfma &&
-      mfma4_serves(N, K, stop_mode == PB_STOP_LOOPS) && (stop_mode != PB_STOP_WINDOW || pick_wide(N, K)->S <= 20)) {
+      mfma4_serves(N, K, false) && (stop_mode != PB_STOP_WINDOW || pick_wide(N, K)->S <= 20)) {
     const int base = mfma4_base(P, (flags & (PB_FLAG_ONE_LAUNCH | PB_FLAG_FORCE_MFMA2)) != 0);
     if (base > 0 && base < P) { nm = base; mf = pb::FORM_MFMA4; tf = FORM_WIDE; }
     else tf = base > 0 ? pb::FORM_MFMA4 : FORM_WIDE;
-  } else if (N >= 1 && K >= 1 && split_shape && !no_mfma && (mfma2_serves_long(N, K, stop_mode == PB_STOP_LOOPS) || mfma2_takes_short_cert(N, K, stop_mode, wind)) && (P >= mfma2_long_min_p(K) || (flags & PB_FLAG_FORCE_MFMA2)) &&
+  } else if (N >= 1 && K >= 1 && split_shape && !no_mfma && (mfma2_serves_long(N, K, false) || mfma2_takes_short_cert(N, K, stop_mode, wind)) && (P >= mfma2_long_min_p(K) || (flags & PB_FLAG_FORCE_MFMA2)) &&
       (stop_mode != PB_STOP_WINDOW || pick_wide(N, K)->S <= 20)) {
     const int base = mfma2_long_base(P, (flags & (PB_FLAG_ONE_LAUNCH | PB_FLAG_FORCE_MFMA2)) != 0);
     const int backup_form = (pick_fast(N, K) && N <= 320) ? FORM_FAST1 : FORM_WIDE;      // what pb_fista_solve uses behind the split form
@@ -893,16 +893,16 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
   const mfma2_launch_fn mfma2 =
       ((stop_mode == PB_STOP_NONE || mfma2_cert || split_loops) && n_done_dev && (!lbda_dev || (flags & (PB_FLAG_FORCE_MFMA | PB_FLAG_FORCE_MFMA2))) &&
        !(flags & (PB_FLAG_FORCE_GENERIC | PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_FORCE_WIDE | PB_FLAG_DIRECT_FIR |
-                  PB_FLAG_NO_MFMA))) ? pick_mfma2(N, K, stop_mode == PB_STOP_LOOPS) : nullptr;
+                  PB_FLAG_NO_MFMA))) ? pick_mfma2(N, K, false) : nullptr;
   // (round 5) the same call shapes at 311..640 scans, partitioned on the device: dense class on whole passes of the split
   // form, sparse class on the pair form over two slots (or the backup form), handed-back problems compacted
   {
     const bool four = N > 640;                       // 641 .. 1 280 scans: the form split over four waves (fista_mfma4.h)
     const bool shape_ok = (stop_mode == PB_STOP_NONE || mfma2_cert || split_loops) && n_done_dev &&
                           !(flags & (PB_FLAG_FORCE_GENERIC | PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_FORCE_WIDE | PB_FLAG_DIRECT_FIR | PB_FLAG_NO_MFMA));
-    const mfma2_launch_fn mfma2_l = four ? ((shape_ok && mfma4_serves(N, K, stop_mode == PB_STOP_LOOPS)) ? pick_mfma4(N, K, stop_mode == PB_STOP_LOOPS) : nullptr)
-                                         : ((mfma2 || !lbda_dev || !(stop_mode == PB_STOP_NONE || mfma2_cert || split_loops)) ? mfma2 : pick_mfma2(N, K, stop_mode == PB_STOP_LOOPS));
-    if (mfma2_l && part_ws && (four || ((mfma2_serves_long(N, K, stop_mode == PB_STOP_LOOPS) || mfma2_takes_short_cert(N, K, stop_mode, wind)) && P >= mfma2_long_min_p(K)))) {
+    const mfma2_launch_fn mfma2_l = four ? ((shape_ok && mfma4_serves(N, K, false)) ? pick_mfma4(N, K, false) : nullptr)
+                                         : ((mfma2 || !lbda_dev || !(stop_mode == PB_STOP_NONE || mfma2_cert || split_loops)) ? mfma2 : pick_mfma2(N, K, false));
+    if (mfma2_l && part_ws && (four || ((mfma2_serves_long(N, K, false) || mfma2_takes_short_cert(N, K, stop_mode, wind)) && P >= mfma2_long_min_p(K)))) {
       const FastEntry* fe1 = pick_fast(N, K);
       const WideEntry* we1 = pick_wide(N, K);
       const bool use_wide = we1 && (!fe1 || N > 320);
@@ -943,7 +943,7 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
   const mfma2_launch_fn mfma4 =
       ((stop_mode == PB_STOP_NONE || mfma2_cert || split_loops) && n_done_dev && (!lbda_dev || (flags & (PB_FLAG_FORCE_MFMA | PB_FLAG_FORCE_MFMA2))) &&
        !(flags & (PB_FLAG_FORCE_GENERIC | PB_FLAG_NO_PAIR | PB_FLAG_FORCE_PAIR | PB_FLAG_FORCE_WIDE | PB_FLAG_DIRECT_FIR |
-                  PB_FLAG_NO_MFMA)) && mfma4_serves(N, K, stop_mode == PB_STOP_LOOPS)) ? pick_mfma4(N, K, stop_mode == PB_STOP_LOOPS) : nullptr;
+                  PB_FLAG_NO_MFMA)) && mfma4_serves(N, K, false)) ? pick_mfma4(N, K, false) : nullptr;
   if (mfma4) {
     const WideEntry* we1 = pick_wide(N, K);
     if (stop_mode != PB_STOP_WINDOW || we1->S <= 20) {     // (the window rule's re-solve needs the rule's increment ring)
@@ -974,7 +974,7 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
       return PB_OK;
     }
   }
-  if (mfma2 && ((flags & PB_FLAG_FORCE_MFMA2) || ((mfma2_serves_long(N, K, stop_mode == PB_STOP_LOOPS) || mfma2_takes_short_cert(N, K, stop_mode, wind)) && P >= mfma2_long_min_p(K)))) {
+  if (mfma2 && ((flags & PB_FLAG_FORCE_MFMA2) || ((mfma2_serves_long(N, K, false) || mfma2_takes_short_cert(N, K, stop_mode, wind)) && P >= mfma2_long_min_p(K)))) {
     const FastEntry* fe1 = pick_fast(N, K);
     const WideEntry* we1 = pick_wide(N, K);
     const bool use_wide = we1 && (!fe1 || N > 320);

@@ -42,14 +42,14 @@ constexpr size_t mfma2_lds_bytes(int nbm) {
 //   tracked samples per WAVE (eight per problem); implies WITH_J; a problem that cannot be cleared is handed back.
 // LOOPS: the _loops_deconv stop rule in full, as on the one-wave form (fista_mfma.h): each wave adds up its half of the two
 //   norms next to the update, the halves meet in LDS at the barrier that ends the iteration; plain variant only.
-// NT: near tiles -- 2 (K <= 33), or 3 (K <= 65: the tiles reach TWO blocks across the cut; plain solves, the cost trace, the certificate).
+// NT: near tiles -- 2 (K <= 33), or 3 (K <= 65: the tiles reach TWO blocks across the cut; every variant but taps from device memory).
 template <int NBA, int NBB, bool TAPS_DEV, int ROLE, bool WITH_J = false, bool CERT = false, bool LOOPS = false, int NT = 2>
 __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& tp, char* smem) {
   static_assert(!CERT || (WITH_J && !TAPS_DEV), "the certificate runs in the rotated (cost trace) loop");
   static_assert(!LOOPS || (!WITH_J && !TAPS_DEV && !CERT), "the _loops_deconv rule rides the plain variant");
   static_assert(NBB >= NBA && NBB <= NBA + 1 && NBA >= 2 && NBB <= 10, "right half = the larger one; two blocks at least per wave");
   constexpr int NBM = NBB;                         // blocks of the larger half: the size of a wave's fragment area
-  static_assert(NT == 2 || (NT == 3 && !TAPS_DEV && !LOOPS && NBA > 3), "three near tiles: plain, cost trace, certificate; four blocks at least per wave");
+  static_assert(NT == 2 || (NT == 3 && !TAPS_DEV && NBA > 3), "three near tiles: taps as kernel arguments; four blocks at least per wave");
   constexpr int LCW = 32 * NT, NX = NT - 1;        // cumulative taps kept: lags 0 .. 32 NT - 1; NX: blocks of the neighbour the near tiles reach into
   constexpr int NBW = ROLE == 0 ? NBA : NBB;       // blocks of this wave
   constexpr int QOFF = ROLE == 0 ? 0 : NBA;        // its first block within the series
@@ -116,9 +116,8 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
     step = a.step_vec[0];
   } else {
     lc[lane] = tp.c[lane];
-    if constexpr (NT == 3) {
-      if (lane < 32) lc[64 + lane] = tp.c[64 + lane];
-    }
+    // (every lane, the upper half twice: a `lane < 32` mask is one more exec-masked region for the compiler to park registers in)
+    if constexpr (NT == 3) lc[64 + (lane & 31)] = tp.c[64 + (lane & 31)];
   }
   wave_sync();
 
@@ -626,7 +625,7 @@ int launch_mfma2(const FistaArgs& a, const double* taps, int K, bool with_j, hip
   if (!a.n_done) return 1;
   if ((with_j || cert || loops) && a.taps_pp) return 1;
   if (loops && with_j) return 1;                   // (the _loops_deconv rule: plain variant, as on the one-wave form)
-  if (three && (a.taps_pp || loops || NBA <= 3)) return 1;     // (the _loops_deconv rule beside three tiles: 12 .. 16 B of scratch)
+  if (three && (a.taps_pp || NBA <= 3)) return 1;
   const int64_t groups = (launch_count(a) + 15) / 16;
   const dim3 grid((unsigned)groups), block(128);
   const size_t lds = mfma2_lds_bytes(NBB);
@@ -638,7 +637,8 @@ int launch_mfma2(const FistaArgs& a, const double* taps, int K, bool with_j, hip
   const MfmaTaps tp = make_mfma_taps(taps, K);
   if constexpr (NBA > 3) {
     if (three) {
-      if (cert) hipLaunchKernelGGL((fista_mfma2_kernel<NBA, NBB, false, true, true, false, 3>), grid, block, lds, st, a, tp);
+      if (loops) hipLaunchKernelGGL((fista_mfma2_kernel<NBA, NBB, false, false, false, true, 3>), grid, block, lds, st, a, tp);
+      else if (cert) hipLaunchKernelGGL((fista_mfma2_kernel<NBA, NBB, false, true, true, false, 3>), grid, block, lds, st, a, tp);
       else if (with_j) hipLaunchKernelGGL((fista_mfma2_kernel<NBA, NBB, false, true, false, false, 3>), grid, block, lds, st, a, tp);
       else hipLaunchKernelGGL((fista_mfma2_kernel<NBA, NBB, false, false, false, false, 3>), grid, block, lds, st, a, tp);
       return 0;

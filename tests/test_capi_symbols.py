@@ -50,9 +50,10 @@ def test_version_and_dispatch_table(lib):
     assert lib.pb_fista_which_kernel(1200, 28, 2000, 0, 0, 6) == 3      # under 5/8 of a pass: the vector form finishes first
     assert lib.pb_fista_which_kernel(1200, 40, 5000, 0, 0, 6) == 6      # 34+ taps: three near tiles (plain solves, cost trace)
     assert lib.pb_fista_which_kernel(1200, 40, 5000, 1, 2, 6) == 6      # ... the window-rule certificate beside them too
-    assert lib.pb_fista_which_kernel(1200, 40, 5000, 0, 1, 6) == 3      # ... but not the _loops_deconv rule: one problem per wave
+    assert lib.pb_fista_which_kernel(1200, 40, 5000, 0, 1, 6) == 6      # ... and the _loops_deconv rule
     assert lib.pb_fista_which_kernel(600, 42, 20000, 0, 0, 6) == 5      # the same on the two-wave form
-    assert lib.pb_fista_which_kernel(600, 42, 20000, 0, 1, 6) in (1, 3)
+    assert lib.pb_fista_which_kernel(600, 42, 20000, 0, 1, 6) == 5       # ... with the _loops_deconv rule too
+    assert lib.pb_fista_which_kernel(600, 42, 20000, 1, 1, 6) in (1, 3)  # ... a cost trace beside it: vector forms
     assert lib.pb_fista_which_kernel(600, 30, 6000, 0, 1, 6) == 5       # the _loops_deconv rule inside the two-wave form
     assert lib.pb_fista_which_kernel(2400, 28, 5000, 1, 2, 6) == 0      # S = 38: ring too large
     assert lib.pb_fista_has_fast_path(100000, 30) == 0
