@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) PB_MFMA_KATTR void fista_mfma_kernel(FistaArgs
     step = a.step_vec[0];
   } else {
     lc[lane] = tp.c[lane];
-    if constexpr (NT == 3) { if (lane < 32) lc[64 + lane] = tp.c[64 + lane]; }
+    if constexpr (NT == 3) lc[64 + (lane & 31)] = tp.c[64 + (lane & 31)];      // (every lane: no exec-masked region here, fista_mfma4.h says why)
   }
   wave_sync();
 
