@@ -9,7 +9,8 @@ from oracle import c_oracle, pybold_oracle as orc
 from pybold_amd import data, solver
 
 n_scans = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-hrf = orc.spm_hrf(1.0, 1.0, 30.0)[0]
+n_taps = int(sys.argv[2]) if len(sys.argv) > 2 else 30       # (34+: the three-near-tile variants of the matrix-pipe forms)
+hrf = orc.spm_hrf(1.0, 30.0 / n_taps, 30.0)[0][:n_taps]
 N = n_scans
 lip = 0.9 * orc.spectral_radius_est(orc._MatrixFreeH(hrf), np.random.RandomState(0).randn(N))
 step = 1.0 / lip
