@@ -173,7 +173,7 @@ int pb_fista_plan_ex(int N, int K, int P, int stop_mode, int wind, unsigned flag
  *   scans N      taps K    plain / cost trace   window rule, wind 6      _loops_deconv rule    form
  *   <= 128       <= 32     (a)                  (a) certificate          (a)                   two problems per row / single row
  *   129 .. 310   <= 33     (b)                  (b) certificate          (b) in full           fista_mfma_kernel, one wave per 16 problems
- *   129 .. 310   34 .. 48  (b)                  (b) from 225 scans on    (a)                   ... with three near tiles (certificate: split form)
+ *   129 .. 310   34 .. 48  (b)                  (b) from 225 scans on    (b) from 225 scans on ... with three near tiles (stop rules: split form)
  *   311 .. 640   <= 33     (b)                  (b) certificate          (b) in full           fista_mfma2_kernel, two waves per 16 problems
  *   311 .. 640   34 .. 48  (b)                  (b) certificate          (b) in full           ... with three near tiles
  *   641 .. 1280  <= 33     (b)                  (b) certificate          (b) in full           fista_mfma4_kernel, four waves per 16 problems

@@ -355,8 +355,9 @@ inline int mfma2_long_min_p(int K) { return K > 33 ? 2048 : MFMA2_LONG_MIN_P; }
 bool mfma2_serves_long(int N, int K, bool extras = true) { return N > MFMA1_NMAX && pick_mfma2(N, K, extras) != nullptr && pick_wide(N, K) != nullptr; }
 // 225 .. 310 scans with 34+ taps and the window rule: the one-wave form has no certificate beside three near tiles (its state does
 // not fit), the split form has -- it takes such calls like a long series
-bool mfma2_takes_short_cert(int N, int K, int stop_mode, int wind) {
-  return K > 33 && stop_mode == PB_STOP_WINDOW && wind == 6 && N > 224 && N <= MFMA1_NMAX && pick_mfma2(N, K, false) != nullptr && pick_wide(N, K) != nullptr;
+bool mfma2_takes_short_cert(int N, int K, int stop_mode, int wind) {     // (... and the _loops_deconv rule, which the one-wave form lacks there too)
+  return K > 33 && ((stop_mode == PB_STOP_WINDOW && wind == 6) || stop_mode == PB_STOP_LOOPS) && N > 224 && N <= MFMA1_NMAX &&
+         pick_mfma2(N, K, false) != nullptr && pick_wide(N, K) != nullptr;
 }
 int mfma2_long_base(int P, bool one_launch) {
   const int pass = (int)wave_slots() * 4;            // 16 problems x (slots / 2 SIMDs / 2 waves)

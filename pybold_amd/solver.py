@@ -80,9 +80,8 @@ def _warn_if_slow_kernel(lib, N, K, P, want_J, stop, wind, flags):
             why = []                                  # (short series: the pair form is the fast one there)
         elif N > 1280:
             why.append("series of %d scans (matrix-pipe forms: 129..1280)" % N)
-        elif K > 48 or (K > 33 and ((_STOP[stop] == PB_STOP_LOOPS and N <= 310) or (_STOP[stop] == PB_STOP_WINDOW and N <= 224))):
-            why.append("HRF of %d taps (matrix-pipe forms: <= 48 taps; <= 33 with the _loops_deconv rule up to 310 scans and "
-                       "with the window rule up to 224)" % K)
+        elif K > 48 or (K > 33 and _STOP[stop] != PB_STOP_NONE and N <= 224):
+            why.append("HRF of %d taps (matrix-pipe forms: <= 48 taps; <= 33 with a stop rule up to 224 scans)" % K)
         elif _STOP[stop] == PB_STOP_LOOPS and want_J:
             why.append("the _loops_deconv rule with a cost trace")
         elif _STOP[stop] == PB_STOP_WINDOW:

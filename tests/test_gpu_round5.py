@@ -509,7 +509,7 @@ def test_partition_and_guard_for_series_of_1200_scans(solver):
     assert int(nd.min()) == 150 and rel_rows(W[idx].cpu().numpy()[nz], Wo1[nz]).max() < 1e-5
 
 
-@pytest.mark.parametrize("n,k", [(600, 30), (330, 27), (640, 33), (1200, 28), (700, 30), (600, 42), (640, 48), (1200, 42)])
+@pytest.mark.parametrize("n,k", [(600, 30), (330, 27), (640, 33), (1200, 28), (700, 30), (600, 42), (640, 48), (1200, 42), (300, 42)])
 def test_loops_rule_inside_the_split_forms(solver, n, k):
     """`_loops_deconv`'s criterion (pybold/bold_signal.py:267-273) in full inside `fista_mfma2_kernel<..., LOOPS>` (311 .. 640
     scans) and `fista_mfma4_kernel<..., LOOPS>` (641 .. 1 280): every wave adds up its share of the two float64 norms beside the
