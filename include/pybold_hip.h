@@ -368,7 +368,7 @@ int pb_spectral_radius(const double* x0_dev, int N, const double* taps_dev, int 
  *                     ldt = 0: ONE HRF (taps_dev [K]) and ONE step (step_dev [1]) in device
  *                     memory shared by every problem -- the shared-HRF blind step, whose
  *                     taps come out of pb_theta_fit without passing through the host.  With
- *                     n_done_dev, no stop rule and K <= 33 that form runs on the matrix-pipe
+ *                     n_done_dev, no stop rule and K <= 48 that form runs on the matrix-pipe
  *                     kernels (129 .. 1 280 scans: one wave, two or four waves per 16 problems),
  *                     what they hand back on the vector forms; per-problem HRFs: vector forms.
  * pb_hrf_cost_pv      pb_hrf_cost with one HRF per (candidate, voxel):

@@ -1683,10 +1683,10 @@ int pb_fista_solve_pp(const float* y_dev, int64_t ldy, double* w_dev, int64_t ld
   // ONE shared HRF, no stop rule, series of 311 .. 1 280 scans (round 5): whole passes on the matrix-pipe form split over two
   // (up to 640 scans) or four waves, which read the HRF and its step from device memory; the rest, and what the guards hand
   // back, on the one-problem-per-wave form
-  if (N > MFMA1_NMAX && ldt == 0 && stop_mode == PB_STOP_NONE && n_done_dev && K <= MFMA_K2 &&
+  if (N > MFMA1_NMAX && ldt == 0 && stop_mode == PB_STOP_NONE && n_done_dev && K <= 65 &&
       !(flags & (PB_FLAG_FORCE_GENERIC | PB_FLAG_FORCE_PAIR | PB_FLAG_NO_PAIR | PB_FLAG_NO_MFMA | PB_FLAG_FORCE_WIDE | PB_FLAG_DIRECT_FIR))) {
     const bool four = N > 640;
-    const mfma2_launch_fn split = four ? pick_mfma4(N, K, true) : pick_mfma2(N, K, true);
+    const mfma2_launch_fn split = four ? pick_mfma4(N, K, false) : pick_mfma2(N, K, false);
     const WideEntry* we = pick_wide(N, K);
     if (split && we && (four || P >= mfma2_long_min_p(K) || (flags & PB_FLAG_FORCE_MFMA2))) {
       const bool all = (flags & (PB_FLAG_ONE_LAUNCH | PB_FLAG_FORCE_MFMA2)) != 0;

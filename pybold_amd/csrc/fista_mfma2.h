@@ -42,14 +42,14 @@ constexpr size_t mfma2_lds_bytes(int nbm) {
 //   tracked samples per WAVE (eight per problem); implies WITH_J; a problem that cannot be cleared is handed back.
 // LOOPS: the _loops_deconv stop rule in full, as on the one-wave form (fista_mfma.h): each wave adds up its half of the two
 //   norms next to the update, the halves meet in LDS at the barrier that ends the iteration; plain variant only.
-// NT: near tiles -- 2 (K <= 33), or 3 (K <= 65: the tiles reach TWO blocks across the cut; every variant but taps from device memory).
+// NT: near tiles -- 2 (K <= 33), or 3 (K <= 65: the tiles reach TWO blocks across the cut).
 template <int NBA, int NBB, bool TAPS_DEV, int ROLE, bool WITH_J = false, bool CERT = false, bool LOOPS = false, int NT = 2>
 __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& tp, char* smem) {
   static_assert(!CERT || (WITH_J && !TAPS_DEV), "the certificate runs in the rotated (cost trace) loop");
   static_assert(!LOOPS || (!WITH_J && !TAPS_DEV && !CERT), "the _loops_deconv rule rides the plain variant");
   static_assert(NBB >= NBA && NBB <= NBA + 1 && NBA >= 2 && NBB <= 10, "right half = the larger one; two blocks at least per wave");
   constexpr int NBM = NBB;                         // blocks of the larger half: the size of a wave's fragment area
-  static_assert(NT == 2 || (NT == 3 && !TAPS_DEV && NBA > 3), "three near tiles: taps as kernel arguments; four blocks at least per wave");
+  static_assert(NT == 2 || (NT == 3 && NBA > 3), "three near tiles: four blocks at least per wave");
   constexpr int LCW = 32 * NT, NX = NT - 1;        // cumulative taps kept: lags 0 .. 32 NT - 1; NX: blocks of the neighbour the near tiles reach into
   constexpr int NBW = ROLE == 0 ? NBA : NBB;       // blocks of this wave
   constexpr int QOFF = ROLE == 0 ? 0 : NBA;        // its first block within the series
@@ -102,15 +102,20 @@ __device__ __forceinline__ void mfma2_role(const FistaArgs& a, const MfmaTaps& t
   double step = a.step, g_scale = tp.g_scale;
   float y_scale = tp.y_scale;
   if constexpr (TAPS_DEV) {
-    double run = 0.0;
+    double run = 0.0, run2 = 0.0;
     for (int k = 0; k <= lane && k < a.K; ++k) run += (double)(float)a.taps_pp[k];
     float cm = fabsf((float)run);
+    if constexpr (NT == 3) {                       // lags 64 .. 95, every lane for lag 64 + (lane & 31): the store below stays unmasked
+      for (int k = 0; k <= 64 + (lane & 31) && k < a.K; ++k) run2 += (double)(float)a.taps_pp[k];
+      cm = fmaxf(cm, fabsf((float)run2));
+    }
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) cm = fmaxf(cm, __shfl_xor(cm, o, 64));
     int e = 0;
     if (cm > 0.0f) (void)frexpf(cm, &e);
     const int sa = 3 - e;
     lc[lane] = (float)ldexp(run, sa);
+    if constexpr (NT == 3) lc[64 + (lane & 31)] = (float)ldexp(run2, sa);
     g_scale = ldexp(1.0, -2 * sa);
     y_scale = ldexpf(1.0f, sa);
     step = a.step_vec[0];
@@ -625,12 +630,18 @@ int launch_mfma2(const FistaArgs& a, const double* taps, int K, bool with_j, hip
   if (!a.n_done) return 1;
   if ((with_j || cert || loops) && a.taps_pp) return 1;
   if (loops && with_j) return 1;                   // (the _loops_deconv rule: plain variant, as on the one-wave form)
-  if (three && (a.taps_pp || NBA <= 3)) return 1;
+  if (three && NBA <= 3) return 1;
   const int64_t groups = (launch_count(a) + 15) / 16;
   const dim3 grid((unsigned)groups), block(128);
   const size_t lds = mfma2_lds_bytes(NBB);
   if (a.taps_pp) {                                 // shared HRF and step in device memory (the blind step's z-step)
     const MfmaTaps none{};
+    if constexpr (NBA > 3) {
+      if (three) {
+        hipLaunchKernelGGL((fista_mfma2_kernel<NBA, NBB, true, false, false, false, 3>), grid, block, lds, st, a, none);
+        return 0;
+      }
+    }
     hipLaunchKernelGGL((fista_mfma2_kernel<NBA, NBB, true>), grid, block, lds, st, a, none);
     return 0;
   }

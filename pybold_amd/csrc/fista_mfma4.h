@@ -41,7 +41,6 @@ __device__ __forceinline__ void mfma4_role(const FistaArgs& a, const MfmaTaps& t
   static_assert(!CERT || (WITH_J && !TAPS_DEV), "the certificate runs in the rotated (cost trace) loop");
   static_assert(!LOOPS || (!WITH_J && !TAPS_DEV && !CERT), "the _loops_deconv rule rides the plain variant");
   static_assert(NT == 2 || NT == 3, "two near tiles (K <= 33) or three (K <= 65)");
-  static_assert(NT == 2 || !TAPS_DEV, "three near tiles: taps as kernel arguments");
   static_assert(NBW > NT && NBW <= 10, "more blocks per wave than near tiles (a tile reaches the neighbour only), ten at most");
   constexpr int NW = MFMA4_WAVES;
   constexpr int LCW = 32 * NT, LCS = 96;             // cumulative taps kept: lags 0 .. 32 NT - 1 (LCS: a wave's slice of the area)
@@ -94,15 +93,20 @@ __device__ __forceinline__ void mfma4_role(const FistaArgs& a, const MfmaTaps& t
   double step = a.step, g_scale = tp.g_scale;
   float y_scale = tp.y_scale;
   if constexpr (TAPS_DEV) {
-    double run = 0.0;
+    double run = 0.0, run2 = 0.0;
     for (int kk = 0; kk <= lane && kk < a.K; ++kk) run += (double)(float)a.taps_pp[kk];
     float cm = fabsf((float)run);
+    if constexpr (NT == 3) {                       // lags 64 .. 95, every lane for lag 64 + (lane & 31): the store below stays unmasked
+      for (int kk = 0; kk <= 64 + (lane & 31) && kk < a.K; ++kk) run2 += (double)(float)a.taps_pp[kk];
+      cm = fmaxf(cm, fabsf((float)run2));
+    }
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) cm = fmaxf(cm, __shfl_xor(cm, o, 64));
     int e = 0;
     if (cm > 0.0f) (void)frexpf(cm, &e);
     const int sa = 3 - e;
     lc[lane] = (float)ldexp(run, sa);
+    if constexpr (NT == 3) lc[64 + (lane & 31)] = (float)ldexp(run2, sa);
     g_scale = ldexp(1.0, -2 * sa);
     y_scale = ldexpf(1.0f, sa);
     step = a.step_vec[0];
@@ -651,7 +655,7 @@ __global__ __launch_bounds__(256) void fista_mfma4_kernel(FistaArgs a, MfmaTaps 
 }
 
 // Plain solves, with or without the cost trace, the window rule (wind = 6) as a no-fire certificate, the _loops_deconv rule
-// in full (no cost trace); HRFs of up to 33 taps -- 34 .. 65 with three near tiles: all of these --; 128 (A - 1) < N <= 128 A: the series ends in one of the last wave's last four blocks.  Shared HRF in device memory
+// in full (no cost trace); HRFs of up to 33 taps -- 34 .. 65 with three near tiles --; 128 (A - 1) < N <= 128 A: the series ends in one of the last wave's last four blocks.  Shared HRF in device memory
 // (the blind step's z-step): plain only.
 template <int A>
 int launch_mfma4(const FistaArgs& a, const double* taps, int K, bool with_j, hipStream_t st) {
@@ -661,7 +665,6 @@ int launch_mfma4(const FistaArgs& a, const double* taps, int K, bool with_j, hip
   if (!a.n_done) return 1;
   if ((with_j || cert || loops) && a.taps_pp) return 1;
   if (loops && with_j) return 1;                   // (the _loops_deconv rule: plain variant, as on the one-wave form)
-  if (three && a.taps_pp) return 1;
   const int64_t groups = (launch_count(a) + 15) / 16;
   const dim3 grid((unsigned)groups), block(256);
   const size_t lds = mfma4_lds_bytes(A);
@@ -670,7 +673,8 @@ int launch_mfma4(const FistaArgs& a, const double* taps, int K, bool with_j, hip
     if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kernel, grid, block, lds, st, a, a.taps_pp ? MfmaTaps{} : make_mfma_taps(taps, K));
   };
-  if (three) go(loops ? fista_mfma4_kernel<A, false, false, false, true, 3> : cert ? fista_mfma4_kernel<A, false, true, true, false, 3>
+  if (three && a.taps_pp) go(fista_mfma4_kernel<A, true, false, false, false, 3>);
+  else if (three) go(loops ? fista_mfma4_kernel<A, false, false, false, true, 3> : cert ? fista_mfma4_kernel<A, false, true, true, false, 3>
                      : (with_j ? fista_mfma4_kernel<A, false, true, false, false, 3> : fista_mfma4_kernel<A, false, false, false, false, 3>));
   else if (a.taps_pp) go(fista_mfma4_kernel<A, true>);
   else if (loops) go(fista_mfma4_kernel<A, false, false, false, true>);

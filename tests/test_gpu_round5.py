@@ -554,11 +554,12 @@ def test_loops_rule_inside_the_split_forms(solver, n, k):
     assert rel_rows(Wl[:V].cpu().numpy()[ok], Wo[ok]).max() < 1e-5
 
 
-@pytest.mark.parametrize("n,k,P", [(600, 27, 8192 + 150), (1200, 28, 4096 + 90), (400, 20, 6000)])
+@pytest.mark.parametrize("n,k,P", [(600, 27, 8192 + 150), (1200, 28, 4096 + 90), (400, 20, 6000), (600, 40, 8192 + 150), (1000, 44, 4096 + 90)])
 def test_shared_hrf_z_step_of_long_series_on_the_split_forms(solver, n, k, P):
     """`pb_fista_solve_pp` with ONE HRF and step in device memory (the blind step's z-step, bd_shared) at 321 .. 1 280 scans:
     whole passes on `fista_mfma2_kernel<..., TAPS_DEV>` / `fista_mfma4_kernel<..., TAPS_DEV>`, the rest and what the guards
-    hand back on the one-problem-per-wave form -- against the float64 oracle and against the vector dispatch."""
+    hand back on the one-problem-per-wave form -- against the float64 oracle and against the vector dispatch; HRFs of 34+ taps
+    with three near tiles (the cumulative taps beyond lag 63 built on the device)."""
     rng = np.random.RandomState(n + k)
     h = orc.spm_hrf(0.9, 20.0 / k, 20.0, False)[0][:k]            # (a 20 s HRF sampled at k points)
     assert len(h) == k

@@ -42,7 +42,7 @@ def test_no_spill_under_a_partial_exec_mask(listings, target):
 def test_no_matrix_pipe_variant_uses_scratch():
     """Every instantiation capi.hip can dispatch -- fista_mfma_kernel<5..10> x {plain, cost trace, certificate, taps from
     device memory, three near tiles, _loops_deconv rule}, fista_mfma2_kernel<a,b> and fista_mfma4_kernel<6..10> x {plain,
-    cost trace, certificate, taps from device memory, _loops_deconv rule, three near tiles}: 225 kernels -- runs without scratch (two explicit allowances of 8 B per lane, tools/mfma_register_table.py: ALLOW).  (Round 4 shipped `<10, ..., LOOPS>` with 156 B per
+    cost trace, certificate, taps from device memory, _loops_deconv rule, three near tiles}: 243 kernels -- runs without scratch (two explicit allowances of 8 B per lane, tools/mfma_register_table.py: ALLOW).  (Round 4 shipped `<10, ..., LOOPS>` with 156 B per
     lane: store addresses of the in-loop write-out hoisted out of the solve loop.)  The reports are written by the compile
     that makes each object (csrc/Makefile)."""
     if subprocess.call(["which", "hipcc"], stdout=subprocess.DEVNULL) != 0 and not os.path.exists("/opt/rocm/bin/hipcc"):
