@@ -1,8 +1,8 @@
-"""CPU-only (hipcc cross-compiles): the ISA listings of the matrix-pipe kernels carry no register spill inside an
+"""CPU-only (hipcc cross-compiles): the matrix-pipe kernels of the build carry no register spill inside an
 exec-masked region -- the code-generation hazard that broke the certificate variant of the split form in round 4
 (a VGPR -> AGPR spill executed under an EMPTY exec mask on a cold start: its reload, an LDS address, was garbage;
-DESIGN 5.0b) -- and no scratch.  tools/isa_spill_lint.py is the check; `make -C pybold_amd/csrc build/mfma2_8_9.s`
-etc. produce the listings."""
+DESIGN 5.0b) -- and no scratch.  tools/isa_spill_lint.py is the check (on the disassembled objects; `make -C pybold_amd/csrc
+build/mfma2_8_9.s` etc. produce annotated listings for reading)."""
 import os
 import re
 import subprocess
@@ -14,29 +14,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "pybold_amd", "csrc")
 
 
-LISTINGS = ["mfma2_8_9", "mfma_10", "mfma4_10"]
-
-
-@pytest.fixture(scope="module")
-def listings():
-    """The three listings in ONE parallel make (about a minute each on one core)."""
+def test_no_spill_under_a_partial_exec_mask():
+    """Every matrix-pipe object of the build (fista_mfma / mfma2 / mfma4 kernels, all variants): the gfx950 code object is
+    extracted from the object file and disassembled (`llvm-objdump`, a second per file -- the code that ships, not a second
+    compile), tools/isa_spill_lint.py scans it for accumulator-register writes inside exec-masked regions."""
     if subprocess.call(["which", "hipcc"], stdout=subprocess.DEVNULL) != 0 and not os.path.exists("/opt/rocm/bin/hipcc"):
         pytest.skip("no hipcc")
-    subprocess.check_call(["make", "-s", "-j4", "-C", CSRC] + ["build/%s.s" % t for t in LISTINGS])
-
-
-@pytest.mark.parametrize("target", LISTINGS)
-def test_no_spill_under_a_partial_exec_mask(listings, target):
-    lst = os.path.join(CSRC, "build", target + ".s")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_spill_lint.py"), lst], capture_output=True, text=True)
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("no llvm-objdump")
+    subprocess.check_call(["make", "-s", "-j8", "-C", CSRC])
+    import glob
+    objs = sorted(glob.glob(os.path.join(CSRC, "build", "mfma*.o")))
+    assert len(objs) >= 27, objs
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_spill_lint.py")] + objs, capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
-    # the variants that matter run without scratch (the plain ones of both kernels, the split form's cost-trace / certificate ones)
-    res = open(os.path.join(CSRC, "build", target + ".res")).read()
-    names = re.findall(r"Function Name: (\S+)", res)
-    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", res)]
-    assert len(names) == len(scratch) and len(names) >= 4
-    plain = [s for n, s in zip(names, scratch) if n.endswith("ILi10ELb0ELb0ELb0ELi2ELb0EEEvNS_9FistaArgsENS_8MfmaTapsE") or "mfma2_kernel" in n or "mfma4_kernel" in n]
-    assert plain and max(plain) == 0, list(zip(names, scratch))
 
 
 def test_no_matrix_pipe_variant_uses_scratch():

@@ -4,18 +4,41 @@ that restores the mask).  Lanes outside the mask are not saved; with an empty ma
 garbage.  Scans `*.s` listings (make build/mfma_10.s, build/mfma2_9_10.s ...) kernel by kernel; regions longer than
 SPAN lines are taken to be whole-body masks (an early `return` of a wave) and ignored.
 
-usage: python tools/isa_spill_lint.py pybold_amd/csrc/build/*.s      (exit code 1 when a kernel has such a write)
+usage: python tools/isa_spill_lint.py pybold_amd/csrc/build/*.s | build/mfma*.o      (exit code 1 when a kernel has such a write)
 """
+import glob
+import os
 import re
+import subprocess
 import sys
+
+OBJDUMP = os.environ.get("LLVM_OBJDUMP", "/opt/rocm/lib/llvm/bin/llvm-objdump")
+
+
+def listing(path):
+    """Lines of a `.s` listing, or -- for an object file of the build -- the disassembly of its gfx950 code object
+    (`llvm-objdump --offloading` extracts it next to the object, `-d` disassembles it: a second per file, and it is
+    the code that ships, not a second compile)."""
+    if not path.endswith(".o"):
+        return open(path)
+    subprocess.check_call([OBJDUMP, "--offloading", path], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    parts = glob.glob(path + ".*")
+    try:
+        co = [f for f in parts if "amdgcn" in f]
+        assert co, "no device code object in " + path
+        return subprocess.run([OBJDUMP, "-d", co[0]], capture_output=True, text=True, check=True).stdout.splitlines()
+    finally:
+        for f in parts:
+            os.remove(f)
+
 
 SPAN = 300
 bad = 0
 for path in sys.argv[1:]:
     kernel, stack, hits = None, [], {}
-    for n, line in enumerate(open(path), 1):
+    for n, line in enumerate(listing(path), 1):
         s = line.strip()
-        m = re.match(r"^(_ZN2pb\w+):", s)
+        m = re.match(r"^(?:[0-9a-f]+ <)?(_ZN2pb\w+)>?:", s)
         if m:
             kernel, stack = m.group(1), []
             continue
