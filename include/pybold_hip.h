@@ -231,7 +231,7 @@ int pb_fista_solve(const float* y_dev, int64_t ldy, int y_rep,
  *     gamma_2 = lmax_v / (||y_v||_2 sum|c| / sqrt(N)),   c = cumsum(taps)        (block signals at SNR 1 dB: 0.16 .. 0.5)
  * -- a series most of whose energy the operator does not see (alternating signs, fast sinusoids, a signal under a strong fast
  * carrier) loses digits in every arithmetic narrower than float64: gamma_2 < 1e-2 -> float64 (fista_exact_kernel on their list; the LDS kernel, which needs taps_dev, for a window other than 6),
- * gamma_2 < 7e-2 -> the float32 vector forms whatever lambda, never (b).  5 120 such series per length through this entry point:
+ * gamma_2 < 7e-2 (3e-2 for 311..640 scans, 2e-2 for 641..1280, HRFs of up to 33 taps) -> the float32 vector forms whatever lambda, never (b).  5 120 such series per length through this entry point:
  * worst 2.9e-6 / 3.7e-6 on diff_z, z, x; without the guard 4e-4 on (b) and 5e-3 on (a) (profiles/r5_gamma_calibration_*.txt).
  * PB_FLAG_NO_ILL_GUARD switches it off.  Calls that are not partitioned are not guarded.
  *

@@ -393,6 +393,16 @@ WorkLayout work_layout(int P, int V) {
 // coherence bounds of the conditioning guard (path.h: path_class; calibrated on 5 120 series per length,
 // profiles/r5_gamma_calibration_*.txt: above them the matrix-pipe form holds 3.3e-6 and the float32 vector forms 3e-6)
 constexpr double PART_GAMMA_F64 = 1.0e-2, PART_GAMMA_MATRIX_PIPE = 7.0e-2;
+// The bound below which a series stays off the matrix pipe, by shape: the error of the matrix-pipe forms at a given coherence falls
+// with the length of the series (profiles/r5_gamma_calibration_*.txt, worst over the adversarial families per bin of gamma_2:
+// 300 scans 4.8e-6 in [5e-2, 7e-2) and 6.7e-6 below; 600 scans 3.7e-6 in [3e-2, 5e-2), 4.9e-6 in [2e-2, 3e-2); 1 200 scans 5.4e-6 in
+// [2e-2, 3e-2), 4.5e-6 in [1e-2, 2e-2); with 34+ taps 8.2e-6 in [5e-2, 7e-2) at 300 scans) -- and white noise, whose own error is
+// 2e-6 at most, has a median gamma_2 of 6e-2 / 4e-2 / 3e-2 at 300 / 600 / 1 200 scans: one bound for every length kept nearly
+// every noise-like series of 1 200 scans on the vector forms.
+inline double part_gamma_matrix_pipe(int N, int K) {
+  if (K > 33 || N <= 310) return PART_GAMMA_MATRIX_PIPE;
+  return N <= 640 ? 3.0e-2 : 2.0e-2;
+}
 // below this many problems a call is latency-bound and keeps the host-side plan (a partition costs ~8 small launches)
 constexpr int PART_MIN_P = 4096;
 
@@ -778,7 +788,7 @@ static int solve_impl(const float* y_dev, int64_t ldy, int y_rep, double* w_dev,
       const bool guard = !(flags & PB_FLAG_NO_ILL_GUARD);
       const double unit = csum / std::sqrt((double)N);
       const float f64_bound = (guard && (ill_exact() || (taps_dev && nd_g <= LDS_DOUBLES_MAX))) ? (float)(PART_GAMMA_F64 * unit) : 0.0f;
-      const float vec_bound = guard ? (float)(PART_GAMMA_MATRIX_PIPE * unit) : 0.0f;
+      const float vec_bound = guard ? (float)(part_gamma_matrix_pipe(N, K) * unit) : 0.0f;
       const dim3 grid((unsigned)((V_series + 3) / 4)), block(256);
       if (N <= 320) hipLaunchKernelGGL((pb::lmax_wave_kernel<5>), grid, block, 4 * (64 * 5 + pb::LMAX_KT) * sizeof(float), user, y_dev, ldy, V_series, N, lt, K, lm, f64_bound, vec_bound);
       else if (N <= 640) hipLaunchKernelGGL((pb::lmax_wave_kernel<10>), grid, block, 4 * (64 * 10 + pb::LMAX_KT) * sizeof(float), user, y_dev, ldy, V_series, N, lt, K, lm, f64_bound, vec_bound);
